@@ -1,0 +1,283 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory from the importable Python
+reference (icyveins7/pydsproutines mounted read-only at /root/reference).
+
+Run ONLY in the build container:
+
+    python tests/golden/make_golden.py
+
+The fixtures are data: seeded inputs plus the reference's outputs for them.
+No reference source travels.  The GPU box and the `-m gpu` tests read only the
+committed ``*.npz`` files.  While generating, the script also prints how far
+the repo's own oracle (``oracle/``) is from the reference on every fixture.
+"""
+
+import os
+import sys
+import contextlib
+import io
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("PYDSP_REFERENCE", "/root/reference")
+
+os.environ.setdefault("MPLBACKEND", "Agg")
+sys.path.insert(0, REPO)
+sys.path.insert(0, REF)
+
+with contextlib.redirect_stdout(io.StringIO()):
+    import xcorrRoutines as R  # noqa: E402  (the reference)
+    import spectralRoutines as RS  # noqa: E402
+    import signalCreationRoutines as RC  # noqa: E402
+
+import oracle as O  # noqa: E402
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def cn(rng, n, dtype=np.complex64):
+    return ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) / np.sqrt(2)).astype(dtype)
+
+
+def qpsk(rng, n, dtype=np.complex64):
+    return np.exp(1j * (np.pi / 4 + np.pi / 2 * rng.integers(0, 4, n))).astype(dtype)
+
+
+def report(name, ref, mine):
+    ref = np.asarray(ref)
+    mine = np.asarray(mine)
+    if ref.dtype.kind in "iu":
+        d = int(np.sum(ref != mine))
+        print("  %-34s index mismatches: %d / %d" % (name, d, ref.size))
+        return d
+    err = float(np.max(np.abs(ref - mine))) if ref.size else 0.0
+    print("  %-34s max|ref-oracle| = %.3e (max|ref| %.3e)" % (name, err, float(np.max(np.abs(ref))) if ref.size else 0))
+    return err
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print("wrote %s (%.1f KiB)" % (path, os.path.getsize(path) / 1024))
+
+
+def gen_fastxcorr():
+    rng = np.random.default_rng(101)
+    n, m = 64, 600
+    rx = cn(rng, m)
+    cut = (rx[100 : 100 + n] * np.complex64(1.7 - 0.3j)).copy()
+    # put a frequency offset of +5 bins on a second copy at delay 300
+    rx[300 : 300 + n] += (cut * np.exp(2j * np.pi * 5 * np.arange(n) / n)).astype(np.complex64)
+    sub = np.arange(7, 500, 11)
+    out = {"cutout": cut, "rx": rx, "shifts_sub": sub}
+    print("fastXcorr (N=%d, M=%d)" % (n, m))
+    for tag, sh in (("all", None), ("sub", sub)):
+        a = quiet(R.fastXcorr, cut, rx, shifts=sh)
+        ac = quiet(R.fastXcorr, cut, rx, shifts=sh, absResult=False)
+        b, bi = quiet(R.fastXcorr, cut, rx, freqsearch=True, shifts=sh)
+        bc, bci = quiet(R.fastXcorr, cut, rx, freqsearch=True, shifts=sh, absResult=False)
+        c = quiet(R.fastXcorr, cut, rx, freqsearch=True, outputCAF=True, shifts=sh)
+        cc = quiet(R.fastXcorr, cut, rx, freqsearch=True, outputCAF=True, shifts=sh, absResult=False)
+        out.update({
+            "A_" + tag: a, "Ac_" + tag: ac, "B_" + tag: b, "Bi_" + tag: bi,
+            "Bc_" + tag: bc, "Bci_" + tag: bci, "C_" + tag: c, "Cc_" + tag: cc,
+        })
+        report("A " + tag, a, O.fastXcorr(cut, rx, shifts=sh))
+        report("A' " + tag, ac, O.fastXcorr(cut, rx, shifts=sh, absResult=False))
+        ob, obi = O.fastXcorr(cut, rx, freqsearch=True, shifts=sh)
+        report("B " + tag, b, ob)
+        report("B idx " + tag, bi, obi)
+        obc, obci = O.fastXcorr(cut, rx, freqsearch=True, shifts=sh, absResult=False)
+        report("B' " + tag, bc, obc)
+        report("B' idx " + tag, bci, obci)
+        report("C " + tag, c, O.fastXcorr(cut, rx, freqsearch=True, outputCAF=True, shifts=sh))
+        report("C' " + tag, cc, O.fastXcorr(cut, rx, freqsearch=True, outputCAF=True, shifts=sh, absResult=False))
+    # complex128 inputs (the TCC unit test upgrades to 64-bit, xcorrRoutines.py:2180-2184)
+    a128 = quiet(R.fastXcorr, cut.astype(np.complex128), rx.astype(np.complex128))
+    out["A_all_c128"] = a128
+    report("A all (c128)", a128, O.fastXcorr(cut.astype(np.complex128), rx.astype(np.complex128)))
+    save("fastxcorr_small", **out)
+
+
+def gen_kat2():
+    # inputs of cython_ext/CyIppXcorrFFT/test_IppXcorrFFT.cpp:9-32 (SURVEY KAT-2)
+    i = np.arange(100)
+    data = (i + 1j * (i + 1)).astype(np.complex64)
+    cut = data[20:50].copy()
+    sh = np.arange(0, 70, 3)
+    q, fi = quiet(R.fastXcorr, cut, data, freqsearch=True, shifts=sh)
+    print("KAT-2")
+    oq, ofi = O.fastXcorr(cut, data, freqsearch=True, shifts=sh)
+    report("qf2", q, oq)
+    report("freqidx", fi, ofi)
+    pk, pfi = O.IppXcorrFFT(cut).xcorr(data, 0, 100, 3)
+    report("IppXcorrFFT restatement (in range)", q.astype(np.float32), pk[:24])
+    assert np.all(pk[24:] == 0) and np.all(pfi[24:] == 0)
+    save("kat2_ippxcorrfft", data=data, cutout=cut, shifts=sh, qf2=q, freqidx=fi)
+
+
+def gen_kat1_kat3():
+    # KAT-1: pybinds/ippGroupXcorrCZT/test.py:4,23-32
+    data = np.arange(200, dtype=np.float32).view(np.complex64)
+    starts = np.array([10, 70])
+    lengths = np.array([10, 12])
+    g = R.GroupXcorrCZT(data, starts, lengths, -0.1, 0.1, 0.1, 100)
+    sh = np.array([9, 10, 11])
+    xc, f = g.xcorr(data, sh)
+    print("KAT-1")
+    og = O.GroupXcorrCZT(data, starts, lengths, -0.1, 0.1, 0.1, 100)
+    oxc, of = og.xcorr(data, sh)
+    report("GroupXcorrCZT qf2", xc, oxc)
+    report("freq", f, of)
+    report("ystackNormSq", np.array([g.ystackNormSq]), np.array([og.ystackNormSq]))
+    # KAT-3: pybinds/ippCZT/test.py:14-47
+    x = (np.arange(10) + 1j * np.arange(10)).astype(np.complex64)
+    cz = RS.CZTCached(10, -1, 1, 0.1, 10, convertTo32fc=True)
+    y = cz.run(x)
+    ocz = O.CZTCached(10, -1, 1, 0.1, 10, convertTo32fc=True)
+    print("KAT-3  k=%d nfft=%d" % (cz.k, cz.nfft))
+    report("CZTCached.run", y, ocz.run(x))
+    assert (ocz.k, ocz.nfft) == (cz.k, cz.nfft)
+    save("kat1_kat3_czt", kat1_data=data, kat1_starts=starts, kat1_lengths=lengths, kat1_shifts=sh,
+         kat1_qf2=xc, kat1_freq=f, kat1_ynormsq=np.array([g.ystackNormSq]),
+         kat3_x=x, kat3_y=y, kat3_k=np.array([cz.k]), kat3_nfft=np.array([cz.nfft]),
+         kat3_ww=cz.ww, kat3_fv=cz.fv, kat3_aa=cz.aa)
+
+
+def gen_czt():
+    rng = np.random.default_rng(202)
+    n, m = 96, 700
+    fs = 1000.0
+    rx = cn(rng, m)
+    cut = rx[200 : 200 + n].copy()
+    rx[200 : 200 + n] *= np.exp(2j * np.pi * 3.3 * np.arange(n) / fs).astype(np.complex64)
+    sh = np.arange(150, 260, 3)
+    caf, f = quiet(R.cztXcorr, cut, rx, -20.0, 20.0, fs, cztStep=0.5, outputCAF=True, shifts=sh)
+    res, fpk = quiet(R.cztXcorr, cut, rx, -20.0, 20.0, fs, cztStep=0.5, outputCAF=False, shifts=sh)
+    print("cztXcorr")
+    ocaf, of = O.cztXcorr(cut, rx, -20.0, 20.0, fs, cztStep=0.5, outputCAF=True, shifts=sh)
+    ores, ofpk = O.cztXcorr(cut, rx, -20.0, 20.0, fs, cztStep=0.5, outputCAF=False, shifts=sh)
+    report("CAF", caf, ocaf)
+    report("freqs", f, of)
+    report("flattened value", res, ores)
+    report("flattened freq", fpk, ofpk)
+    # stand-alone czt + CZTCached on random data, f64 and 32fc constants
+    x = cn(rng, 300, np.complex128)
+    y1 = RS.czt(x, -30.0, 30.0, 0.25, fs)
+    cz = RS.CZTCached(300, -30.0, 30.0, 0.25, fs)
+    y2 = cz.run(x)
+    report("czt", y1, O.czt(x, -30.0, 30.0, 0.25, fs))
+    report("CZTCached.run f64", y2, O.CZTCached(300, -30.0, 30.0, 0.25, fs).run(x))
+    xm = cn(rng, 5 * 300).reshape(5, 300)
+    cz32 = RS.CZTCached(300, -30.0, 30.0, 0.25, fs, convertTo32fc=True)
+    ym = cz32.runMany(xm)
+    report("CZTCached.runMany 32fc", ym, O.CZTCached(300, -30.0, 30.0, 0.25, fs, convertTo32fc=True).runMany(xm))
+    save("cztxcorr_small", cutout=cut, rx=rx, shifts=sh, fs=np.array([fs]), caf=caf, freqs=f, res=res, fpk=fpk,
+         czt_x=x, czt_y=y1, cached_y=y2, many_x=xm, many_y=ym)
+
+
+def gen_group():
+    rng = np.random.default_rng(303)
+    fs = 2048.0
+    m = 3000
+    y = qpsk(rng, 900)
+    starts = np.array([100, 400, 650])
+    lengths = np.array([128, 100, 128])
+    rx = (0.5 * cn(rng, m)).astype(np.complex64)
+    d0 = 777
+    tone = np.exp(2j * np.pi * 6.0 * np.arange(900) / fs)
+    for s, l in zip(starts, lengths):
+        rx[d0 + s - starts[0] : d0 + s - starts[0] + l] += (y[s : s + l] * tone[s - starts[0] : s - starts[0] + l]).astype(np.complex64)
+    freqs = np.arange(-16.0, 16.0, 1.0)
+    sh = np.arange(700, 860)
+    g = R.GroupXcorr(y, starts, lengths, freqs, fs)
+    xc, fpk = g.xcorr(rx, sh)
+    print("GroupXcorr")
+    og = O.GroupXcorr(y, starts, lengths, freqs, fs)
+    oxc, ofpk = og.xcorr(rx, sh)
+    report("xc", xc, oxc)
+    report("freqpeaks", fpk, ofpk)
+    # equal-length groups on the makeFreq grid: GroupXcorrFFT == GroupXcorr(freqs=makeFreq)
+    L, fftlen = 128, 256
+    st2 = np.array([50, 300, 600])
+    yg = np.stack([y[s : s + L] for s in st2])
+    rx2 = (0.5 * cn(rng, m)).astype(np.complex64)
+    for s in st2:
+        rx2[500 + s - st2[0] : 500 + s - st2[0] + L] += y[s : s + L]
+    sh2 = np.arange(440, 560)
+    mf = RC.makeFreq(fftlen, fs)
+    g2 = R.GroupXcorr(y, st2, np.array([L, L, L]), mf, fs)
+    xc2, fpk2 = g2.xcorr(rx2, sh2)
+    of = O.GroupXcorrFFT(yg, st2, fs, fftlen=fftlen)
+    oxc2, ofi2 = of.xcorr(rx2, sh2)
+    report("GroupXcorrFFT vs GroupXcorr(makeFreq)", xc2, oxc2)
+    report("  freq", fpk2, mf[ofi2])
+    save("groupxcorr_small", y=y, starts=starts, lengths=lengths, rx=rx, freqs=freqs, fs=np.array([fs]), shifts=sh,
+         xc=xc, freqpeaks=fpk, st2=st2, yg=yg, rx2=rx2, sh2=sh2, fftlen=np.array([fftlen]), xc2=xc2, fpk2=fpk2)
+
+
+def gen_c2_mini():
+    """Scaled-down config C2: N=256 template, M=8192 rx, F=32 on-grid bins, 0 dB SNR, planted
+    at (d0, k0); golden = the reference's own CAF columns."""
+    rng = np.random.default_rng(404)
+    n, m, k0, d0 = 256, 8192, 5, 3000
+    t = qpsk(rng, n)
+    rx = cn(rng, m)
+    rx[d0 : d0 + n] += (t * np.exp(2j * np.pi * k0 * np.arange(n) / n)).astype(np.complex64)
+    bins = np.arange(-16, 16)
+    sh = np.concatenate((np.arange(0, 64), np.arange(d0 - 40, d0 + 40), np.arange(m - n + 1 - 64, m - n + 1)))
+    caf = quiet(R.fastXcorr, t, rx, freqsearch=True, outputCAF=True, shifts=sh)[:, np.mod(bins, n)]
+    g = R.GroupXcorr(t, np.array([0]), np.array([n]), bins * (float(n) / n), float(n))
+    xc, fpk = g.xcorr(rx, sh[:-1])
+    print("C2-mini")
+    report("caf_bins", caf, O.caf_bins(t, rx, bins, sh))
+    report("overlap-save (same algorithm, CPU)", caf, O.caf_overlap_save(t, rx, bins, block=1024)[sh])
+    save("c2_mini", template=t, rx=rx, bins=bins, shifts=sh, caf=caf, d0=np.array([d0]), k0=np.array([k0]),
+         gx_xc=xc, gx_fpk=fpk)
+
+
+def gen_c1():
+    """Config C1: one 1024-sample template vs 65536-sample rx, no frequency search."""
+    rng = np.random.default_rng(0)
+    rx = cn(rng, 65536)
+    d0 = 1000
+    cut = rx[d0 : d0 + 1024].copy()
+    q = quiet(R.fastXcorr, cut, rx)
+    print("C1")
+    report("fastXcorr default", q, O.fastXcorr(cut, rx))
+    save("c1_fastxcorr", rx=rx, d0=np.array([d0]), qf2=q.astype(np.float32), argmax=np.array([int(np.argmax(q))]),
+         peak=np.array([q.max()]))
+
+
+def gen_kat4():
+    """TemplateCrossCorrelator unit test inputs (xcorrRoutines.py:2130-2241): the class itself
+    needs cupy upstream; its own test pins it to sqrt(fastXcorr) and |fastXcorr(absResult=False)|."""
+    rng = np.random.default_rng(505)
+    x = qpsk(rng, 100)
+    t1 = (x[20:40] * np.float32(1.234)).astype(np.complex64)
+    t2 = (x[40:60] * np.float32(2.345)).astype(np.complex64)
+    chk = np.sqrt(quiet(R.fastXcorr, t1.astype(np.complex128), x.astype(np.complex128)))
+    a1 = np.abs(quiet(R.fastXcorr, t1, x, absResult=False))
+    a2 = np.abs(quiet(R.fastXcorr, t2, x, absResult=False))
+    print("KAT-4")
+    tcc = O.TemplateCrossCorrelator(np.vstack((t1, t2)), 100)
+    out = tcc.correlate(x)
+    report("TCC restatement |row0| vs sqrt(fastXcorr)", chk, np.abs(out[0]))
+    report("TCC restatement |row1|", a2, np.abs(out[1]))
+    save("kat4_tcc", x=x, t1=t1, t2=t2, qf_single=chk, abs1=a1, abs2=a2)
+
+
+if __name__ == "__main__":
+    gen_fastxcorr()
+    gen_kat2()
+    gen_kat1_kat3()
+    gen_czt()
+    gen_group()
+    gen_c2_mini()
+    gen_c1()
+    gen_kat4()
