@@ -1,0 +1,154 @@
+"""ctypes binding of libcaf.so (include/caf.h).
+
+Follows the reference's own C-DLL idiom (cpuWola.py:38-70, cpuTone.py:28-47,
+cython_ext/compareIntPreambles/compareIntPreambles.py:7-52): the shared library
+sits next to the Python modules and is loaded with ``np.ctypeslib.load_library``;
+every entry point returns an int32 status (0 = success) and writes into
+caller-allocated buffers.
+
+There is NO CPU fallback: if the library is missing or a call fails, the host
+raises.  The oracle under ``oracle/`` is test infrastructure and is never
+imported from here.
+"""
+
+import ctypes as ct
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.realpath(__file__))
+
+CAF_OK = 0
+CAF_ERR_INVALID = 1
+CAF_ERR_HIP = 2
+CAF_ERR_ROCFFT = 3
+CAF_ERR_NOMEM = 4
+CAF_ERR_NODEVICE = 5
+
+CAF_FREQ_BINS = 0
+CAF_FREQ_NORM = 1
+CAF_NUM_STAGES = 7
+STAGE_NAMES = (
+    "energy_prefix",
+    "gather_blocks",
+    "fft_forward(rocFFT)",
+    "spectral_conj_multiply",
+    "fft_inverse(rocFFT)",
+    "magsq_norm_argmax",
+    "peak_reduce",
+)
+
+
+class CafPlanDesc(ct.Structure):
+    _fields_ = [
+        ("num_templates", ct.c_int32),
+        ("template_len", ct.c_int32),
+        ("h_templates", ct.c_void_p),
+        ("auto_conj", ct.c_int32),
+        ("num_groups", ct.c_int32),
+        ("h_group_start", ct.c_void_p),
+        ("h_group_len", ct.c_void_p),
+        ("freq_mode", ct.c_int32),
+        ("num_freqs", ct.c_int32),
+        ("h_bins", ct.c_void_p),
+        ("grid", ct.c_int32),
+        ("h_freqs_norm", ct.c_void_p),
+        ("max_rx_len", ct.c_int64),
+        ("log2_block", ct.c_int32),
+        ("blocks_per_batch", ct.c_int32),
+    ]
+
+
+class CafOutputs(ct.Structure):
+    _fields_ = [
+        ("d_surface", ct.c_void_p),
+        ("d_row_max", ct.c_void_p),
+        ("d_row_arg", ct.c_void_p),
+        ("d_peak_val", ct.c_void_p),
+        ("d_peak_delay", ct.c_void_p),
+        ("d_peak_freq", ct.c_void_p),
+    ]
+
+
+_P = ct.c_void_p
+_I32 = ct.c_int32
+_I64 = ct.c_int64
+
+# name -> argtypes; restype is always int32 (the reference DLL convention)
+_SIGNATURES = {
+    "caf_last_error": [ct.c_char_p, _I32],
+    "caf_abi_version": [],
+    "caf_device_count": [ct.POINTER(_I32)],
+    "caf_set_device": [_I32],
+    "caf_device_info": [_I32, ct.c_char_p, _I32, ct.POINTER(_I64), ct.POINTER(_I32)],
+    "caf_malloc": [ct.POINTER(_P), _I64],
+    "caf_free": [_P],
+    "caf_memset": [_P, _I32, _I64, _P],
+    "caf_h2d": [_P, _P, _I64, _P],
+    "caf_d2h": [_P, _P, _I64, _P],
+    "caf_d2d": [_P, _P, _I64, _P],
+    "caf_stream_sync": [_P],
+    "caf_plan_create": [ct.POINTER(_P), ct.POINTER(CafPlanDesc)],
+    "caf_plan_destroy": [_P],
+    "caf_plan_info": [_P, ct.POINTER(_I32), ct.POINTER(_I32), ct.POINTER(_I32), ct.POINTER(_I64)],
+    "caf_plan_execute": [_P, _P, _I64, _I64, _I64, ct.POINTER(CafOutputs), _P],
+    "caf_plan_profile": [_P, _I32],
+    "caf_plan_profile_get": [_P, ct.POINTER(ct.c_double), ct.POINTER(_I64)],
+    "caf_plan_execute_host": [_P, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P],
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def load():
+    """Load libcaf.so (once).  Raises OSError with build instructions if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    try:
+        lib = np.ctypeslib.load_library("libcaf", _HERE)
+    except OSError as e:
+        raise OSError(
+            "pydsproutines_amd: libcaf.so (the HIP extension) is missing or cannot be loaded from %s "
+            "(%s). Build it with `python -c 'import __graft_entry__ as g; g.build()'` or "
+            "`make -C pydsproutines_amd/csrc`. There is no CPU fallback." % (_HERE, e)
+        ) from e
+    for name, argtypes in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = _I32
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def last_error():
+    buf = ct.create_string_buffer(1024)
+    load().caf_last_error(buf, 1024)
+    return buf.value.decode("utf-8", "replace")
+
+
+def check(rc, what=""):
+    """Map a libcaf status to the reference's exception types
+    (ValueError shape/range, MemoryError resource, RuntimeError 'DLL returned an error')."""
+    if rc == CAF_OK:
+        return
+    msg = "%s: %s" % (what or "libcaf", last_error())
+    if rc == CAF_ERR_INVALID:
+        raise ValueError(msg)
+    if rc == CAF_ERR_NOMEM:
+        raise MemoryError(msg)
+    raise RuntimeError("DLL returned an error. " + msg)
+
+
+def device_count():
+    n = _I32(0)
+    rc = load().caf_device_count(ct.byref(n))
+    return n.value if rc == CAF_OK else 0
+
+
+def require_device():
+    """Fail loudly when no GPU is usable (no silent CPU path)."""
+    if device_count() < 1:
+        raise RuntimeError("pydsproutines_amd: no MI355X/HIP device visible: " + last_error())

@@ -1,0 +1,460 @@
+// Hand-written gfx950 (CDNA4, wave64) kernels of the CAF hypothesis engine.
+//
+// Replaces, with a different algorithm (frequency-domain overlap-save per hypothesis
+// instead of one DFT per delay), what the reference does with
+//   custom_kernels/multiplySlices.cu:113-216   sliding conjugate-multiply + window energy
+//   custom_kernels/complex_magn.cu:8-19        |.|^2
+//   custom_kernels/argmax.cu:93-153            per-row argmax
+//   custom_kernels/filter.cu:291-347           sliding energy (moving sum, double accumulate)
+// These kernels are HBM-bound elementwise / transpose / reduction work: no MFMA.
+#include "caf_internal.h"
+
+namespace caf {
+
+// ----------------------------------------------------------------------------------------
+// Sliding energy.  P[i] = sum_{j<i} |rx[j]|^2 in float64 for i in [0, M]; the window energy
+// of any support is then a difference of two prefix values (exact to ~1e-16 relative), the
+// f64 counterpart of the reference's double-accumulated moving sum (filter.cu:324-339,
+// multiplySlices.cu:153,201).
+// ----------------------------------------------------------------------------------------
+constexpr int PFX_THREADS = 256;
+constexpr int PFX_PER_THREAD = 4;
+constexpr int PFX_TILE = PFX_THREADS * PFX_PER_THREAD;
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(PFX_THREADS) void k_power_tile_sums(const float2* __restrict__ rx, int64_t m,
+                                                                 double* __restrict__ tile_sums) {
+    __shared__ double s_part[PFX_THREADS / 64];
+    const int64_t base = (int64_t)blockIdx.x * PFX_TILE + (int64_t)threadIdx.x * PFX_PER_THREAD;
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < PFX_PER_THREAD; ++j) {
+        const int64_t i = base + j;
+        if (i < m) {
+            const float2 v = rx[i];
+            acc += (double)v.x * (double)v.x + (double)v.y * (double)v.y;
+        }
+    }
+    acc = wave_sum_f64(acc);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < PFX_THREADS / 64; ++w) t += s_part[w];
+        tile_sums[blockIdx.x] = t;
+    }
+}
+
+// Exclusive scan of the tile sums in place, one workgroup, sequential over chunks of 1024.
+__global__ __launch_bounds__(1024) void k_scan_tile_sums(double* __restrict__ tile_sums, int64_t ntiles) {
+    __shared__ double s_wave[16];
+    __shared__ double s_carry;
+    if (threadIdx.x == 0) s_carry = 0.0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t c = 0; c < ntiles; c += 1024) {
+        const int64_t i = c + threadIdx.x;
+        const double v = (i < ntiles) ? tile_sums[i] : 0.0;
+        double incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const double u = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += u;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        double woff = 0.0;
+        for (int w = 0; w < wave; ++w) woff += s_wave[w];
+        const double carry = s_carry;
+        if (i < ntiles) tile_sums[i] = carry + woff + (incl - v);
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = carry + woff + incl;
+        __syncthreads();
+    }
+}
+
+// prefix[i] for i in [0, m]  (m+1 entries); tile_off = exclusive-scanned tile sums.
+__global__ __launch_bounds__(PFX_THREADS) void k_prefix_write(const float2* __restrict__ rx, int64_t m,
+                                                              const double* __restrict__ tile_off,
+                                                              double* __restrict__ prefix) {
+    __shared__ double s_wave[PFX_THREADS / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t base = (int64_t)blockIdx.x * PFX_TILE + (int64_t)threadIdx.x * PFX_PER_THREAD;
+    double p[PFX_PER_THREAD];
+    double tot = 0.0;
+#pragma unroll
+    for (int j = 0; j < PFX_PER_THREAD; ++j) {
+        const int64_t i = base + j;
+        double e = 0.0;
+        if (i < m) {
+            const float2 v = rx[i];
+            e = (double)v.x * (double)v.x + (double)v.y * (double)v.y;
+        }
+        p[j] = tot;  // exclusive within the thread
+        tot += e;
+    }
+    double incl = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double u = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += u;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    double off = tile_off[blockIdx.x] + (incl - tot);
+    for (int w = 0; w < wave; ++w) off += s_wave[w];
+#pragma unroll
+    for (int j = 0; j < PFX_PER_THREAD; ++j) {
+        const int64_t i = base + j;
+        if (i <= m) prefix[i] = off + p[j];
+    }
+}
+
+// inv_e[i] = 1 / sum_g (P[s+st_g+len_g] - P[s+st_g]),  s = shift_start + i.
+__global__ __launch_bounds__(256) void k_inv_energy(const double* __restrict__ prefix, int64_t shift_start,
+                                                    int64_t num_shifts, const int32_t* __restrict__ gstart,
+                                                    const int32_t* __restrict__ glen, int32_t ngroups,
+                                                    float* __restrict__ inv_e) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= num_shifts) return;
+    const int64_t s = shift_start + i;
+    double e = 0.0;
+    for (int g = 0; g < ngroups; ++g) {
+        const int64_t a = s + gstart[g];
+        e += prefix[a + glen[g]] - prefix[a];
+    }
+    inv_e[i] = (float)(1.0 / e);
+}
+
+// ----------------------------------------------------------------------------------------
+// Overlap-save block gather: xb[b][m] = rx[src0 + b*step + m] (0 past the end of rx).
+// ----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gather_blocks(const float2* __restrict__ rx, int64_t rx_len,
+                                                       int64_t src0, int32_t step, int32_t bsz,
+                                                       float2* __restrict__ xb) {
+    const int b = blockIdx.y;
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= bsz) return;
+    const int64_t src = src0 + (int64_t)b * step + m;
+    float2 v = make_float2(0.f, 0.f);
+    if (src < rx_len) v = rx[src];
+    xb[(int64_t)b * bsz + m] = v;
+}
+
+// hc[i] = conj(h[i]) * scale   (template spectra -> pre-conjugated, 1/B folded in)
+__global__ __launch_bounds__(256) void k_conj_scale(float2* __restrict__ h, int64_t n, float scale) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float2 v = h[i];
+    h[i] = make_float2(v.x * scale, -v.y * scale);
+}
+
+// ----------------------------------------------------------------------------------------
+// Spectral conjugate-multiply across hypotheses (the frequency-domain counterpart of the
+// reference's sliding conjugate-multiply, multiplySlices.cu:206-211):
+//     P[z][h][m] = X[z][m] * Hc_h[m],     h = t*F + f
+// SHIFT mode: Hc_h[m] = Hc0_t[(m - shift_f) mod B]  (on-grid frequency = circular shift of
+// one template spectrum, so all F hypotheses read one B-point table that stays in L2);
+// TABLE mode: Hc_h given explicitly.
+// One thread owns two consecutive spectral points (16-byte loads/stores) and walks HG
+// hypotheses with X held in registers: per element written, 8 B go to HBM and the X read is
+// amortised 1/HG.  Write-bound.
+// ----------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 cmul2(const float4 x, const float4 h) {
+    float4 r;
+    r.x = x.x * h.x - x.y * h.y;
+    r.y = x.x * h.y + x.y * h.x;
+    r.z = x.z * h.z - x.w * h.w;
+    r.w = x.z * h.w + x.w * h.z;
+    return r;
+}
+
+template <int MODE>  // 0: shift, even shifts (16-B H loads) ; 1: shift, any ; 2: table
+__global__ __launch_bounds__(MUL_THREADS) void k_spectral_mul(const float2* __restrict__ xb,
+                                                             const float2* __restrict__ hc,
+                                                             const int32_t* __restrict__ shifts, int32_t bsz,
+                                                             int32_t pitch, int32_t nfreq, int32_t nhyp,
+                                                             int32_t hyp_per_wg, float2* __restrict__ pbuf) {
+    const int m = (blockIdx.x * MUL_THREADS + threadIdx.x) * 2;
+    if (m >= bsz) return;
+    const int z = blockIdx.z;
+    const float4 x = *reinterpret_cast<const float4*>(xb + (int64_t)z * bsz + m);
+    const int h0 = blockIdx.y * hyp_per_wg;
+    const int h1 = min(h0 + hyp_per_wg, nhyp);
+    const int mask = bsz - 1;
+    float2* prow = pbuf + ((int64_t)z * nhyp + h0) * pitch + m;
+#pragma unroll 4
+    for (int h = h0; h < h1; ++h, prow += pitch) {
+        float4 hv;
+        if (MODE == 2) {
+            hv = *reinterpret_cast<const float4*>(hc + (int64_t)h * bsz + m);
+        } else {
+            const int t = h / nfreq;
+            const int f = h - t * nfreq;
+            const int i0 = (m - shifts[f]) & mask;
+            const float2* hrow = hc + (int64_t)t * bsz;
+            if (MODE == 0) {
+                hv = *reinterpret_cast<const float4*>(hrow + i0);
+            } else {
+                const float2 a = hrow[i0];
+                const float2 b = hrow[(i0 + 1) & mask];
+                hv = make_float4(a.x, a.y, b.x, b.y);
+            }
+        }
+        *reinterpret_cast<float4*>(prow) = cmul2(x, hv);
+    }
+}
+
+// ----------------------------------------------------------------------------------------
+// |.|^2 + normalise + transpose + per-delay argmax + partial global peak, on the IFFT output
+// (the fused counterpart of complex_magn.cu:8-19 + argmax.cu:93-153 + the QF^2 division of
+// xcorrRoutines.py:528-529).
+//   in : P[z][t*F+f][s_local]  complex64, hypothesis-major, row pitch `pitch`
+//   out: surface[t][s][f]      float32, delay-major (the reference's CAF layout)
+//        row_max / row_arg [t][s], and one (value, delay, f) record per workgroup.
+// A workgroup owns MAG_S consecutive delays of one (rx block, template) and walks the F axis in
+// chunks of MAG_F through an LDS tile: reads are MAG_S*8 B contiguous per hypothesis row,
+// writes are MAG_F*4 B contiguous per delay row.
+// ----------------------------------------------------------------------------------------
+struct Best {
+    float v;
+    int32_t i;
+};
+
+__device__ __forceinline__ Best wave_best(Best b) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(b.v, o, 64);
+        const int32_t oi = __shfl_xor(b.i, o, 64);
+        if (ov > b.v || (ov == b.v && oi < b.i)) {
+            b.v = ov;
+            b.i = oi;
+        }
+    }
+    return b;
+}
+
+__global__ __launch_bounds__(MAG_THREADS) void k_magsq_norm_argmax(
+    const float2* __restrict__ pbuf, int32_t pitch, int32_t ntmpl, int32_t nfreq, const float* __restrict__ tscale,
+    const float* __restrict__ inv_e, int64_t num_shifts, int64_t shift_start, int32_t step, int32_t blk0,
+    int32_t tiles_per_blk, float* __restrict__ surface, float* __restrict__ row_max, int32_t* __restrict__ row_arg,
+    PeakRec* __restrict__ partial, int64_t partial_per_tmpl) {
+    __shared__ float s_tile[MAG_S][MAG_F + 1];
+    __shared__ float s_rowv[MAG_S];
+    __shared__ int32_t s_rowi[MAG_S];
+
+    const int z = blockIdx.z, t = blockIdx.y;
+    const int blk = blk0 + z;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sl0 = blockIdx.x * MAG_S;                     // first local delay of this tile
+    const int64_t rel0 = (int64_t)blk * step + sl0;         // index relative to shift_start
+    int64_t nv = num_shifts - (int64_t)blk * step;          // valid delays in this rx block
+    if (nv > step) nv = step;
+    const int64_t pidx = ((int64_t)blk * tiles_per_blk + blockIdx.x);
+    if (sl0 >= nv) {  // whole tile past the end (last, partial rx block): neutral record
+        if (threadIdx.x == 0 && partial) {
+            PeakRec r;
+            r.v = -1.f;
+            r.delay = 0x7fffffff;
+            r.f = 0;
+            partial[(int64_t)t * partial_per_tmpl + pidx] = r;
+        }
+        return;
+    }
+    const int nrows = (int)min((int64_t)MAG_S, nv - sl0);
+    const bool lane_ok = lane < nrows;
+    const float ie = lane_ok ? inv_e[rel0 + lane] : 0.f;
+    const float ts = tscale[t];
+    const float2* pin = pbuf + ((int64_t)z * ntmpl + t) * nfreq * (int64_t)pitch + sl0 + lane;
+
+    constexpr int ROWS_PER_WAVE = MAG_S / (MAG_THREADS / 64);
+    float bv[ROWS_PER_WAVE];
+    int32_t bi[ROWS_PER_WAVE];
+#pragma unroll
+    for (int r = 0; r < ROWS_PER_WAVE; ++r) {
+        bv[r] = -1.f;
+        bi[r] = 0;
+    }
+
+    for (int f0 = 0; f0 < nfreq; f0 += MAG_F) {
+        const int nf = min(MAG_F, nfreq - f0);
+        // phase 1: hypothesis rows -> LDS tile (transposed)
+#pragma unroll 8
+        for (int fl = wave; fl < nf; fl += MAG_THREADS / 64) {
+            float v = -1.f;
+            if (lane_ok) {
+                const float2 p = pin[(int64_t)(f0 + fl) * pitch];
+                v = (p.x * p.x + p.y * p.y) * ts * ie;
+            }
+            s_tile[lane][fl] = v;
+        }
+        __syncthreads();
+        // phase 2: delay rows -> surface, running argmax
+#pragma unroll
+        for (int r = 0; r < ROWS_PER_WAVE; ++r) {
+            const int row = wave + r * (MAG_THREADS / 64);
+            if (row < nrows) {
+                Best b;
+                b.v = -1.f;
+                b.i = 0;
+                float* srow = surface ? surface + ((int64_t)t * num_shifts + rel0 + row) * nfreq + f0 : nullptr;
+#pragma unroll
+                for (int c = 0; c < MAG_F / 64; ++c) {
+                    const int fl = lane + 64 * c;
+                    if (fl < nf) {
+                        const float v = s_tile[row][fl];
+                        if (srow) srow[fl] = v;
+                        if (v > b.v) {
+                            b.v = v;
+                            b.i = f0 + fl;
+                        }
+                    }
+                }
+                b = wave_best(b);
+                if (b.v > bv[r]) {
+                    bv[r] = b.v;
+                    bi[r] = b.i;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // per-row results -> LDS -> coalesced stores; tile best -> partial record
+    if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < ROWS_PER_WAVE; ++r) {
+            const int row = wave + r * (MAG_THREADS / 64);
+            s_rowv[row] = bv[r];
+            s_rowi[row] = bi[r];
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float v = -1.f;
+        int32_t fi = 0;
+        if (lane_ok) {
+            v = s_rowv[lane];
+            fi = s_rowi[lane];
+            const int64_t o = (int64_t)t * num_shifts + rel0 + lane;
+            if (row_max) row_max[o] = v;
+            if (row_arg) row_arg[o] = fi;
+        }
+        if (partial) {
+            // best over the tile: highest value, then lowest delay
+            Best b;
+            b.v = v;
+            b.i = lane;
+            b = wave_best(b);
+            if (lane == 0) {
+                PeakRec r;
+                r.v = b.v;
+                r.delay = (int32_t)(shift_start + rel0 + b.i);
+                r.f = s_rowi[b.i];
+                partial[(int64_t)t * partial_per_tmpl + pidx] = r;
+            }
+        }
+    }
+}
+
+// One workgroup per template: reduce the per-tile records (highest value, then lowest delay).
+__global__ __launch_bounds__(1024) void k_peak_reduce(const PeakRec* __restrict__ partial, int64_t per_tmpl,
+                                                      int64_t stride, float* __restrict__ peak_val,
+                                                      int32_t* __restrict__ peak_delay,
+                                                      int32_t* __restrict__ peak_freq) {
+    __shared__ PeakRec s_w[16];
+    const int t = blockIdx.x;
+    const PeakRec* p = partial + (int64_t)t * stride;
+    PeakRec b;
+    b.v = -2.f;
+    b.delay = 0x7fffffff;
+    b.f = 0;
+    for (int64_t i = threadIdx.x; i < per_tmpl; i += 1024) {
+        const PeakRec r = p[i];
+        if (r.v > b.v || (r.v == b.v && r.delay < b.delay)) b = r;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        PeakRec r;
+        r.v = __shfl_xor(b.v, o, 64);
+        r.delay = __shfl_xor(b.delay, o, 64);
+        r.f = __shfl_xor(b.f, o, 64);
+        if (r.v > b.v || (r.v == b.v && r.delay < b.delay)) b = r;
+    }
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = b;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w) {
+            const PeakRec r = s_w[w];
+            if (r.v > b.v || (r.v == b.v && r.delay < b.delay)) b = r;
+        }
+        if (peak_val) peak_val[t] = b.v;
+        if (peak_delay) peak_delay[t] = b.delay;
+        if (peak_freq) peak_freq[t] = b.f;
+    }
+}
+
+// ----------------------------------------------------------------------------------------
+// Launch wrappers (host)
+// ----------------------------------------------------------------------------------------
+int64_t prefix_num_tiles(int64_t m) { return (m + 1 + PFX_TILE - 1) / PFX_TILE; }
+
+void launch_energy_prefix(const float2* rx, int64_t m, double* tile_sums, double* prefix, hipStream_t st) {
+    const int64_t nt = prefix_num_tiles(m);
+    hipLaunchKernelGGL(k_power_tile_sums, dim3((unsigned)nt), dim3(PFX_THREADS), 0, st, rx, m, tile_sums);
+    hipLaunchKernelGGL(k_scan_tile_sums, dim3(1), dim3(1024), 0, st, tile_sums, nt);
+    hipLaunchKernelGGL(k_prefix_write, dim3((unsigned)nt), dim3(PFX_THREADS), 0, st, rx, m, tile_sums, prefix);
+}
+
+void launch_inv_energy(const double* prefix, int64_t shift_start, int64_t num_shifts, const int32_t* gstart,
+                       const int32_t* glen, int32_t ngroups, float* inv_e, hipStream_t st) {
+    const unsigned g = (unsigned)((num_shifts + 255) / 256);
+    hipLaunchKernelGGL(k_inv_energy, dim3(g), dim3(256), 0, st, prefix, shift_start, num_shifts, gstart, glen, ngroups,
+                       inv_e);
+}
+
+void launch_gather_blocks(const float2* rx, int64_t rx_len, int64_t src0, int32_t step, int32_t bsz, int32_t nblk,
+                          float2* xb, hipStream_t st) {
+    hipLaunchKernelGGL(k_gather_blocks, dim3((bsz + 255) / 256, nblk), dim3(256), 0, st, rx, rx_len, src0, step, bsz,
+                       xb);
+}
+
+void launch_conj_scale(float2* h, int64_t n, float scale, hipStream_t st) {
+    hipLaunchKernelGGL(k_conj_scale, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, h, n, scale);
+}
+
+void launch_spectral_mul(int mode, const float2* xb, const float2* hc, const int32_t* shifts, int32_t bsz,
+                         int32_t pitch, int32_t nfreq, int32_t nhyp, int32_t hyp_per_wg, int32_t nblk, float2* pbuf,
+                         hipStream_t st) {
+    const dim3 grid((bsz / 2 + MUL_THREADS - 1) / MUL_THREADS, (nhyp + hyp_per_wg - 1) / hyp_per_wg, nblk);
+    if (mode == 0)
+        hipLaunchKernelGGL(k_spectral_mul<0>, grid, dim3(MUL_THREADS), 0, st, xb, hc, shifts, bsz, pitch, nfreq, nhyp,
+                           hyp_per_wg, pbuf);
+    else if (mode == 1)
+        hipLaunchKernelGGL(k_spectral_mul<1>, grid, dim3(MUL_THREADS), 0, st, xb, hc, shifts, bsz, pitch, nfreq, nhyp,
+                           hyp_per_wg, pbuf);
+    else
+        hipLaunchKernelGGL(k_spectral_mul<2>, grid, dim3(MUL_THREADS), 0, st, xb, hc, shifts, bsz, pitch, nfreq, nhyp,
+                           hyp_per_wg, pbuf);
+}
+
+void launch_magsq(const float2* pbuf, int32_t pitch, int32_t ntmpl, int32_t nfreq, const float* tscale,
+                  const float* inv_e, int64_t num_shifts, int64_t shift_start, int32_t step, int32_t blk0,
+                  int32_t nblk, int32_t tiles_per_blk, float* surface, float* row_max, int32_t* row_arg,
+                  PeakRec* partial, int64_t partial_per_tmpl, hipStream_t st) {
+    hipLaunchKernelGGL(k_magsq_norm_argmax, dim3(tiles_per_blk, ntmpl, nblk), dim3(MAG_THREADS), 0, st, pbuf, pitch,
+                       ntmpl, nfreq, tscale, inv_e, num_shifts, shift_start, step, blk0, tiles_per_blk, surface,
+                       row_max, row_arg, partial, partial_per_tmpl);
+}
+
+void launch_peak_reduce(const PeakRec* partial, int64_t count, int64_t stride, int32_t ntmpl, float* pv, int32_t* pd,
+                        int32_t* pf, hipStream_t st) {
+    hipLaunchKernelGGL(k_peak_reduce, dim3(ntmpl), dim3(1024), 0, st, partial, count, stride, pv, pd, pf);
+}
+
+}  // namespace caf

@@ -1,0 +1,571 @@
+// libcaf: plan object of the hypothesis engine + the C-ABI of include/caf.h.
+// Host-side C++ around the gfx950 kernels of caf_kernels.hip and batched rocFFT.
+#include <rocfft/rocfft.h>
+
+#include <algorithm>
+#include <cmath>
+#include <complex>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "caf_internal.h"
+
+namespace caf {
+
+static thread_local std::string g_last_error;
+void set_error(const std::string& msg) { g_last_error = msg; }
+
+static std::once_flag g_rocfft_once;
+static void rocfft_init_once() {
+    std::call_once(g_rocfft_once, [] { rocfft_setup(); });
+}
+
+#define CAF_FFT_TRY(expr)                                                                 \
+    do {                                                                                  \
+        rocfft_status _s = (expr);                                                        \
+        if (_s != rocfft_status_success) {                                                \
+            caf::set_error(std::string(#expr) + ": rocfft status " + std::to_string(_s)); \
+            return CAF_ERR_ROCFFT;                                                        \
+        }                                                                                 \
+    } while (0)
+
+#define CAF_REQUIRE(cond, msg)          \
+    do {                                \
+        if (!(cond)) {                  \
+            caf::set_error(msg);        \
+            return CAF_ERR_INVALID;     \
+        }                               \
+    } while (0)
+
+struct FftPlan {
+    rocfft_plan plan = nullptr;
+    rocfft_execution_info info = nullptr;
+    void* work = nullptr;
+    size_t work_bytes = 0;
+
+    int create(bool inverse, size_t len, size_t batch, size_t dist) {
+        rocfft_init_once();
+        rocfft_plan_description desc = nullptr;
+        CAF_FFT_TRY(rocfft_plan_description_create(&desc));
+        size_t stride = 1;
+        CAF_FFT_TRY(rocfft_plan_description_set_data_layout(desc, rocfft_array_type_complex_interleaved,
+                                                            rocfft_array_type_complex_interleaved, nullptr, nullptr, 1,
+                                                            &stride, dist, 1, &stride, dist));
+        rocfft_status s = rocfft_plan_create(&plan, rocfft_placement_inplace,
+                                             inverse ? rocfft_transform_type_complex_inverse
+                                                     : rocfft_transform_type_complex_forward,
+                                             rocfft_precision_single, 1, &len, batch, desc);
+        rocfft_plan_description_destroy(desc);
+        CAF_FFT_TRY(s);
+        CAF_FFT_TRY(rocfft_plan_get_work_buffer_size(plan, &work_bytes));
+        CAF_FFT_TRY(rocfft_execution_info_create(&info));
+        if (work_bytes) {
+            CAF_HIP_TRY(hipMalloc(&work, work_bytes));
+            CAF_FFT_TRY(rocfft_execution_info_set_work_buffer(info, work, work_bytes));
+        }
+        return CAF_OK;
+    }
+    int exec(void* buf, hipStream_t st) {
+        CAF_FFT_TRY(rocfft_execution_info_set_stream(info, st));
+        void* in[1] = {buf};
+        CAF_FFT_TRY(rocfft_execute(plan, in, nullptr, info));
+        return CAF_OK;
+    }
+    void destroy() {
+        if (info) rocfft_execution_info_destroy(info);
+        if (plan) rocfft_plan_destroy(plan);
+        if (work) (void)hipFree(work);
+        info = nullptr;
+        plan = nullptr;
+        work = nullptr;
+    }
+};
+
+}  // namespace caf
+
+using namespace caf;
+
+struct caf_plan_t {
+    int T = 0, N = 0, F = 0, G = 0;
+    int freq_mode = 0, mul_mode = 0;
+    int B = 0, step = 0, pitch = 0, nb = 0, tiles_per_blk = 0, hyp_per_wg = 16;
+    int64_t max_rx = 0, max_blocks = 0, partial_per_tmpl = 0;
+    int device = 0;
+    float2* d_hc = nullptr;
+    int32_t* d_shifts = nullptr;
+    float* d_tscale = nullptr;
+    int32_t* d_gstart = nullptr;
+    int32_t* d_glen = nullptr;
+    double* d_tile_sums = nullptr;
+    double* d_prefix = nullptr;
+    float* d_inv_e = nullptr;
+    float2* d_xb = nullptr;
+    float2* d_pbuf = nullptr;
+    PeakRec* d_partial = nullptr;
+    FftPlan fwd, inv;
+    int64_t workspace_bytes = 0;
+    // profiling
+    bool prof = false;
+    struct Rec {
+        int stage;
+        hipEvent_t a, b;
+    };
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> pool;
+    double acc_ms[CAF_NUM_STAGES] = {0};
+    int64_t acc_n[CAF_NUM_STAGES] = {0};
+
+    hipEvent_t get_event() {
+        if (!pool.empty()) {
+            hipEvent_t e = pool.back();
+            pool.pop_back();
+            return e;
+        }
+        hipEvent_t e;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+    void stage_begin(int stage, hipStream_t st) {
+        if (!prof) return;
+        Rec r;
+        r.stage = stage;
+        r.a = get_event();
+        r.b = get_event();
+        (void)hipEventRecord(r.a, st);
+        recs.push_back(r);
+    }
+    void stage_end(hipStream_t st) {
+        if (!prof) return;
+        (void)hipEventRecord(recs.back().b, st);
+    }
+    void drain() {
+        for (auto& r : recs) {
+            (void)hipEventSynchronize(r.b);
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+                acc_ms[r.stage] += ms;
+                acc_n[r.stage] += 1;
+            }
+            pool.push_back(r.a);
+            pool.push_back(r.b);
+        }
+        recs.clear();
+    }
+    template <typename Tp>
+    int alloc(Tp** p, int64_t count) {
+        const int64_t bytes = count * (int64_t)sizeof(Tp);
+        CAF_HIP_TRY(hipMalloc((void**)p, (size_t)std::max<int64_t>(bytes, 16)));
+        workspace_bytes += bytes;
+        return CAF_OK;
+    }
+    void release() {
+        drain();
+        for (auto e : pool) (void)hipEventDestroy(e);
+        pool.clear();
+        fwd.destroy();
+        inv.destroy();
+        void* ptrs[] = {d_hc, d_shifts, d_tscale, d_gstart, d_glen, d_tile_sums, d_prefix, d_inv_e, d_xb, d_pbuf, d_partial};
+        for (void* p : ptrs)
+            if (p) (void)hipFree(p);
+    }
+};
+
+static int ilog2_ceil(int64_t v) {
+    int l = 0;
+    while (((int64_t)1 << l) < v) ++l;
+    return l;
+}
+
+extern "C" {
+
+int32_t caf_last_error(char* buf, int32_t len) {
+    if (!buf || len <= 0) return CAF_ERR_INVALID;
+    std::strncpy(buf, g_last_error.c_str(), (size_t)len - 1);
+    buf[len - 1] = 0;
+    return CAF_OK;
+}
+
+int32_t caf_abi_version(void) { return (1 << 16) | 0; }
+
+int32_t caf_device_count(int32_t* count) {
+    CAF_REQUIRE(count, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        set_error(std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+        return CAF_ERR_NODEVICE;
+    }
+    *count = n;
+    return CAF_OK;
+}
+
+int32_t caf_set_device(int32_t device) {
+    CAF_HIP_TRY(hipSetDevice(device));
+    return CAF_OK;
+}
+
+int32_t caf_device_info(int32_t device, char* name, int32_t name_len, int64_t* total_mem, int32_t* compute_units) {
+    hipDeviceProp_t prop;
+    CAF_HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (name && name_len > 0) {
+        std::snprintf(name, (size_t)name_len, "%s (%s)", prop.name, prop.gcnArchName);
+    }
+    if (total_mem) *total_mem = (int64_t)prop.totalGlobalMem;
+    if (compute_units) *compute_units = prop.multiProcessorCount;
+    return CAF_OK;
+}
+
+int32_t caf_malloc(void** d_ptr, int64_t bytes) {
+    CAF_REQUIRE(d_ptr && bytes >= 0, "caf_malloc: bad arguments");
+    CAF_HIP_TRY(hipMalloc(d_ptr, (size_t)std::max<int64_t>(bytes, 16)));
+    return CAF_OK;
+}
+int32_t caf_free(void* d_ptr) {
+    if (d_ptr) CAF_HIP_TRY(hipFree(d_ptr));
+    return CAF_OK;
+}
+int32_t caf_memset(void* d_ptr, int32_t value, int64_t bytes, void* stream) {
+    CAF_HIP_TRY(hipMemsetAsync(d_ptr, value, (size_t)bytes, (hipStream_t)stream));
+    return CAF_OK;
+}
+int32_t caf_h2d(void* d_dst, const void* h_src, int64_t bytes, void* stream) {
+    CAF_HIP_TRY(hipMemcpyAsync(d_dst, h_src, (size_t)bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    CAF_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return CAF_OK;
+}
+int32_t caf_d2h(void* h_dst, const void* d_src, int64_t bytes, void* stream) {
+    CAF_HIP_TRY(hipMemcpyAsync(h_dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    CAF_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return CAF_OK;
+}
+int32_t caf_d2d(void* d_dst, const void* d_src, int64_t bytes, void* stream) {
+    CAF_HIP_TRY(hipMemcpyAsync(d_dst, d_src, (size_t)bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return CAF_OK;
+}
+int32_t caf_stream_sync(void* stream) {
+    CAF_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return CAF_OK;
+}
+
+int32_t caf_plan_destroy(caf_plan plan) {
+    if (!plan) return CAF_OK;
+    (void)hipSetDevice(plan->device);
+    plan->release();
+    delete plan;
+    return CAF_OK;
+}
+
+static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
+    CAF_REQUIRE(d->num_templates >= 1 && d->template_len >= 1 && d->h_templates, "need >= 1 template");
+    CAF_REQUIRE(d->num_freqs >= 1, "need >= 1 frequency hypothesis");
+    CAF_REQUIRE(d->max_rx_len >= d->template_len, "max_rx_len shorter than the template");
+    CAF_REQUIRE(d->max_rx_len < ((int64_t)1 << 31) - (1 << 20), "rx longer than 2^31 samples is not supported");
+    CAF_REQUIRE(d->freq_mode == CAF_FREQ_BINS || d->freq_mode == CAF_FREQ_NORM, "bad freq_mode");
+    CAF_HIP_TRY(hipGetDevice(&p->device));
+    p->T = d->num_templates;
+    p->N = d->template_len;
+    p->F = d->num_freqs;
+    p->freq_mode = d->freq_mode;
+    p->max_rx = d->max_rx_len;
+    const int T = p->T, N = p->N, F = p->F;
+
+    // groups (support of the template for the energy normalisation)
+    std::vector<int32_t> gs, gl;
+    if (d->num_groups >= 1 && d->h_group_start && d->h_group_len) {
+        gs.assign(d->h_group_start, d->h_group_start + d->num_groups);
+        gl.assign(d->h_group_len, d->h_group_len + d->num_groups);
+    } else {
+        gs = {0};
+        gl = {N};
+    }
+    p->G = (int)gs.size();
+    for (int g = 0; g < p->G; ++g)
+        CAF_REQUIRE(gs[g] >= 0 && gl[g] >= 1 && (int64_t)gs[g] + gl[g] <= N, "group outside the template span");
+
+    // block size: B = 2^k, B >= 2N (>= 50 % valid outputs); default 16 N clipped to [2^12, 2^18]
+    int lb = d->log2_block;
+    const int lmin = ilog2_ceil(2 * (int64_t)N);
+    if (lb <= 0) {
+        lb = std::min(std::max(ilog2_ceil(16 * (int64_t)N), 12), 18);
+        // no point in blocks much longer than the data
+        lb = std::min(lb, std::max(ilog2_ceil(d->max_rx_len), 12));
+        lb = std::max(lb, lmin);
+    }
+    CAF_REQUIRE(lb >= lmin && lb <= 24, "log2_block must satisfy 2N <= 2^log2_block <= 2^24");
+    lb = std::max(lb, 9);  // the multiply kernel tiles 512 points per workgroup
+    p->B = 1 << lb;
+    p->step = p->B - N + 1;
+    p->pitch = p->B + 64;  // break the power-of-two stride between hypothesis rows
+    const int B = p->B;
+
+    // frequency hypotheses
+    std::vector<int32_t> shifts;
+    bool all_even = true;
+    if (d->freq_mode == CAF_FREQ_BINS) {
+        CAF_REQUIRE(d->h_bins && d->grid >= 1, "CAF_FREQ_BINS needs bins and grid");
+        CAF_REQUIRE(B % d->grid == 0, "grid must divide the block size (use CAF_FREQ_NORM otherwise)");
+        const int64_t mult = B / d->grid;
+        shifts.resize(F);
+        for (int f = 0; f < F; ++f) {
+            int64_t s = ((int64_t)d->h_bins[f] * mult) % B;
+            if (s < 0) s += B;
+            shifts[f] = (int32_t)s;
+            if (s & 1) all_even = false;
+        }
+        p->mul_mode = all_even ? 0 : 1;
+    } else {
+        CAF_REQUIRE(d->h_freqs_norm, "CAF_FREQ_NORM needs freqs_norm");
+        p->mul_mode = 2;
+    }
+    const int64_t nspec = (p->mul_mode == 2) ? (int64_t)T * F : T;  // template spectra held
+
+    // batch: aim at ~128 MiB of hypothesis products in flight
+    const int64_t total_blocks = (d->max_rx_len - N + 1 + p->step - 1) / p->step;
+    int nb = d->blocks_per_batch;
+    if (nb <= 0) {
+        const int64_t per_block = (int64_t)T * F * p->pitch * 8;
+        nb = (int)std::max<int64_t>(1, std::min<int64_t>(64, ((int64_t)128 << 20) / per_block));
+    }
+    nb = (int)std::min<int64_t>(nb, std::max<int64_t>(1, total_blocks));
+    p->nb = nb;
+    p->max_blocks = (total_blocks + nb - 1) / nb * nb;
+    p->tiles_per_blk = (p->step + MAG_S - 1) / MAG_S;
+    p->partial_per_tmpl = p->max_blocks * p->tiles_per_blk;
+    p->hyp_per_wg = (int)std::min<int64_t>(16, (int64_t)T * F);
+
+    // device buffers
+    int rc;
+    if ((rc = p->alloc(&p->d_hc, nspec * B))) return rc;
+    if ((rc = p->alloc(&p->d_shifts, std::max(F, 1)))) return rc;
+    if ((rc = p->alloc(&p->d_tscale, T))) return rc;
+    if ((rc = p->alloc(&p->d_gstart, p->G))) return rc;
+    if ((rc = p->alloc(&p->d_glen, p->G))) return rc;
+    if ((rc = p->alloc(&p->d_tile_sums, prefix_num_tiles(d->max_rx_len) + 1024))) return rc;
+    if ((rc = p->alloc(&p->d_prefix, d->max_rx_len + 1))) return rc;
+    if ((rc = p->alloc(&p->d_inv_e, d->max_rx_len))) return rc;
+    if ((rc = p->alloc(&p->d_xb, (int64_t)nb * B))) return rc;
+    if ((rc = p->alloc(&p->d_pbuf, (int64_t)nb * T * F * p->pitch))) return rc;
+    if ((rc = p->alloc(&p->d_partial, (int64_t)T * p->partial_per_tmpl))) return rc;
+
+    // template spectra: u = auto_conj ? tmpl : conj(tmpl);  u_f[n] = u[n] exp(+j 2 pi nu_f n);
+    // Hc = conj(FFT_B(u_f)) / B  (rocFFT's inverse is unnormalised, 1/B is folded in here)
+    std::vector<float> tscale(T);
+    {
+        std::vector<std::complex<float>> host((size_t)nspec * B, std::complex<float>(0.f, 0.f));
+        const std::complex<float>* tm = reinterpret_cast<const std::complex<float>*>(d->h_templates);
+        for (int t = 0; t < T; ++t) {
+            double e = 0.0;
+            for (int n = 0; n < N; ++n) e += std::norm(std::complex<double>(tm[(size_t)t * N + n]));
+            tscale[t] = (float)(1.0 / e);
+            if (p->mul_mode != 2) {
+                for (int n = 0; n < N; ++n) {
+                    std::complex<float> u = tm[(size_t)t * N + n];
+                    host[(size_t)t * B + n] = d->auto_conj ? u : std::conj(u);
+                }
+            } else {
+                for (int f = 0; f < F; ++f) {
+                    const double nu = d->h_freqs_norm[f];
+                    std::complex<float>* dst = &host[((size_t)t * F + f) * B];
+                    for (int n = 0; n < N; ++n) {
+                        std::complex<double> u(tm[(size_t)t * N + n]);
+                        if (!d->auto_conj) u = std::conj(u);
+                        // reduce the phase in cycles before the trig call to keep full f64 accuracy
+                        double cyc = nu * (double)n;
+                        cyc -= std::floor(cyc);
+                        const double ph = 2.0 * M_PI * cyc;
+                        u *= std::complex<double>(std::cos(ph), std::sin(ph));
+                        dst[n] = std::complex<float>((float)u.real(), (float)u.imag());
+                    }
+                }
+            }
+        }
+        CAF_HIP_TRY(hipMemcpy(p->d_hc, host.data(), host.size() * sizeof(std::complex<float>), hipMemcpyHostToDevice));
+    }
+    {
+        FftPlan tmp;
+        rc = tmp.create(false, (size_t)B, (size_t)nspec, (size_t)B);
+        if (rc == CAF_OK) rc = tmp.exec(p->d_hc, nullptr);
+        if (rc == CAF_OK) launch_conj_scale(p->d_hc, nspec * B, 1.0f / (float)B, nullptr);
+        hipError_t e = hipStreamSynchronize(nullptr);
+        tmp.destroy();
+        if (rc) return rc;
+        CAF_HIP_TRY(e);
+    }
+    if (!shifts.empty())
+        CAF_HIP_TRY(hipMemcpy(p->d_shifts, shifts.data(), shifts.size() * 4, hipMemcpyHostToDevice));
+    CAF_HIP_TRY(hipMemcpy(p->d_tscale, tscale.data(), (size_t)T * 4, hipMemcpyHostToDevice));
+    CAF_HIP_TRY(hipMemcpy(p->d_gstart, gs.data(), gs.size() * 4, hipMemcpyHostToDevice));
+    CAF_HIP_TRY(hipMemcpy(p->d_glen, gl.data(), gl.size() * 4, hipMemcpyHostToDevice));
+
+    if ((rc = p->fwd.create(false, (size_t)B, (size_t)nb, (size_t)B))) return rc;
+    if ((rc = p->inv.create(true, (size_t)B, (size_t)nb * T * F, (size_t)p->pitch))) return rc;
+    p->workspace_bytes += (int64_t)p->fwd.work_bytes + (int64_t)p->inv.work_bytes;
+    return CAF_OK;
+}
+
+int32_t caf_plan_create(caf_plan* plan, const caf_plan_desc* desc) {
+    CAF_REQUIRE(plan && desc, "caf_plan_create: NULL argument");
+    *plan = nullptr;
+    caf_plan p = new (std::nothrow) caf_plan_t();
+    if (!p) {
+        set_error("out of host memory");
+        return CAF_ERR_NOMEM;
+    }
+    int32_t rc;
+    try {
+        rc = plan_build(p, desc);
+    } catch (const std::bad_alloc&) {
+        set_error("out of host memory while building template spectra");
+        rc = CAF_ERR_NOMEM;
+    }
+    if (rc != CAF_OK) {
+        p->release();
+        delete p;
+        return rc;
+    }
+    *plan = p;
+    return CAF_OK;
+}
+
+int32_t caf_plan_info(caf_plan plan, int32_t* block, int32_t* step, int32_t* blocks_per_batch,
+                      int64_t* workspace_bytes) {
+    CAF_REQUIRE(plan, "NULL plan");
+    if (block) *block = plan->B;
+    if (step) *step = plan->step;
+    if (blocks_per_batch) *blocks_per_batch = plan->nb;
+    if (workspace_bytes) *workspace_bytes = plan->workspace_bytes;
+    return CAF_OK;
+}
+
+int32_t caf_plan_profile(caf_plan plan, int32_t enable) {
+    CAF_REQUIRE(plan, "NULL plan");
+    plan->drain();
+    plan->prof = enable != 0;
+    for (int i = 0; i < CAF_NUM_STAGES; ++i) {
+        plan->acc_ms[i] = 0.0;
+        plan->acc_n[i] = 0;
+    }
+    return CAF_OK;
+}
+
+int32_t caf_plan_profile_get(caf_plan plan, double* ms, int64_t* launches) {
+    CAF_REQUIRE(plan, "NULL plan");
+    plan->drain();
+    for (int i = 0; i < CAF_NUM_STAGES; ++i) {
+        if (ms) ms[i] = plan->acc_ms[i];
+        if (launches) launches[i] = plan->acc_n[i];
+    }
+    return CAF_OK;
+}
+
+int32_t caf_plan_execute(caf_plan p, const float* d_rx, int64_t rx_len, int64_t shift_start, int64_t num_shifts,
+                         const caf_outputs* out, void* stream) {
+    CAF_REQUIRE(p && d_rx && out, "caf_plan_execute: NULL argument");
+    CAF_REQUIRE(rx_len >= p->N && rx_len <= p->max_rx, "rx_len outside [template_len, max_rx_len]");
+    CAF_REQUIRE(shift_start >= 0 && num_shifts >= 1, "need shift_start >= 0 and num_shifts >= 1");
+    CAF_REQUIRE(shift_start + num_shifts - 1 + p->N <= rx_len, "delays run past the end of rx");
+    CAF_REQUIRE((reinterpret_cast<uintptr_t>(d_rx) & 7) == 0, "d_rx must be 8-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const float2* rx = reinterpret_cast<const float2*>(d_rx);
+    const int T = p->T, F = p->F;
+    const bool want_peak = out->d_peak_val || out->d_peak_delay || out->d_peak_freq;
+
+    p->stage_begin(0, st);
+    launch_energy_prefix(rx, rx_len, p->d_tile_sums, p->d_prefix, st);
+    launch_inv_energy(p->d_prefix, shift_start, num_shifts, p->d_gstart, p->d_glen, p->G, p->d_inv_e, st);
+    p->stage_end(st);
+
+    const int64_t nblk = (num_shifts + p->step - 1) / p->step;
+    const int64_t nblk_pad = (nblk + p->nb - 1) / p->nb * p->nb;
+    for (int64_t b0 = 0; b0 < nblk; b0 += p->nb) {
+        p->stage_begin(1, st);
+        launch_gather_blocks(rx, rx_len, shift_start + b0 * p->step, p->step, p->B, p->nb, p->d_xb, st);
+        p->stage_end(st);
+
+        p->stage_begin(2, st);
+        int rc = p->fwd.exec(p->d_xb, st);
+        p->stage_end(st);
+        if (rc) return rc;
+
+        p->stage_begin(3, st);
+        launch_spectral_mul(p->mul_mode, p->d_xb, p->d_hc, p->d_shifts, p->B, p->pitch, F, T * F, p->hyp_per_wg, p->nb,
+                            p->d_pbuf, st);
+        p->stage_end(st);
+
+        p->stage_begin(4, st);
+        rc = p->inv.exec(p->d_pbuf, st);
+        p->stage_end(st);
+        if (rc) return rc;
+
+        p->stage_begin(5, st);
+        launch_magsq(p->d_pbuf, p->pitch, T, F, p->d_tscale, p->d_inv_e, num_shifts, shift_start, p->step, (int32_t)b0,
+                     p->nb, p->tiles_per_blk, out->d_surface, out->d_row_max, out->d_row_arg,
+                     want_peak ? p->d_partial : nullptr, p->partial_per_tmpl, st);
+        p->stage_end(st);
+    }
+    if (want_peak) {
+        p->stage_begin(6, st);
+        // only the records of the blocks touched by this call are valid
+        launch_peak_reduce(p->d_partial, nblk_pad * p->tiles_per_blk, p->partial_per_tmpl, T, out->d_peak_val,
+                           out->d_peak_delay, out->d_peak_freq, st);
+        p->stage_end(st);
+    }
+    CAF_HIP_TRY(hipGetLastError());
+    return CAF_OK;
+}
+
+int32_t caf_plan_execute_host(caf_plan p, const float* h_rx, int64_t rx_len, int64_t shift_start, int64_t num_shifts,
+                              float* h_surface, float* h_row_max, int32_t* h_row_arg, float* h_peak_val,
+                              int32_t* h_peak_delay, int32_t* h_peak_freq) {
+    CAF_REQUIRE(p && h_rx, "caf_plan_execute_host: NULL argument");
+    CAF_REQUIRE(num_shifts >= 1, "num_shifts must be >= 1");
+    const int T = p->T, F = p->F;
+    float2* d_rx = nullptr;
+    caf_outputs o;
+    std::memset(&o, 0, sizeof(o));
+    std::vector<void*> owned;
+    auto dalloc = [&](void** ptr, int64_t bytes) -> int {
+        CAF_HIP_TRY(hipMalloc(ptr, (size_t)std::max<int64_t>(bytes, 16)));
+        owned.push_back(*ptr);
+        return CAF_OK;
+    };
+    int rc = dalloc((void**)&d_rx, rx_len * 8);
+    if (!rc && h_surface) rc = dalloc((void**)&o.d_surface, (int64_t)T * num_shifts * F * 4);
+    if (!rc && h_row_max) rc = dalloc((void**)&o.d_row_max, (int64_t)T * num_shifts * 4);
+    if (!rc && h_row_arg) rc = dalloc((void**)&o.d_row_arg, (int64_t)T * num_shifts * 4);
+    if (!rc && h_peak_val) rc = dalloc((void**)&o.d_peak_val, T * 4);
+    if (!rc && h_peak_delay) rc = dalloc((void**)&o.d_peak_delay, T * 4);
+    if (!rc && h_peak_freq) rc = dalloc((void**)&o.d_peak_freq, T * 4);
+    auto cleanup = [&]() {
+        for (void* q : owned) (void)hipFree(q);
+    };
+    if (rc) {
+        cleanup();
+        return rc;
+    }
+    hipError_t e = hipMemcpy(d_rx, h_rx, (size_t)rx_len * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        rc = caf_plan_execute(p, reinterpret_cast<const float*>(d_rx), rx_len, shift_start, num_shifts, &o, nullptr);
+        if (rc) {
+            cleanup();
+            return rc;
+        }
+        e = hipStreamSynchronize(nullptr);
+    }
+    auto back = [&](void* h, const void* dptr, int64_t bytes) {
+        if (e == hipSuccess && h) e = hipMemcpy(h, dptr, (size_t)bytes, hipMemcpyDeviceToHost);
+    };
+    back(h_surface, o.d_surface, (int64_t)T * num_shifts * F * 4);
+    back(h_row_max, o.d_row_max, (int64_t)T * num_shifts * 4);
+    back(h_row_arg, o.d_row_arg, (int64_t)T * num_shifts * 4);
+    back(h_peak_val, o.d_peak_val, T * 4);
+    back(h_peak_delay, o.d_peak_delay, T * 4);
+    back(h_peak_freq, o.d_peak_freq, T * 4);
+    cleanup();
+    CAF_HIP_TRY(e);
+    return CAF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,180 @@
+"""GPU parity tests of the hypothesis engine (caf_plan_* through the C-ABI) against the oracle
+and the committed golden vectors.  Tolerance: CAF surface within 1e-4 of the surface
+maximum; global (delay, frequency) peak exact; per-delay argmax exact wherever the oracle's top-2
+margin exceeds the tolerance."""
+
+import numpy as np
+import pytest
+
+import oracle as O
+from conftest import cn, qpsk
+
+pytestmark = pytest.mark.gpu
+
+
+def _surface_check(surf, ref, rel=1e-4):
+    tol = rel * float(ref.max())
+    err = float(np.max(np.abs(surf - ref)))
+    assert err <= tol, "surface error %.3e > %.3e" % (err, tol)
+    return tol
+
+
+def _argmax_check(row_arg, row_max, ref, tol):
+    """Exact argmax where the oracle's top-2 margin is above tolerance; value always within tol."""
+    top2 = np.sort(ref, axis=1)[:, -2:] if ref.shape[1] > 1 else np.hstack((np.full((ref.shape[0], 1), -1.0), ref))
+    clear = (top2[:, 1] - top2[:, 0]) > 2 * tol
+    np.testing.assert_array_equal(row_arg[clear], np.argmax(ref, axis=1)[clear])
+    assert np.max(np.abs(row_max - ref.max(axis=1))) <= tol
+    return int(clear.sum())
+
+
+def test_c2_mini_golden(golden):
+    from pydsproutines_amd import CAFPlan, asarray
+
+    g = golden("c2_mini")
+    t, rx, bins, sh = g["template"], g["rx"], g["bins"], g["shifts"]
+    plan = CAFPlan(t, max_rx_len=rx.size, bins=bins, grid=t.size, log2_block=10)
+    res = plan.run(asarray(rx), surface=True)
+    surf = res.surface.get()[0]
+    assert surf.shape == (rx.size - t.size + 1, bins.size)
+    tol = _surface_check(surf[sh], g["caf"])
+    n_clear = _argmax_check(res.row_arg.get()[0][sh], res.row_max.get()[0][sh], g["caf"], tol)
+    assert n_clear > sh.size // 2
+    assert int(res.peak_delay.get()[0]) == int(g["d0"][0])
+    assert int(bins[res.peak_freq.get()[0]]) == int(g["k0"][0])
+    assert abs(float(res.peak_val.get()[0]) - g["caf"].max()) <= tol
+    # row results are exactly the max / first argmax of the surface the GPU itself wrote
+    np.testing.assert_array_equal(res.row_max.get()[0], surf.max(axis=1))
+    np.testing.assert_array_equal(res.row_arg.get()[0], np.argmax(surf, axis=1))
+
+
+@pytest.mark.parametrize("log2_block,nb", [(9, 1), (10, 3), (12, 2), (0, 0)])
+@pytest.mark.parametrize("F", [1, 5, 32, 200])
+def test_engine_vs_oracle_bins(log2_block, nb, F):
+    from pydsproutines_amd import CAFPlan, asarray
+
+    rng = np.random.default_rng(100 + F)
+    n, m = 128, 5000 + 37 * F
+    t = qpsk(rng, n)
+    rx = cn(rng, m)
+    d0, k0 = 2345, int(F // 3) - F // 2
+    rx[d0 : d0 + n] += (1.5 * t * np.exp(2j * np.pi * k0 * np.arange(n) / n)).astype(np.complex64)
+    bins = np.arange(F) - F // 2
+    plan = CAFPlan(t, max_rx_len=m, bins=bins, grid=n, log2_block=log2_block, blocks_per_batch=nb)
+    res = plan.run(asarray(rx), surface=True)
+    ref = O.caf_bins(t, rx, bins)
+    surf = res.surface.get()[0]
+    tol = _surface_check(surf, ref)
+    _argmax_check(res.row_arg.get()[0], res.row_max.get()[0], ref, tol)
+    r, c = np.unravel_index(np.argmax(ref), ref.shape)
+    assert (int(res.peak_delay.get()[0]), int(res.peak_freq.get()[0])) == (r, c) == (d0, k0 + F // 2)
+
+
+def test_shift_range_and_peak_only():
+    from pydsproutines_amd import CAFPlan, asarray
+
+    rng = np.random.default_rng(5)
+    n, m = 200, 9000  # non power-of-two template, grid = 256-point DFT bins
+    t = cn(rng, n)
+    rx = cn(rng, m)
+    rx[4000 : 4000 + n] += 2 * t
+    bins = np.array([0, 3, -3, 17, 100, -128], dtype=np.int32)  # unsorted, sparse, odd shifts
+    plan = CAFPlan(t, max_rx_len=m, bins=bins, grid=256, log2_block=11)
+    d_rx = asarray(rx)
+    res = plan.run(d_rx, shift_start=3900, num_shifts=333, surface=False, rows=True, peak=True)
+    assert res.surface is None
+    # oracle: 256-point DFT of the (zero-padded) 200-sample product
+    def ref_grid(sh):
+        win = np.lib.stride_tricks.sliding_window_view(rx, n)[sh].astype(np.complex128)
+        spec = np.fft.fft(win * t.conj().astype(np.complex128), 256, axis=1)[:, np.mod(bins, 256)]
+        e = np.sum(np.abs(win) ** 2, axis=1)
+        return np.abs(spec) ** 2 / e[:, None] / np.sum(np.abs(t.astype(np.complex128)) ** 2)
+
+    ref = ref_grid(np.arange(3900, 3900 + 333))
+    tol = 1e-4 * ref.max()
+    _argmax_check(res.row_arg.get()[0], res.row_max.get()[0], ref, tol)
+    assert int(res.peak_delay.get()[0]) == 4000 and int(res.peak_freq.get()[0]) == 0
+    # re-running with a shorter range after a longer one must not see stale partial peaks
+    res2 = plan.run(d_rx, shift_start=100, num_shifts=50)
+    ref2 = ref_grid(np.arange(100, 150))
+    assert abs(float(res2.peak_val.get()[0]) - ref2.max()) <= 1e-4 * ref2.max()
+    r2, c2 = np.unravel_index(np.argmax(ref2), ref2.shape)
+    assert (int(res2.peak_delay.get()[0]), int(res2.peak_freq.get()[0])) == (100 + r2, c2)
+
+
+def test_freqs_norm_table_mode_vs_groupxcorr(golden):
+    """Arbitrary (off-grid) frequencies + composite template == GroupXcorr (xcorrRoutines.py:852-954)."""
+    from pydsproutines_amd import CAFPlan, asarray
+
+    g = golden("groupxcorr_small")
+    fs = float(g["fs"][0])
+    y, starts, lengths, rx, freqs, sh = g["y"], g["starts"], g["lengths"], g["rx"], g["freqs"], g["shifts"]
+    rel = starts - starts[0]
+    span = int(rel[-1] + lengths[-1])
+    tm = np.zeros(span, np.complex64)
+    for s, r, l in zip(starts, rel, lengths):
+        tm[r : r + l] = y[s : s + l]
+    plan = CAFPlan(tm, max_rx_len=rx.size, freqs_norm=freqs / fs, group_starts=rel, group_lens=lengths, log2_block=11)
+    res = plan.run(asarray(rx), shift_start=int(sh[0]), num_shifts=sh.size, surface=True)
+    ref = O.GroupXcorr(y, starts, lengths, freqs, fs).caf(rx, sh)
+    surf = res.surface.get()[0]
+    tol = _surface_check(surf, ref)
+    np.testing.assert_allclose(res.row_max.get()[0], g["xc"], atol=tol)
+    clear = np.sort(ref, axis=1)[:, -1] - np.sort(ref, axis=1)[:, -2] > 2 * tol
+    np.testing.assert_array_equal(freqs[res.row_arg.get()[0]][clear], g["freqpeaks"][clear])
+    assert int(res.peak_delay.get()[0]) == 777 and freqs[int(res.peak_freq.get()[0])] == 6.0
+
+
+def test_multi_template_and_host_call():
+    from pydsproutines_amd import CAFPlan
+
+    rng = np.random.default_rng(9)
+    n, m, T = 64, 3000, 5
+    tm = np.stack([qpsk(rng, n) * (1 + i) for i in range(T)])
+    rx = (0.7 * cn(rng, m)).astype(np.complex64)
+    delays = [100, 700, 1500, 2200, 2900]
+    for i, d in enumerate(delays):
+        rx[d : d + n] += tm[i] / (1 + i)
+    plan = CAFPlan(tm, max_rx_len=m, bins=[0, 1, -1], grid=n, log2_block=9, blocks_per_batch=2)
+    out = plan.run_host(rx, surface=True)
+    for i in range(T):
+        ref = O.caf_bins(tm[i], rx, [0, 1, -1])
+        tol = _surface_check(out["surface"][i], ref)
+        assert int(out["peak_delay"][i]) == delays[i] and int(out["peak_freq"][i]) == 0
+        assert abs(out["peak_val"][i] - ref.max()) <= tol
+
+
+def test_c1_full(golden):
+    """Config C1: 1024-sample template vs 65536-sample rx, no frequency search (F=1, bin 0)."""
+    from pydsproutines_amd import CAFPlan, asarray
+
+    g = golden("c1_fastxcorr")
+    rx, d0 = g["rx"], int(g["d0"][0])
+    plan = CAFPlan(rx[d0 : d0 + 1024].copy(), max_rx_len=rx.size, bins=[0], grid=1024)
+    res = plan.run(asarray(rx))
+    q = res.row_max.get()[0]
+    assert q.shape == (64513,)
+    assert np.max(np.abs(q - g["qf2"])) <= 1e-6 + 1e-4 * 1.0 * 0.01  # 1e-6 abs (same arithmetic class)
+    assert int(res.peak_delay.get()[0]) == d0 and abs(float(res.peak_val.get()[0]) - 1.0) <= 1e-5
+
+
+def test_argument_validation():
+    from pydsproutines_amd import CAFPlan, asarray
+
+    t = np.ones(64, np.complex64)
+    with pytest.raises(ValueError):
+        CAFPlan(t, max_rx_len=32, bins=[0], grid=64)  # rx shorter than template
+    with pytest.raises(ValueError):
+        CAFPlan(t, max_rx_len=1000, bins=[0], grid=48)  # grid does not divide the block
+    with pytest.raises(ValueError):
+        CAFPlan(t, max_rx_len=1000, bins=[0], grid=64, log2_block=5)  # block < 2N
+    with pytest.raises(ValueError):
+        CAFPlan(t, max_rx_len=1000)  # neither bins nor freqs
+    plan = CAFPlan(t, max_rx_len=1000, bins=[0], grid=64)
+    rx = asarray(np.ones(500, np.complex64))
+    with pytest.raises(ValueError):
+        plan.run(rx, shift_start=400, num_shifts=100)  # runs past the end
+    with pytest.raises(ValueError):
+        plan.run(asarray(np.ones(2000, np.complex64)))  # longer than max_rx_len
+    with pytest.raises(TypeError):
+        plan.run(np.ones(500, np.complex64))  # host array where a device array is required
