@@ -136,15 +136,16 @@ __global__ __launch_bounds__(256) void k_inv_energy(const double* __restrict__ p
 // Overlap-save block gather: xb[b][m] = rx[src0 + b*step + m] (0 past the end of rx).
 // ----------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_gather_blocks(const float2* __restrict__ rx, int64_t rx_len,
-                                                       int64_t src0, int32_t step, int32_t bsz,
-                                                       float2* __restrict__ xb) {
-    const int b = blockIdx.y;
-    const int m = blockIdx.x * 256 + threadIdx.x;
-    if (m >= bsz) return;
-    const int64_t src = src0 + (int64_t)b * step + m;
+                                                       int64_t src0, int32_t step, int32_t log2_bsz,
+                                                       int64_t total, float2* __restrict__ xb) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int64_t b = i >> log2_bsz;
+    const int64_t m = i & (((int64_t)1 << log2_bsz) - 1);
+    const int64_t src = src0 + b * step + m;
     float2 v = make_float2(0.f, 0.f);
     if (src < rx_len) v = rx[src];
-    xb[(int64_t)b * bsz + m] = v;
+    xb[i] = v;
 }
 
 // hc[i] = conj(h[i]) * scale   (template spectra -> pre-conjugated, 1/B folded in)
@@ -420,8 +421,11 @@ void launch_inv_energy(const double* prefix, int64_t shift_start, int64_t num_sh
 
 void launch_gather_blocks(const float2* rx, int64_t rx_len, int64_t src0, int32_t step, int32_t bsz, int32_t nblk,
                           float2* xb, hipStream_t st) {
-    hipLaunchKernelGGL(k_gather_blocks, dim3((bsz + 255) / 256, nblk), dim3(256), 0, st, rx, rx_len, src0, step, bsz,
-                       xb);
+    int lb = 0;
+    while ((1 << lb) < bsz) ++lb;
+    const int64_t total = (int64_t)nblk * bsz;
+    hipLaunchKernelGGL(k_gather_blocks, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, rx, rx_len, src0, step,
+                       lb, total, xb);
 }
 
 void launch_conj_scale(float2* h, int64_t n, float scale, hipStream_t st) {

@@ -89,7 +89,7 @@ using namespace caf;
 struct caf_plan_t {
     int T = 0, N = 0, F = 0, G = 0;
     int freq_mode = 0, mul_mode = 0;
-    int B = 0, step = 0, pitch = 0, nb = 0, tiles_per_blk = 0, hyp_per_wg = 16;
+    int B = 0, step = 0, pitch = 0, nb = 0, tiles_per_blk = 0, hyp_per_wg = 16, fwd_chunk = 1;
     int64_t max_rx = 0, max_blocks = 0, partial_per_tmpl = 0;
     int device = 0;
     float2* d_hc = nullptr;
@@ -345,7 +345,9 @@ static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
     if ((rc = p->alloc(&p->d_tile_sums, prefix_num_tiles(d->max_rx_len) + 1024))) return rc;
     if ((rc = p->alloc(&p->d_prefix, d->max_rx_len + 1))) return rc;
     if ((rc = p->alloc(&p->d_inv_e, d->max_rx_len))) return rc;
-    if ((rc = p->alloc(&p->d_xb, (int64_t)nb * B))) return rc;
+    // all rx block spectra are produced up front, fwd_chunk blocks per rocFFT launch
+    p->fwd_chunk = (int)std::min<int64_t>(32, p->max_blocks);
+    if ((rc = p->alloc(&p->d_xb, (p->max_blocks + p->fwd_chunk) * B))) return rc;
     if ((rc = p->alloc(&p->d_pbuf, (int64_t)nb * T * F * p->pitch))) return rc;
     if ((rc = p->alloc(&p->d_partial, (int64_t)T * p->partial_per_tmpl))) return rc;
 
@@ -399,7 +401,7 @@ static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
     CAF_HIP_TRY(hipMemcpy(p->d_gstart, gs.data(), gs.size() * 4, hipMemcpyHostToDevice));
     CAF_HIP_TRY(hipMemcpy(p->d_glen, gl.data(), gl.size() * 4, hipMemcpyHostToDevice));
 
-    if ((rc = p->fwd.create(false, (size_t)B, (size_t)nb, (size_t)B))) return rc;
+    if ((rc = p->fwd.create(false, (size_t)B, (size_t)p->fwd_chunk, (size_t)B))) return rc;
     if ((rc = p->inv.create(true, (size_t)B, (size_t)nb * T * F, (size_t)p->pitch))) return rc;
     p->workspace_bytes += (int64_t)p->fwd.work_bytes + (int64_t)p->inv.work_bytes;
     return CAF_OK;
@@ -479,18 +481,21 @@ int32_t caf_plan_execute(caf_plan p, const float* d_rx, int64_t rx_len, int64_t 
 
     const int64_t nblk = (num_shifts + p->step - 1) / p->step;
     const int64_t nblk_pad = (nblk + p->nb - 1) / p->nb * p->nb;
-    for (int64_t b0 = 0; b0 < nblk; b0 += p->nb) {
-        p->stage_begin(1, st);
-        launch_gather_blocks(rx, rx_len, shift_start + b0 * p->step, p->step, p->B, p->nb, p->d_xb, st);
-        p->stage_end(st);
-
+    // overlap-save blocks of rx -> spectra X[b] for every block of this call
+    const int64_t nfwd = (nblk_pad + p->fwd_chunk - 1) / p->fwd_chunk;
+    p->stage_begin(1, st);
+    launch_gather_blocks(rx, rx_len, shift_start, p->step, p->B, (int32_t)(nfwd * p->fwd_chunk), p->d_xb, st);
+    p->stage_end(st);
+    for (int64_t c = 0; c < nfwd; ++c) {
         p->stage_begin(2, st);
-        int rc = p->fwd.exec(p->d_xb, st);
+        int rc = p->fwd.exec(p->d_xb + c * p->fwd_chunk * (int64_t)p->B, st);
         p->stage_end(st);
         if (rc) return rc;
-
+    }
+    for (int64_t b0 = 0; b0 < nblk; b0 += p->nb) {
+        int rc;
         p->stage_begin(3, st);
-        launch_spectral_mul(p->mul_mode, p->d_xb, p->d_hc, p->d_shifts, p->B, p->pitch, F, T * F, p->hyp_per_wg, p->nb,
+        launch_spectral_mul(p->mul_mode, p->d_xb + b0 * (int64_t)p->B, p->d_hc, p->d_shifts, p->B, p->pitch, F, T * F, p->hyp_per_wg, p->nb,
                             p->d_pbuf, st);
         p->stage_end(st);
 
