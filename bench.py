@@ -130,13 +130,16 @@ def main():
     res.peak_delay = DeviceArray((1,), np.int32, ptr=t_peak.data_ptr())
     res.peak_freq = DeviceArray((1,), np.int32, ptr=t_peak.data_ptr() + 4)
     res.peak_val = DeviceArray((1,), np.float32, ptr=t_peak.data_ptr() + 8)
-    table = torch.zeros((world, 3), dtype=torch.int32, device=device) if world > 1 else None
+    from pydsproutines_amd import sharding
+
+    gathered = {}
 
     def step():
         stream = torch.cuda.current_stream().cuda_stream
         plan.run(rx, surface=surface_on, rows=True, peak=True, stream=stream, out=res)
         if world > 1:
-            dist.all_gather_into_tensor(table, t_peak)
+            # the only collective of the path: RCCL all-gather of the (delay, freq, |peak|) rows
+            gathered["table"] = sharding.all_gather_peak_table(t_peak.view(1, 3), world)
 
     def fence():
         if world > 1:
@@ -165,7 +168,7 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        tb = table.cpu().numpy()
+        tb = gathered["table"].cpu().numpy()
         if not all(int(r[0]) == D0 and int(bins[r[1]]) == K0 for r in tb):
             raise SystemExit("gathered peak table is wrong: %r" % (tb,))
 

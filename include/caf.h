@@ -116,6 +116,9 @@ typedef struct caf_outputs {
     float* d_peak_val;     /* [T] float32: global maximum of QF2 for template t                    */
     int32_t* d_peak_delay; /* [T] int32: its delay (absolute sample index; lowest on ties)         */
     int32_t* d_peak_freq;  /* [T] int32: its frequency-hypothesis index f                          */
+    float* d_cqf;          /* [T][F][num_shifts] complex64 QF = r / (||tmpl|| * ||rx window||), i.e.   */
+                           /* hypothesis-major like TemplateCrossCorrelator.correlate (:352-357) and   */
+                           /* fastXcorr(absResult=False) (:533-548)                                    */
 } caf_outputs;
 
 /* d_rx: device complex64 [rx_len].  Requires shift_start >= 0 and
@@ -139,6 +142,79 @@ CAF_EXPORT int32_t caf_plan_execute_host(caf_plan plan, const float* h_rx, int64
                                          int64_t num_shifts, float* h_surface, float* h_row_max,
                                          int32_t* h_row_arg, float* h_peak_val, int32_t* h_peak_delay,
                                          int32_t* h_peak_freq);
+
+/* ---- the per-delay path (one DFT per delay; what the reference literally does) --------------
+ *
+ * For delays s_i = start + i*step, i < num:   z_i = FFT_N( rx[s_i : s_i+N] * cutout ) / (||cutout|| ||rx window||)
+ * replaces fastXcorr branches B/B'/C/C' (xcorrRoutines.py:511-580), cp_fastXcorr (:29-167) and
+ * IppXcorrFFT_32fc::xcorr_thread (IppXcorrFFT.cpp:94-178).  `d_cutout` is used AS GIVEN (the caller
+ * passes conj(cutout) for the usual correlation, like ippsMul_32fc(m_cutout(conj'd), ...) :133-138).
+ * Outputs (any may be NULL): d_qf2[num] = max_k |z_i[k]|^2, d_fidx[num] = first argmax bin,
+ * d_caf[num][N] = |z_i|^2 (float32), d_ccaf[num][N] = z_i (complex64).
+ * zero_oor != 0: delays whose window leaves [0, rx_len) give (0, 0) / zero rows (IppXcorrFFT.cpp:125-130);
+ * zero_oor == 0: such a delay is an error (CAF_ERR_INVALID). Blocking (allocates and frees scratch). */
+CAF_EXPORT int32_t caf_xcorr_perdelay(const float* d_cutout, int32_t n, const float* d_rx, int64_t rx_len,
+                                      int64_t start, int64_t step, int64_t num, int32_t zero_oor, float* d_qf2,
+                                      int32_t* d_fidx, float* d_caf, float* d_ccaf, int64_t batch_rows, void* stream);
+
+/* ---- stand-alone kernels (device pointers), one per reference CUDA kernel wrapper ------------- */
+/* batched row FFT, replaces cp.fft.fft(x, axis=1) / ifft (xcorrRoutines.py:135,246,339,352); in place when
+ * d_out == d_in; inverse != 0 applies the 1/len normalisation of numpy/cupy ifft. */
+CAF_EXPORT int32_t caf_fft_rows(const float* d_in, float* d_out, int64_t rows, int64_t len, int32_t inverse,
+                                void* stream);
+/* slidingMultiplyNormalised (multiplySlices.cu:113-216, cupyExtensions.py:491-560): d_z[idxlen][xlen] */
+CAF_EXPORT int32_t caf_sliding_multiply_normalised(const float* d_x, int32_t xlen, const float* d_y, int64_t ylen,
+                                                   int64_t start_idx, int64_t idxlen, double coefficient,
+                                                   float* d_z, void* stream);
+/* multiTemplateSlidingDotProduct (multiplySlices.cu:251-399, cupyExtensions.py:563-640) */
+CAF_EXPORT int32_t caf_multi_template_sliding_dot(const float* d_templates, const float* d_energies, int32_t num_templates,
+                                                  int32_t template_len, const float* d_x, int64_t xlen,
+                                                  int64_t start_idx, int64_t idxlen, int32_t* d_template_idx,
+                                                  float* d_qf2, void* stream);
+/* multiplySlicesWithIndexedRowsOptimistic (multiplySlices.cu:25-84, cupyExtensions.py:405-488) */
+/* d_out[num_slices][out_len]; slice i covers d_slice_lens[i] samples (NULL = out_len), zero beyond */
+CAF_EXPORT int32_t caf_multiply_slices_indexed_rows(const float* d_x, int64_t xlen, const float* d_rows, int32_t num_rows,
+                                                    int32_t row_len, const int32_t* d_slice_starts,
+                                                    const int32_t* d_slice_lens, const int32_t* d_row_idx,
+                                                    int32_t out_len, int64_t num_slices, float* d_out, void* stream);
+/* complex_magnSq_kernel<T,U> (complex_magn.cu:8-19): in complex64 (in_c128=0) or complex128, out f32 or f64 */
+CAF_EXPORT int32_t caf_complex_magnsq(const void* d_x, int64_t n, int32_t in_c128, void* d_out, int32_t out_f64,
+                                      void* stream);
+/* multiArgmaxAbsRows_complex64 (argmax.cu:93-153): first index of the maximum (NumPy tie-break) */
+CAF_EXPORT int32_t caf_argmax_abs_rows(const float* d_x, int64_t rows, int64_t len, uint32_t* d_argmax, float* d_max,
+                                       int32_t use_normsq, void* stream);
+/* movingAverage (filter.cu:291-347), multiMovingAverage (:196-240): causal, zero history, per row */
+CAF_EXPORT int32_t caf_moving_average(const float* d_x, int64_t rows, int64_t n, int32_t avg_length,
+                                      int32_t sum_instead, float* d_out, void* stream);
+/* movingComplexSum (filter.cu:374-438): d_out[n - L + 1] = |sum of L consecutive samples|^2 */
+CAF_EXPORT int32_t caf_complex_moving_sum(const float* d_x, int64_t n, int32_t sum_length, float* d_out, void* stream);
+/* copy*SlicesToMatrix_32fc (copying.cu:8-138): row i = x[starts[i] : +len] (starts_stride 1), the
+ * [start,end) rows of an (N,2) bounds array (starts_stride 2, zero beyond end), or x[start0 + i*inc : +len]
+ * when d_starts is NULL; samples outside x read as 0 */
+CAF_EXPORT int32_t caf_copy_slices_to_matrix(const float* d_x, int64_t xlen, const int32_t* d_starts,
+                                             int32_t starts_stride, int64_t start0, int64_t increment, int32_t len,
+                                             int64_t rows, float* d_out, void* stream);
+/* copy_groups_kernel32fc (cupyExtensions.py:17-38) */
+CAF_EXPORT int32_t caf_copy_groups(const float* d_x, float* d_y, const int32_t* d_x_starts, const int32_t* d_y_starts,
+                                   const int32_t* d_lengths, int32_t num_groups, void* stream);
+/* findLocalMaxima (peakfinding.cu:14-58): indices in ASCENDING order (deterministic), *d_count = total found */
+CAF_EXPORT int32_t caf_find_local_maxima(const float* d_x, int64_t n, float min_height, int32_t max_peaks,
+                                         int32_t* d_peak_index, int32_t* d_count, void* stream);
+/* filter_smtaps* (filter.cu:9-181) == scipy.signal.lfilter(taps, 1, x)[ds_phase::dsr] with carried-in history */
+CAF_EXPORT int32_t caf_fir_lfilter(const float* d_x, int64_t n, const float* d_taps, int32_t num_taps,
+                                   const float* d_delay, int32_t delay_len, int32_t dsr, int32_t ds_phase, float* d_out,
+                                   int64_t out_len, void* stream);
+/* upfirdn_naive / upfirdn_sm (upfirdn.cu:6-182) == scipy.signal.upfirdn(taps, x, up, down) per row */
+CAF_EXPORT int32_t caf_upfirdn(const float* d_x, int64_t rows, int64_t n, const float* d_taps, int32_t num_taps,
+                               int32_t up, int32_t down, float* d_out, float* d_out_abs, int64_t out_len, void* stream);
+/* CZTCachedGPU.runMany (spectralRoutines.py:370-391) / IppCZT32fc::runMany (CZT.cpp): rows of length m ->
+ * k CZT bins; aa[m], fv[nfft], ww_slice[k] are the cached complex64 constants (host computes them in f64). */
+CAF_EXPORT int32_t caf_czt_run_many(const float* d_x, int64_t rows, int32_t m, int32_t k, int32_t nfft,
+                                    const float* d_aa, const float* d_fv, const float* d_ww, float* d_out,
+                                    void* stream);
+/* per column of a complex64 (rows, n) matrix: max_r |z| and the first row attaining it
+ * (TemplateCrossCorrelator.correlate(returnMax=True), xcorrRoutines.py:361-371) */
+CAF_EXPORT int32_t caf_colmax_abs(const float* d_z, int32_t rows, int64_t n, float* d_max, int32_t* d_arg, void* stream);
 
 #ifdef __cplusplus
 }

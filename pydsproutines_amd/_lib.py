@@ -67,6 +67,7 @@ class CafOutputs(ct.Structure):
         ("d_peak_val", ct.c_void_p),
         ("d_peak_delay", ct.c_void_p),
         ("d_peak_freq", ct.c_void_p),
+        ("d_cqf", ct.c_void_p),
     ]
 
 
@@ -95,6 +96,22 @@ _SIGNATURES = {
     "caf_plan_profile": [_P, _I32],
     "caf_plan_profile_get": [_P, ct.POINTER(ct.c_double), ct.POINTER(_I64)],
     "caf_plan_execute_host": [_P, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P],
+    "caf_xcorr_perdelay": [_P, _I32, _P, _I64, _I64, _I64, _I64, _I32, _P, _P, _P, _P, _I64, _P],
+    "caf_fft_rows": [_P, _P, _I64, _I64, _I32, _P],
+    "caf_sliding_multiply_normalised": [_P, _I32, _P, _I64, _I64, _I64, ct.c_double, _P, _P],
+    "caf_multi_template_sliding_dot": [_P, _P, _I32, _I32, _P, _I64, _I64, _I64, _P, _P, _P],
+    "caf_multiply_slices_indexed_rows": [_P, _I64, _P, _I32, _I32, _P, _P, _P, _I32, _I64, _P, _P],
+    "caf_complex_magnsq": [_P, _I64, _I32, _P, _I32, _P],
+    "caf_argmax_abs_rows": [_P, _I64, _I64, _P, _P, _I32, _P],
+    "caf_moving_average": [_P, _I64, _I64, _I32, _I32, _P, _P],
+    "caf_complex_moving_sum": [_P, _I64, _I32, _P, _P],
+    "caf_copy_slices_to_matrix": [_P, _I64, _P, _I32, _I64, _I64, _I32, _I64, _P, _P],
+    "caf_copy_groups": [_P, _P, _P, _P, _P, _I32, _P],
+    "caf_find_local_maxima": [_P, _I64, ct.c_float, _I32, _P, _P, _P],
+    "caf_fir_lfilter": [_P, _I64, _P, _I32, _P, _I32, _I32, _I32, _P, _I64, _P],
+    "caf_upfirdn": [_P, _I64, _I64, _P, _I32, _I32, _I32, _P, _P, _I64, _P],
+    "caf_czt_run_many": [_P, _I64, _I32, _I32, _I32, _P, _P, _P, _P, _P],
+    "caf_colmax_abs": [_P, _I32, _I64, _P, _P, _P],
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

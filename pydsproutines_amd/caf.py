@@ -18,11 +18,12 @@ from .devarray import DeviceArray, as_device_ptr, asarray, empty
 class CAFResult:
     """Device-resident outputs of one execute."""
 
-    __slots__ = ("surface", "row_max", "row_arg", "peak_val", "peak_delay", "peak_freq")
+    __slots__ = ("surface", "row_max", "row_arg", "peak_val", "peak_delay", "peak_freq", "cqf")
 
     def __init__(self):
         self.surface = self.row_max = self.row_arg = None
         self.peak_val = self.peak_delay = self.peak_freq = None
+        self.cqf = None
 
 
 class CAFPlan:
@@ -109,7 +110,8 @@ class CAFPlan:
             pass
 
     # ------------------------------------------------------------------------------------
-    def run(self, rx, shift_start=0, num_shifts=None, surface=False, rows=True, peak=True, stream=None, out=None):
+    def run(self, rx, shift_start=0, num_shifts=None, surface=False, rows=True, peak=True, stream=None, out=None,
+            cqf=False):
         """Asynchronous execute on device-resident rx (DeviceArray or CUDA torch tensor).
 
         Returns a CAFResult of DeviceArrays: surface (T,S,F) float32 if requested, row_max (T,S)
@@ -131,7 +133,10 @@ class CAFPlan:
             res.peak_val = empty((self.T,), np.float32)
             res.peak_delay = empty((self.T,), np.int32)
             res.peak_freq = empty((self.T,), np.int32)
+        if cqf and res.cqf is None:
+            res.cqf = empty((self.T, self.F, S), np.complex64)
         o = _lib.CafOutputs()
+        o.d_cqf = res.cqf.ptr if cqf else None
         o.d_surface = res.surface.ptr if surface else None
         o.d_row_max = res.row_max.ptr if rows else None
         o.d_row_arg = res.row_arg.ptr if rows else None

@@ -1,0 +1,66 @@
+// rocFFT plumbing shared by the hypothesis-engine plan and the kernel-level ops:
+// batched 1-D complex64 transforms (in place or out of place) with an explicit batch distance.
+#include <rocfft/rocfft.h>
+
+#include <mutex>
+
+#include "caf_internal.h"
+
+namespace caf {
+
+static std::once_flag g_rocfft_once;
+
+#define CAF_FFT_TRY(expr)                                                                 \
+    do {                                                                                  \
+        rocfft_status _s = (expr);                                                        \
+        if (_s != rocfft_status_success) {                                                \
+            caf::set_error(std::string(#expr) + ": rocfft status " + std::to_string(_s)); \
+            return CAF_ERR_ROCFFT;                                                        \
+        }                                                                                 \
+    } while (0)
+
+int FftPlan::create(bool inverse, size_t len, size_t batch, size_t dist, bool inplace) {
+    std::call_once(g_rocfft_once, [] { rocfft_setup(); });
+    rocfft_plan_description desc = nullptr;
+    CAF_FFT_TRY(rocfft_plan_description_create(&desc));
+    size_t stride = 1;
+    CAF_FFT_TRY(rocfft_plan_description_set_data_layout(desc, rocfft_array_type_complex_interleaved,
+                                                        rocfft_array_type_complex_interleaved, nullptr, nullptr, 1,
+                                                        &stride, dist, 1, &stride, dist));
+    rocfft_plan p = nullptr;
+    rocfft_status s = rocfft_plan_create(&p, inplace ? rocfft_placement_inplace : rocfft_placement_notinplace,
+                                         inverse ? rocfft_transform_type_complex_inverse
+                                                 : rocfft_transform_type_complex_forward,
+                                         rocfft_precision_single, 1, &len, batch, desc);
+    rocfft_plan_description_destroy(desc);
+    CAF_FFT_TRY(s);
+    plan = p;
+    CAF_FFT_TRY(rocfft_plan_get_work_buffer_size(p, &work_bytes));
+    rocfft_execution_info ei = nullptr;
+    CAF_FFT_TRY(rocfft_execution_info_create(&ei));
+    info = ei;
+    if (work_bytes) {
+        CAF_HIP_TRY(hipMalloc(&work, work_bytes));
+        CAF_FFT_TRY(rocfft_execution_info_set_work_buffer(ei, work, work_bytes));
+    }
+    return CAF_OK;
+}
+
+int FftPlan::exec(void* in, void* out, hipStream_t st) {
+    CAF_FFT_TRY(rocfft_execution_info_set_stream((rocfft_execution_info)info, st));
+    void* ib[1] = {in};
+    void* ob[1] = {out};
+    CAF_FFT_TRY(rocfft_execute((rocfft_plan)plan, ib, (out && out != in) ? ob : nullptr, (rocfft_execution_info)info));
+    return CAF_OK;
+}
+
+void FftPlan::destroy() {
+    if (info) rocfft_execution_info_destroy((rocfft_execution_info)info);
+    if (plan) rocfft_plan_destroy((rocfft_plan)plan);
+    if (work) (void)hipFree(work);
+    info = nullptr;
+    plan = nullptr;
+    work = nullptr;
+}
+
+}  // namespace caf

@@ -47,5 +47,60 @@ void launch_magsq(const float2* pbuf, int32_t pitch, int32_t ntmpl, int32_t nfre
                   PeakRec* partial, int64_t partial_per_tmpl, hipStream_t st);
 void launch_peak_reduce(const PeakRec* partial, int64_t count, int64_t stride, int32_t ntmpl, float* pv, int32_t* pd,
                         int32_t* pf, hipStream_t st);
+void scan_tiles(double* tile_sums, int64_t ntiles, hipStream_t st);
+
+// caf_rows.hip
+void launch_sliding_multiply(const float2* x, int32_t xlen, const float2* y, int64_t ylen, const double* prefix,
+                             int64_t start, int64_t step, int64_t rows, double coef, int32_t zero_oor, float2* z,
+                             hipStream_t st);
+void launch_rows_argmax(const float2* z, int64_t rows, int64_t len, int32_t use_normsq, float scale, uint32_t* argmax,
+                        float* maxv, float* plane, hipStream_t st);
+void launch_magnsq(const void* x, int64_t n, int in_c128, void* out, int out_f64, hipStream_t st);
+int64_t moving_num_tiles(int64_t n);
+void launch_moving_average(const float* x, int64_t n, int32_t L, int32_t sum_instead, double* tile_sums,
+                           double* prefix, float* out, hipStream_t st);
+void launch_complex_moving_sum(const float2* x, int64_t n, int32_t L, float* out, hipStream_t st);
+void launch_multi_template_dot(const float2* tm, const float* te, int32_t ntm, int32_t L, const float2* x, int64_t xlen,
+                               const double* prefix, int64_t start, int64_t nslides, int32_t* tidx, float* qf2,
+                               hipStream_t st);
+void launch_multiply_indexed_rows(const float2* x, int64_t xlen, const float2* rows, int32_t row_len,
+                                  const int32_t* slice_start, const int32_t* slice_lens, const int32_t* row_idx,
+                                  int32_t slice_len, int64_t nslices, float2* out, hipStream_t st);
+void launch_copy_slices(const float2* x, int64_t xlen, const int32_t* starts, int32_t starts_stride, int64_t start0,
+                        int64_t inc, int32_t len, int64_t rows, float2* out, hipStream_t st);
+void launch_copy_groups(const float2* x, float2* y, const int32_t* xs, const int32_t* ys, const int32_t* lens,
+                        int32_t ngroups, hipStream_t st);
+void launch_find_local_maxima(const float* x, int64_t n, float min_height, uint8_t* flags, int32_t max_out,
+                              int32_t* idx, int32_t* count, hipStream_t st);
+void launch_fir(const float2* x, int64_t n, const float* taps, int32_t ntaps, const float2* delay, int32_t dlen,
+                int32_t dsr, int32_t phase, float2* out, int64_t nout, hipStream_t st);
+void launch_upfirdn(const float2* x, int64_t rows, int64_t n, const float* taps, int32_t ntaps, int32_t up, int32_t down,
+                    int64_t nout, float2* out, float* out_abs, hipStream_t st);
+void launch_rows_mul_vec(const float2* x, int64_t in_pitch, int64_t in_off, const float2* v, int64_t len, float2* y,
+                         int64_t out_pitch, int64_t pad_to, int64_t rows, float scale, hipStream_t st);
+void launch_complex_norm(const float2* pbuf, int32_t pitch, int32_t nfreq, const float* tscale, const float* inv_e,
+                         int64_t num_shifts, int32_t step, int32_t blk0, int32_t nblk, int32_t nhyp, float2* cqf,
+                         hipStream_t st);
+void launch_scale(float2* y, int64_t n, float scale, hipStream_t st);
+void launch_colmax_abs(const float2* z, int32_t rows, int64_t n, float* maxv, int32_t* arg, hipStream_t st);
+
+// rocFFT wrapper shared by the plan and the ops (caf_fft.hip)
+struct FftPlan {
+    void* plan = nullptr;  // rocfft_plan
+    void* info = nullptr;  // rocfft_execution_info
+    void* work = nullptr;
+    size_t work_bytes = 0;
+    int create(bool inverse, size_t len, size_t batch, size_t dist, bool inplace = true);
+    int exec(void* in, void* out, hipStream_t st);
+    void destroy();
+};
+
+#define CAF_REQUIRE(cond, msg)      \
+    do {                            \
+        if (!(cond)) {              \
+            caf::set_error(msg);    \
+            return CAF_ERR_INVALID; \
+        }                           \
+    } while (0)
 
 }  // namespace caf

@@ -412,6 +412,10 @@ void launch_energy_prefix(const float2* rx, int64_t m, double* tile_sums, double
     hipLaunchKernelGGL(k_prefix_write, dim3((unsigned)nt), dim3(PFX_THREADS), 0, st, rx, m, tile_sums, prefix);
 }
 
+void scan_tiles(double* tile_sums, int64_t ntiles, hipStream_t st) {
+    hipLaunchKernelGGL(k_scan_tile_sums, dim3(1), dim3(1024), 0, st, tile_sums, ntiles);
+}
+
 void launch_inv_energy(const double* prefix, int64_t shift_start, int64_t num_shifts, const int32_t* gstart,
                        const int32_t* glen, int32_t ngroups, float* inv_e, hipStream_t st) {
     const unsigned g = (unsigned)((num_shifts + 255) / 256);

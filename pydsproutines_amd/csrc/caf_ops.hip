@@ -1,0 +1,341 @@
+// libcaf C-ABI, part 2: the per-delay path and the stand-alone kernel-level entry points
+// (include/caf.h).  Host-side C++ that validates arguments, manages scratch and launches the
+// gfx950 kernels of caf_rows.hip / caf_kernels.hip and batched rocFFT rows.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
+
+#include "caf_internal.h"
+
+using namespace caf;
+
+namespace {
+
+// Small cache of row-FFT plans keyed by (device, len, batch, inverse, inplace); plans are reused
+// across calls (create -> use many), destroyed at process exit by the OS.
+struct PlanKey {
+    int dev;
+    int64_t len, batch;
+    int inv, inplace;
+    bool operator<(const PlanKey& o) const {
+        return std::tie(dev, len, batch, inv, inplace) < std::tie(o.dev, o.len, o.batch, o.inv, o.inplace);
+    }
+};
+std::mutex g_plan_mu;
+std::map<PlanKey, FftPlan> g_plans;
+
+int get_row_plan(int64_t len, int64_t batch, bool inverse, bool inplace, FftPlan** out) {
+    int dev = 0;
+    CAF_HIP_TRY(hipGetDevice(&dev));
+    PlanKey k{dev, len, batch, inverse ? 1 : 0, inplace ? 1 : 0};
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    auto it = g_plans.find(k);
+    if (it == g_plans.end()) {
+        if (g_plans.size() > 64) {  // bound the cache
+            for (auto& kv : g_plans) kv.second.destroy();
+            g_plans.clear();
+        }
+        FftPlan p;
+        int rc = p.create(inverse, (size_t)len, (size_t)batch, (size_t)len, inplace);
+        if (rc) {
+            p.destroy();
+            return rc;
+        }
+        it = g_plans.emplace(k, p).first;
+    }
+    *out = &it->second;
+    return CAF_OK;
+}
+
+// rows FFT of a (rows, len) matrix, chunked so that the plan batch is bounded
+int fft_rows(const float2* in, float2* out, int64_t rows, int64_t len, bool inverse, hipStream_t st) {
+    if (rows <= 0) return CAF_OK;
+    const bool inplace = (out == in);
+    int64_t done = 0;
+    while (done < rows) {
+        // largest power-of-two chunk <= remaining keeps the number of distinct plans small
+        int64_t chunk = 1;
+        while (chunk * 2 <= rows - done && chunk * 2 * len <= ((int64_t)1 << 27)) chunk *= 2;
+        FftPlan* p = nullptr;
+        int rc = get_row_plan(len, chunk, inverse, inplace, &p);
+        if (rc) return rc;
+        rc = p->exec((void*)(in + done * len), inplace ? nullptr : (void*)(out + done * len), st);
+        if (rc) return rc;
+        done += chunk;
+    }
+    return CAF_OK;
+}
+
+struct Scratch {
+    std::vector<void*> ptrs;
+    template <typename T>
+    int get(T** p, int64_t count) {
+        void* q = nullptr;
+        CAF_HIP_TRY(hipMalloc(&q, (size_t)std::max<int64_t>(count * (int64_t)sizeof(T), 16)));
+        ptrs.push_back(q);
+        *p = (T*)q;
+        return CAF_OK;
+    }
+    ~Scratch() {
+        for (void* q : ptrs) (void)hipFree(q);
+    }
+};
+
+int energy_prefix(const float2* x, int64_t n, Scratch& sc, double** prefix, hipStream_t st) {
+    double* tiles = nullptr;
+    int rc = sc.get(&tiles, prefix_num_tiles(n) + 1024);
+    if (rc) return rc;
+    if ((rc = sc.get(prefix, n + 1))) return rc;
+    launch_energy_prefix(x, n, tiles, *prefix, st);
+    return CAF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t caf_fft_rows(const float* d_in, float* d_out, int64_t rows, int64_t len, int32_t inverse, void* stream) {
+    CAF_REQUIRE(d_in && d_out && rows >= 0 && len >= 1, "caf_fft_rows: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    int rc = fft_rows((const float2*)d_in, (float2*)d_out, rows, len, inverse != 0, st);
+    if (rc) return rc;
+    if (inverse) launch_scale((float2*)d_out, rows * len, 1.0f / (float)len, st);  // numpy/cupy ifft normalisation
+    CAF_HIP_TRY(hipGetLastError());
+    return CAF_OK;
+}
+
+int32_t caf_xcorr_perdelay(const float* d_cutout, int32_t n, const float* d_rx, int64_t rx_len, int64_t start,
+                           int64_t step, int64_t num, int32_t zero_oor, float* d_qf2, int32_t* d_fidx, float* d_caf,
+                           float* d_ccaf, int64_t batch_rows, void* stream) {
+    CAF_REQUIRE(d_cutout && d_rx && n >= 1 && rx_len >= 1 && num >= 0 && step != 0, "caf_xcorr_perdelay: bad arguments");
+    if (!zero_oor) {
+        const int64_t last = start + (num - 1) * step;
+        const int64_t lo = std::min(start, last), hi = std::max(start, last);
+        CAF_REQUIRE(num == 0 || (lo >= 0 && hi + n <= rx_len), "caf_xcorr_perdelay: delay window leaves rx");
+    }
+    if (num == 0) return CAF_OK;
+    hipStream_t st = (hipStream_t)stream;
+    Scratch sc;
+    double* prefix = nullptr;
+    int rc = energy_prefix((const float2*)d_rx, rx_len, sc, &prefix, st);
+    if (rc) return rc;
+    // ||cutout|| in float64 on the host (n is small compared with the work that follows)
+    std::vector<float> hc((size_t)n * 2);
+    CAF_HIP_TRY(hipMemcpyAsync(hc.data(), d_cutout, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+    CAF_HIP_TRY(hipStreamSynchronize(st));
+    double e = 0.0;
+    for (size_t i = 0; i < hc.size(); ++i) e += (double)hc[i] * (double)hc[i];
+    const double cnorm = std::sqrt(e);
+    if (batch_rows <= 0) batch_rows = std::max<int64_t>(1, std::min<int64_t>(num, ((int64_t)1 << 25) / n));
+    batch_rows = std::min(batch_rows, num);
+    float2* rows = nullptr;
+    float2* direct = (float2*)d_ccaf;  // when the complex plane is wanted, build it in place
+    if (!direct && (rc = sc.get(&rows, batch_rows * n))) return rc;
+    for (int64_t r0 = 0; r0 < num; r0 += batch_rows) {
+        const int64_t nr = std::min(batch_rows, num - r0);
+        float2* buf = direct ? direct + r0 * n : rows;
+        launch_sliding_multiply((const float2*)d_cutout, n, (const float2*)d_rx, rx_len, prefix, start + r0 * step, step,
+                                nr, cnorm, zero_oor ? 1 : 0, buf, st);
+        if ((rc = fft_rows(buf, buf, nr, n, false, st))) return rc;
+        if (d_qf2 || d_fidx || d_caf)
+            launch_rows_argmax(buf, nr, n, 1, 1.0f, (uint32_t*)(d_fidx ? d_fidx + r0 : nullptr), d_qf2 ? d_qf2 + r0 : nullptr,
+                               d_caf ? d_caf + r0 * n : nullptr, st);
+    }
+    CAF_HIP_TRY(hipStreamSynchronize(st));  // scratch is freed on return
+    CAF_HIP_TRY(hipGetLastError());
+    return CAF_OK;
+}
+
+int32_t caf_sliding_multiply_normalised(const float* d_x, int32_t xlen, const float* d_y, int64_t ylen,
+                                        int64_t start_idx, int64_t idxlen, double coefficient, float* d_z,
+                                        void* stream) {
+    CAF_REQUIRE(d_x && d_y && d_z && xlen >= 1 && ylen >= 1, "caf_sliding_multiply_normalised: bad arguments");
+    CAF_REQUIRE(start_idx >= 0 && idxlen >= 0 && start_idx + idxlen <= ylen,
+                "startIdx and idxlen should be within the bounds of d_y.");
+    if (idxlen == 0) return CAF_OK;
+    hipStream_t st = (hipStream_t)stream;
+    Scratch sc;
+    double* prefix = nullptr;
+    int rc = energy_prefix((const float2*)d_y, ylen, sc, &prefix, st);
+    if (rc) return rc;
+    launch_sliding_multiply((const float2*)d_x, xlen, (const float2*)d_y, ylen, prefix, start_idx, 1, idxlen, coefficient,
+                            0, (float2*)d_z, st);
+    CAF_HIP_TRY(hipStreamSynchronize(st));
+    CAF_HIP_TRY(hipGetLastError());
+    return CAF_OK;
+}
+
+int32_t caf_multi_template_sliding_dot(const float* d_templates, const float* d_energies, int32_t num_templates,
+                                       int32_t template_len, const float* d_x, int64_t xlen, int64_t start_idx,
+                                       int64_t idxlen, int32_t* d_template_idx, float* d_qf2, void* stream) {
+    CAF_REQUIRE(d_templates && d_energies && d_x && d_template_idx && d_qf2, "caf_multi_template_sliding_dot: NULL");
+    CAF_REQUIRE(num_templates >= 1 && template_len >= 1, "need >= 1 template");
+    CAF_REQUIRE(template_len <= 8192, "template too long for the LDS-resident kernel (use the hypothesis engine)");
+    CAF_REQUIRE(start_idx >= 0 && idxlen >= 0 && start_idx + idxlen - 1 + template_len - 1 < xlen,
+                "final slide index should be within the bounds of d_x");
+    if (idxlen == 0) return CAF_OK;
+    hipStream_t st = (hipStream_t)stream;
+    Scratch sc;
+    double* prefix = nullptr;
+    int rc = energy_prefix((const float2*)d_x, xlen, sc, &prefix, st);
+    if (rc) return rc;
+    launch_multi_template_dot((const float2*)d_templates, d_energies, num_templates, template_len, (const float2*)d_x,
+                              xlen, prefix, start_idx, idxlen, d_template_idx, d_qf2, st);
+    CAF_HIP_TRY(hipStreamSynchronize(st));
+    CAF_HIP_TRY(hipGetLastError());
+    return CAF_OK;
+}
+
+int32_t caf_multiply_slices_indexed_rows(const float* d_x, int64_t xlen, const float* d_rows, int32_t num_rows,
+                                         int32_t row_len, const int32_t* d_slice_starts, const int32_t* d_slice_lens,
+                                         const int32_t* d_row_idx, int32_t out_len, int64_t num_slices, float* d_out,
+                                         void* stream) {
+    CAF_REQUIRE(d_x && d_rows && d_slice_starts && d_row_idx && d_out, "caf_multiply_slices_indexed_rows: NULL");
+    CAF_REQUIRE(out_len >= 1 && num_rows >= 1 && num_slices >= 0, "bad slice/row lengths");
+    launch_multiply_indexed_rows((const float2*)d_x, xlen, (const float2*)d_rows, row_len, d_slice_starts, d_slice_lens,
+                                 d_row_idx, out_len, num_slices, (float2*)d_out, (hipStream_t)stream);
+    CAF_HIP_TRY(hipGetLastError());
+    return CAF_OK;
+}
+
+int32_t caf_complex_magnsq(const void* d_x, int64_t n, int32_t in_c128, void* d_out, int32_t out_f64, void* stream) {
+    CAF_REQUIRE(d_x && d_out && n >= 0, "caf_complex_magnsq: bad arguments");
+    CAF_REQUIRE(!(in_c128 && !out_f64), "complex128 input needs float64 output");
+    if (n) launch_magnsq(d_x, n, in_c128, d_out, out_f64, (hipStream_t)stream);
+    CAF_HIP_TRY(hipGetLastError());
+    return CAF_OK;
+}
+
+int32_t caf_argmax_abs_rows(const float* d_x, int64_t rows, int64_t len, uint32_t* d_argmax, float* d_max,
+                            int32_t use_normsq, void* stream) {
+    CAF_REQUIRE(d_x && d_argmax && rows >= 0 && len >= 1, "caf_argmax_abs_rows: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    for (int64_t r0 = 0; r0 < rows; r0 += ((int64_t)1 << 30))
+        launch_rows_argmax((const float2*)d_x + r0 * len, std::min<int64_t>(rows - r0, (int64_t)1 << 30), len, use_normsq,
+                           1.0f, d_argmax + r0, d_max ? d_max + r0 : nullptr, nullptr, st);
+    CAF_HIP_TRY(hipGetLastError());
+    return CAF_OK;
+}
+
+int32_t caf_moving_average(const float* d_x, int64_t rows, int64_t n, int32_t avg_length, int32_t sum_instead,
+                           float* d_out, void* stream) {
+    CAF_REQUIRE(d_x && d_out && rows >= 1 && n >= 1 && avg_length >= 1, "caf_moving_average: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    Scratch sc;
+    double *tiles = nullptr, *prefix = nullptr;
+    int rc = sc.get(&tiles, moving_num_tiles(n) + 1024);
+    if (rc) return rc;
+    if ((rc = sc.get(&prefix, n + 1))) return rc;
+    for (int64_t r = 0; r < rows; ++r)
+        launch_moving_average(d_x + r * n, n, avg_length, sum_instead, tiles, prefix, d_out + r * n, st);
+    CAF_HIP_TRY(hipStreamSynchronize(st));
+    CAF_HIP_TRY(hipGetLastError());
+    return CAF_OK;
+}
+
+int32_t caf_complex_moving_sum(const float* d_x, int64_t n, int32_t sum_length, float* d_out, void* stream) {
+    CAF_REQUIRE(d_x && d_out && sum_length >= 1 && n >= sum_length, "caf_complex_moving_sum: bad arguments");
+    CAF_REQUIRE(sum_length <= 4096, "sum_length too long for the LDS-resident kernel");
+    launch_complex_moving_sum((const float2*)d_x, n, sum_length, d_out, (hipStream_t)stream);
+    CAF_HIP_TRY(hipGetLastError());
+    return CAF_OK;
+}
+
+int32_t caf_copy_slices_to_matrix(const float* d_x, int64_t xlen, const int32_t* d_starts, int32_t starts_stride,
+                                  int64_t start0, int64_t increment, int32_t len, int64_t rows, float* d_out,
+                                  void* stream) {
+    CAF_REQUIRE(d_x && d_out && len >= 1 && rows >= 0, "caf_copy_slices_to_matrix: bad arguments");
+    CAF_REQUIRE(!d_starts || starts_stride == 1 || starts_stride == 2, "starts_stride must be 1 or 2");
+    if (rows)
+        launch_copy_slices((const float2*)d_x, xlen, d_starts, starts_stride, start0, increment, len, rows,
+                           (float2*)d_out, (hipStream_t)stream);
+    CAF_HIP_TRY(hipGetLastError());
+    return CAF_OK;
+}
+
+int32_t caf_copy_groups(const float* d_x, float* d_y, const int32_t* d_x_starts, const int32_t* d_y_starts,
+                        const int32_t* d_lengths, int32_t num_groups, void* stream) {
+    CAF_REQUIRE(d_x && d_y && d_x_starts && d_y_starts && d_lengths && num_groups >= 0, "caf_copy_groups: bad arguments");
+    launch_copy_groups((const float2*)d_x, (float2*)d_y, d_x_starts, d_y_starts, d_lengths, num_groups,
+                       (hipStream_t)stream);
+    CAF_HIP_TRY(hipGetLastError());
+    return CAF_OK;
+}
+
+int32_t caf_find_local_maxima(const float* d_x, int64_t n, float min_height, int32_t max_peaks, int32_t* d_peak_index,
+                              int32_t* d_count, void* stream) {
+    CAF_REQUIRE(d_x && d_peak_index && d_count && n >= 1 && max_peaks >= 1, "caf_find_local_maxima: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    Scratch sc;
+    uint8_t* flags = nullptr;
+    int rc = sc.get(&flags, n);
+    if (rc) return rc;
+    launch_find_local_maxima(d_x, n, min_height, flags, max_peaks, d_peak_index, d_count, st);
+    CAF_HIP_TRY(hipStreamSynchronize(st));
+    CAF_HIP_TRY(hipGetLastError());
+    return CAF_OK;
+}
+
+int32_t caf_fir_lfilter(const float* d_x, int64_t n, const float* d_taps, int32_t num_taps, const float* d_delay,
+                        int32_t delay_len, int32_t dsr, int32_t ds_phase, float* d_out, int64_t out_len, void* stream) {
+    CAF_REQUIRE(d_x && d_taps && d_out && n >= 1 && num_taps >= 1, "caf_fir_lfilter: bad arguments");
+    CAF_REQUIRE(dsr >= 1 && ds_phase >= 0 && ds_phase < dsr, "dsPhase must be between in the range [0,dsr-1].");
+    CAF_REQUIRE(num_taps <= 4096, "more than 4096 taps: use an overlap-save FIR (hypothesis engine) instead");
+    CAF_REQUIRE(delay_len >= 0 && (delay_len == 0 || d_delay), "delay_len > 0 needs d_delay");
+    launch_fir((const float2*)d_x, n, d_taps, num_taps, (const float2*)d_delay, delay_len, dsr, ds_phase, (float2*)d_out,
+               out_len, (hipStream_t)stream);
+    CAF_HIP_TRY(hipGetLastError());
+    return CAF_OK;
+}
+
+int32_t caf_upfirdn(const float* d_x, int64_t rows, int64_t n, const float* d_taps, int32_t num_taps, int32_t up,
+                    int32_t down, float* d_out, float* d_out_abs, int64_t out_len, void* stream) {
+    CAF_REQUIRE(d_x && d_taps && (d_out || d_out_abs) && rows >= 1 && rows <= 65535 && n >= 1, "caf_upfirdn: bad arguments");
+    CAF_REQUIRE(num_taps >= 1 && num_taps <= 16384 && up >= 1 && down >= 1, "caf_upfirdn: bad taps/up/down");
+    const int64_t full = ((n - 1) * up + num_taps + down - 1) / down;
+    CAF_REQUIRE(out_len >= 1 && out_len <= full, "caf_upfirdn: out_len larger than the full upfirdn length");
+    launch_upfirdn((const float2*)d_x, rows, n, d_taps, num_taps, up, down, out_len, (float2*)d_out, d_out_abs,
+                   (hipStream_t)stream);
+    CAF_HIP_TRY(hipGetLastError());
+    return CAF_OK;
+}
+
+int32_t caf_czt_run_many(const float* d_x, int64_t rows, int32_t m, int32_t k, int32_t nfft, const float* d_aa,
+                         const float* d_fv, const float* d_ww, float* d_out, void* stream) {
+    CAF_REQUIRE(d_x && d_aa && d_fv && d_ww && d_out, "caf_czt_run_many: NULL");
+    CAF_REQUIRE(rows >= 0 && m >= 1 && k >= 1 && nfft >= m + k - 1, "caf_czt_run_many: need nfft >= m + k - 1");
+    if (rows == 0) return CAF_OK;
+    hipStream_t st = (hipStream_t)stream;
+    Scratch sc;
+    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(rows, ((int64_t)1 << 25) / nfft));
+    float2* buf = nullptr;
+    int rc = sc.get(&buf, chunk * nfft);
+    if (rc) return rc;
+    for (int64_t r0 = 0; r0 < rows; r0 += chunk) {
+        const int64_t nr = std::min(chunk, rows - r0);
+        // y = x * aa, zero-padded to nfft
+        launch_rows_mul_vec((const float2*)d_x + r0 * m, m, 0, (const float2*)d_aa, m, buf, nfft, nfft, nr, 1.0f, st);
+        if ((rc = fft_rows(buf, buf, nr, nfft, false, st))) return rc;
+        launch_rows_mul_vec(buf, nfft, 0, (const float2*)d_fv, nfft, buf, nfft, nfft, nr, 1.0f, st);
+        if ((rc = fft_rows(buf, buf, nr, nfft, true, st))) return rc;
+        // g[m-1 : m+k-1] * ww / nfft
+        launch_rows_mul_vec(buf, nfft, m - 1, (const float2*)d_ww, k, (float2*)d_out + r0 * k, k, k, nr,
+                            1.0f / (float)nfft, st);
+    }
+    CAF_HIP_TRY(hipStreamSynchronize(st));
+    CAF_HIP_TRY(hipGetLastError());
+    return CAF_OK;
+}
+
+int32_t caf_colmax_abs(const float* d_z, int32_t rows, int64_t n, float* d_max, int32_t* d_arg, void* stream) {
+    CAF_REQUIRE(d_z && d_max && d_arg && rows >= 1 && n >= 1, "caf_colmax_abs: bad arguments");
+    launch_colmax_abs((const float2*)d_z, rows, n, d_max, d_arg, (hipStream_t)stream);
+    CAF_HIP_TRY(hipGetLastError());
+    return CAF_OK;
+}
+
+}  // extern "C"

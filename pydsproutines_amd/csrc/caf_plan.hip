@@ -1,7 +1,5 @@
 // libcaf: plan object of the hypothesis engine + the C-ABI of include/caf.h.
 // Host-side C++ around the gfx950 kernels of caf_kernels.hip and batched rocFFT.
-#include <rocfft/rocfft.h>
-
 #include <algorithm>
 #include <cmath>
 #include <complex>
@@ -15,72 +13,6 @@ namespace caf {
 
 static thread_local std::string g_last_error;
 void set_error(const std::string& msg) { g_last_error = msg; }
-
-static std::once_flag g_rocfft_once;
-static void rocfft_init_once() {
-    std::call_once(g_rocfft_once, [] { rocfft_setup(); });
-}
-
-#define CAF_FFT_TRY(expr)                                                                 \
-    do {                                                                                  \
-        rocfft_status _s = (expr);                                                        \
-        if (_s != rocfft_status_success) {                                                \
-            caf::set_error(std::string(#expr) + ": rocfft status " + std::to_string(_s)); \
-            return CAF_ERR_ROCFFT;                                                        \
-        }                                                                                 \
-    } while (0)
-
-#define CAF_REQUIRE(cond, msg)          \
-    do {                                \
-        if (!(cond)) {                  \
-            caf::set_error(msg);        \
-            return CAF_ERR_INVALID;     \
-        }                               \
-    } while (0)
-
-struct FftPlan {
-    rocfft_plan plan = nullptr;
-    rocfft_execution_info info = nullptr;
-    void* work = nullptr;
-    size_t work_bytes = 0;
-
-    int create(bool inverse, size_t len, size_t batch, size_t dist) {
-        rocfft_init_once();
-        rocfft_plan_description desc = nullptr;
-        CAF_FFT_TRY(rocfft_plan_description_create(&desc));
-        size_t stride = 1;
-        CAF_FFT_TRY(rocfft_plan_description_set_data_layout(desc, rocfft_array_type_complex_interleaved,
-                                                            rocfft_array_type_complex_interleaved, nullptr, nullptr, 1,
-                                                            &stride, dist, 1, &stride, dist));
-        rocfft_status s = rocfft_plan_create(&plan, rocfft_placement_inplace,
-                                             inverse ? rocfft_transform_type_complex_inverse
-                                                     : rocfft_transform_type_complex_forward,
-                                             rocfft_precision_single, 1, &len, batch, desc);
-        rocfft_plan_description_destroy(desc);
-        CAF_FFT_TRY(s);
-        CAF_FFT_TRY(rocfft_plan_get_work_buffer_size(plan, &work_bytes));
-        CAF_FFT_TRY(rocfft_execution_info_create(&info));
-        if (work_bytes) {
-            CAF_HIP_TRY(hipMalloc(&work, work_bytes));
-            CAF_FFT_TRY(rocfft_execution_info_set_work_buffer(info, work, work_bytes));
-        }
-        return CAF_OK;
-    }
-    int exec(void* buf, hipStream_t st) {
-        CAF_FFT_TRY(rocfft_execution_info_set_stream(info, st));
-        void* in[1] = {buf};
-        CAF_FFT_TRY(rocfft_execute(plan, in, nullptr, info));
-        return CAF_OK;
-    }
-    void destroy() {
-        if (info) rocfft_execution_info_destroy(info);
-        if (plan) rocfft_plan_destroy(plan);
-        if (work) (void)hipFree(work);
-        info = nullptr;
-        plan = nullptr;
-        work = nullptr;
-    }
-};
 
 }  // namespace caf
 
@@ -388,7 +320,7 @@ static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
     {
         FftPlan tmp;
         rc = tmp.create(false, (size_t)B, (size_t)nspec, (size_t)B);
-        if (rc == CAF_OK) rc = tmp.exec(p->d_hc, nullptr);
+        if (rc == CAF_OK) rc = tmp.exec(p->d_hc, nullptr, nullptr);
         if (rc == CAF_OK) launch_conj_scale(p->d_hc, nspec * B, 1.0f / (float)B, nullptr);
         hipError_t e = hipStreamSynchronize(nullptr);
         tmp.destroy();
@@ -488,7 +420,7 @@ int32_t caf_plan_execute(caf_plan p, const float* d_rx, int64_t rx_len, int64_t 
     p->stage_end(st);
     for (int64_t c = 0; c < nfwd; ++c) {
         p->stage_begin(2, st);
-        int rc = p->fwd.exec(p->d_xb + c * p->fwd_chunk * (int64_t)p->B, st);
+        int rc = p->fwd.exec(p->d_xb + c * p->fwd_chunk * (int64_t)p->B, nullptr, st);
         p->stage_end(st);
         if (rc) return rc;
     }
@@ -500,12 +432,17 @@ int32_t caf_plan_execute(caf_plan p, const float* d_rx, int64_t rx_len, int64_t 
         p->stage_end(st);
 
         p->stage_begin(4, st);
-        rc = p->inv.exec(p->d_pbuf, st);
+        rc = p->inv.exec(p->d_pbuf, nullptr, st);
         p->stage_end(st);
         if (rc) return rc;
 
+        if (out->d_cqf)
+            launch_complex_norm(p->d_pbuf, p->pitch, F, p->d_tscale, p->d_inv_e, num_shifts, p->step, (int32_t)b0, p->nb,
+                                T * F, reinterpret_cast<float2*>(out->d_cqf), st);
+        const bool want_mag = out->d_surface || out->d_row_max || out->d_row_arg || want_peak;
         p->stage_begin(5, st);
-        launch_magsq(p->d_pbuf, p->pitch, T, F, p->d_tscale, p->d_inv_e, num_shifts, shift_start, p->step, (int32_t)b0,
+        if (want_mag)
+            launch_magsq(p->d_pbuf, p->pitch, T, F, p->d_tscale, p->d_inv_e, num_shifts, shift_start, p->step, (int32_t)b0,
                      p->nb, p->tiles_per_blk, out->d_surface, out->d_row_max, out->d_row_arg,
                      want_peak ? p->d_partial : nullptr, p->partial_per_tmpl, st);
         p->stage_end(st);

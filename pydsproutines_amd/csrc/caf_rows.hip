@@ -1,0 +1,643 @@
+// gfx950 kernels of the per-delay (time-domain product) path and the stand-alone kernel-level ops.
+// CDNA4 counterparts -- by semantics, not by code -- of the reference's
+//   custom_kernels/multiplySlices.cu:113-216  slidingMultiplyNormalised
+//   custom_kernels/multiplySlices.cu:251-399  multiTemplateSlidingDotProduct
+//   custom_kernels/multiplySlices.cu:25-84    multiplySlicesWithIndexedRowsOptimistic
+//   custom_kernels/complex_magn.cu:8-19       complex_magnSq_kernel<T,U>
+//   custom_kernels/argmax.cu:93-153           multiArgmaxAbsRows_complex64
+//   custom_kernels/filter.cu:196-347,374-438  movingAverage / multiMovingAverage / movingComplexSum
+//   custom_kernels/filter.cu:9-181            filter_smtaps*  (lfilter semantics)
+//   custom_kernels/upfirdn.cu:6-182           upfirdn_naive / upfirdn_sm
+//   custom_kernels/peakfinding.cu:14-58       findLocalMaxima
+//   custom_kernels/copying.cu:8-138, cupyExtensions.py:17-38   slice/group copies
+// All are HBM-bound (or, for long FIRs, VALU-bound) elementwise / sliding-window work.
+#include "caf_internal.h"
+
+namespace caf {
+
+// ---------------------------------------------------------------------------------------
+// z[i][t] = x[t] * y[s_i + t] / (sqrt(E_i) * coef),  s_i = start + i*step,
+// E_i = sum_t |y[s_i + t]|^2 from the f64 prefix array (samples past the end of y read as 0).
+// Rows whose window does not lie inside [0, ylen) are written as zeros when zero_oor != 0
+// (IppXcorrFFT.cpp:125-130 semantics), otherwise they are computed with zero padding
+// (multiplySlices.cu:147-163 semantics).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sliding_multiply(const float2* __restrict__ x, int32_t xlen,
+                                                          const float2* __restrict__ y, int64_t ylen,
+                                                          const double* __restrict__ prefix, int64_t start,
+                                                          int64_t step, double coef, int32_t zero_oor,
+                                                          float2* __restrict__ z) {
+    const int64_t row = blockIdx.y;
+    const int64_t s = start + row * step;
+    const bool oor = (s < 0) || (s + xlen > ylen);
+    float inv = 0.f;
+    if (!(oor && zero_oor)) {
+        int64_t a = s < 0 ? 0 : (s > ylen ? ylen : s);
+        int64_t b = s + xlen;
+        b = b < 0 ? 0 : (b > ylen ? ylen : b);
+        const double e = prefix[b] - prefix[a];
+        inv = (float)(1.0 / (sqrt(e) * coef));
+    }
+    float2* zr = z + row * (int64_t)xlen;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < xlen; t += gridDim.x * 256) {
+        float2 r = make_float2(0.f, 0.f);
+        const int64_t j = s + t;
+        if (!(oor && zero_oor) && j >= 0 && j < ylen) {
+            const float2 a = x[t], b = y[j];
+            r.x = (a.x * b.x - a.y * b.y) * inv;
+            r.y = (a.x * b.y + a.y * b.x) * inv;
+        }
+        zr[t] = r;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Row post-processing after the row FFT: per row r of (rows, len) complex64
+//   argmax[r] (first index of the maximum of |z|^2), max[r] (|z|^2 or |z|),
+//   optional |z|^2 plane (float32), all scaled by `scale`.
+// One workgroup per row.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_rows_argmax(const float2* __restrict__ z, int64_t len, int32_t use_normsq,
+                                                     float scale, uint32_t* __restrict__ argmax,
+                                                     float* __restrict__ maxv, float* __restrict__ plane) {
+    __shared__ float s_v[4];
+    __shared__ uint32_t s_i[4];
+    const int64_t row = blockIdx.x;
+    const float2* zr = z + row * len;
+    float bv = -1.f;
+    uint32_t bi = 0;
+    for (int64_t t = threadIdx.x; t < len; t += 256) {
+        const float2 a = zr[t];
+        const float v = (a.x * a.x + a.y * a.y) * scale;
+        if (plane) plane[row * len + t] = v;
+        if (v > bv) {
+            bv = v;
+            bi = (uint32_t)t;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o, 64);
+        const uint32_t oi = __shfl_xor(bi, o, 64);
+        if (ov > bv || (ov == bv && oi < bi)) {
+            bv = ov;
+            bi = oi;
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_v[threadIdx.x >> 6] = bv;
+        s_i[threadIdx.x >> 6] = bi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (s_v[w] > bv || (s_v[w] == bv && s_i[w] < bi)) {
+                bv = s_v[w];
+                bi = s_i[w];
+            }
+        if (bv < 0.f) {  // empty or all-NaN row: the reference's zero-initialised workspace (argmax.cu:108-109)
+            bv = 0.f;
+            bi = 0;
+        }
+        if (argmax) argmax[row] = bi;
+        if (maxv) maxv[row] = use_normsq ? bv : sqrtf(bv);
+    }
+}
+
+// |x|^2, elementwise.  IN: 0 complex64, 1 complex128.  OUT: 0 float32, 1 float64.
+template <typename TIn, typename TOut>
+__global__ __launch_bounds__(256) void k_magnsq(const TIn* __restrict__ x, int64_t n, TOut* __restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const TIn v = x[i];
+        out[i] = (TOut)(v.x * v.x + v.y * v.y);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Causal moving sum / mean of float32 (zeros in front), double accumulation (filter.cu:324-339).
+// Each workgroup produces MA_TILE outputs from an LDS-staged window; a thread sums its first
+// window directly and then slides, re-anchoring every MA_PER_THREAD outputs.
+// ---------------------------------------------------------------------------------------
+constexpr int MA_THREADS = 256;
+constexpr int MA_PER_THREAD = 16;
+constexpr int MA_TILE = MA_THREADS * MA_PER_THREAD;
+
+__global__ __launch_bounds__(MA_THREADS) void k_moving_sum_prefix(const float* __restrict__ x, int64_t n,
+                                                                  double* __restrict__ tile_sums) {
+    // per-tile sums of x (float64) for the two-level prefix used by the moving sum
+    __shared__ double s_part[MA_THREADS / 64];
+    const int64_t base = (int64_t)blockIdx.x * MA_TILE + (int64_t)threadIdx.x * MA_PER_THREAD;
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < MA_PER_THREAD; ++j)
+        if (base + j < n) acc += (double)x[base + j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < MA_THREADS / 64; ++w) t += s_part[w];
+        tile_sums[blockIdx.x] = t;
+    }
+}
+
+// prefix[i] = sum_{j<i} x[j] (float64), i in [0, n]
+__global__ __launch_bounds__(MA_THREADS) void k_moving_prefix_write(const float* __restrict__ x, int64_t n,
+                                                                    const double* __restrict__ tile_off,
+                                                                    double* __restrict__ prefix) {
+    __shared__ double s_wave[MA_THREADS / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t base = (int64_t)blockIdx.x * MA_TILE + (int64_t)threadIdx.x * MA_PER_THREAD;
+    double p[MA_PER_THREAD];
+    double tot = 0.0;
+#pragma unroll
+    for (int j = 0; j < MA_PER_THREAD; ++j) {
+        p[j] = tot;
+        if (base + j < n) tot += (double)x[base + j];
+    }
+    double incl = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double u = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += u;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    double off = tile_off[blockIdx.x] + (incl - tot);
+    for (int w = 0; w < wave; ++w) off += s_wave[w];
+#pragma unroll
+    for (int j = 0; j < MA_PER_THREAD; ++j)
+        if (base + j <= n) prefix[base + j] = off + p[j];
+}
+
+// out[i] = (prefix[i+1] - prefix[max(0, i+1-L)]) [/ L]
+__global__ __launch_bounds__(256) void k_moving_from_prefix(const double* __restrict__ prefix, int64_t n, int32_t L,
+                                                            int32_t sum_instead, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t lo = i + 1 - L;
+    const double s = prefix[i + 1] - prefix[lo < 0 ? 0 : lo];
+    out[i] = sum_instead ? (float)s : (float)(s / (double)L);
+}
+
+// valid-only forward moving complex sum -> |sum|^2 (filter.cu:374-438): direct O(L) per output in f64
+// staged through LDS (L is small in the reference's use: symbol-length sums).
+__global__ __launch_bounds__(256) void k_complex_moving_sum(const float2* __restrict__ x, int64_t n, int32_t L,
+                                                            float* __restrict__ out) {
+    extern __shared__ float2 s_x[];  // 256*CMS_PER + L - 1 samples
+    constexpr int PER = 8;
+    const int64_t o0 = (int64_t)blockIdx.x * 256 * PER;
+    const int64_t nout = n - L + 1;
+    const int span = 256 * PER + L - 1;
+    for (int t = threadIdx.x; t < span; t += 256) {
+        const int64_t j = o0 + t;
+        s_x[t] = (j < n) ? x[j] : make_float2(0.f, 0.f);
+    }
+    __syncthreads();
+    const int l0 = threadIdx.x * PER;
+    double sr = 0.0, si = 0.0;
+    for (int k = 0; k < L; ++k) {
+        sr += (double)s_x[l0 + k].x;
+        si += (double)s_x[l0 + k].y;
+    }
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int64_t o = o0 + l0 + j;
+        if (o < nout) out[o] = (float)(sr * sr + si * si);
+        sr += (double)s_x[l0 + j + L].x - (double)s_x[l0 + j].x;
+        si += (double)s_x[l0 + j + L].y - (double)s_x[l0 + j].y;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// multiTemplateSlidingDotProduct: per slide k, best template i of
+//   |sum_t T_i[t] x[k+t]|^2 / E_i / ||x[k:k+L]||^2   (first template wins ties; all-zero -> (0, 0)).
+// One workgroup owns MT_SLIDES consecutive slides; the x section and one template at a time live in
+// LDS; each wave computes whole dot products (lanes stride over t, shuffle reduce), so no block-wide
+// barrier per slide as in the reference.
+// ---------------------------------------------------------------------------------------
+constexpr int MT_SLIDES = 64;
+
+__global__ __launch_bounds__(256) void k_multi_template_dot(const float2* __restrict__ tm, const float* __restrict__ te,
+                                                            int32_t ntm, int32_t L, const float2* __restrict__ x,
+                                                            int64_t xlen, const double* __restrict__ prefix,
+                                                            int64_t start, int64_t nslides, int32_t* __restrict__ tidx,
+                                                            float* __restrict__ qf2) {
+    extern __shared__ float2 s_mem[];
+    float2* s_t = s_mem;          // L
+    float2* s_xs = s_mem + L;     // MT_SLIDES + L - 1
+    const int64_t k0 = (int64_t)blockIdx.x * MT_SLIDES;
+    const int span = MT_SLIDES + L - 1;
+    for (int t = threadIdx.x; t < span; t += 256) {
+        const int64_t j = start + k0 + t;
+        s_xs[t] = (j < xlen) ? x[j] : make_float2(0.f, 0.f);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int PER_WAVE = MT_SLIDES / 4;
+    float bv[PER_WAVE];
+    int32_t bi[PER_WAVE];
+#pragma unroll
+    for (int r = 0; r < PER_WAVE; ++r) {
+        bv[r] = 0.f;
+        bi[r] = 0;
+    }
+    for (int i = 0; i < ntm; ++i) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < L; t += 256) s_t[t] = tm[(int64_t)i * L + t];
+        __syncthreads();
+        const float inv_te = 1.0f / te[i];
+#pragma unroll
+        for (int r = 0; r < PER_WAVE; ++r) {
+            const int k = wave * PER_WAVE + r;
+            if (k0 + k >= nslides) break;
+            float ar = 0.f, ai = 0.f;
+            for (int t = lane; t < L; t += 64) {
+                const float2 a = s_t[t], b = s_xs[k + t];
+                ar += a.x * b.x - a.y * b.y;
+                ai += a.x * b.y + a.y * b.x;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                ar += __shfl_xor(ar, o, 64);
+                ai += __shfl_xor(ai, o, 64);
+            }
+            const int64_t s = start + k0 + k;
+            int64_t e1 = s + L;
+            if (e1 > xlen) e1 = xlen;
+            const float e = (float)(prefix[e1] - prefix[s]);
+            const float v = (ar * ar + ai * ai) * inv_te / e;
+            if (v > bv[r]) {
+                bv[r] = v;
+                bi[r] = i;
+            }
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < PER_WAVE; ++r) {
+            const int64_t k = k0 + wave * PER_WAVE + r;
+            if (k < nslides) {
+                tidx[k] = bi[r];
+                qf2[k] = bv[r];
+            }
+        }
+    }
+}
+
+// out[i][t] = rows[row_idx[i]][t] * x[slice_start[i] + t] for t < slice_lens[i] (0 beyond), t < slice_len
+__global__ __launch_bounds__(256) void k_multiply_indexed_rows(const float2* __restrict__ x, int64_t xlen,
+                                                               const float2* __restrict__ rows, int32_t row_len,
+                                                               const int32_t* __restrict__ slice_start,
+                                                               const int32_t* __restrict__ slice_lens,
+                                                               const int32_t* __restrict__ row_idx, int32_t slice_len,
+                                                               float2* __restrict__ out) {
+    const int64_t i = blockIdx.y;
+    const float2* r = rows + (int64_t)row_idx[i] * row_len;
+    const int64_t s0 = slice_start[i];
+    const int li = slice_lens ? min(slice_lens[i], row_len) : min(slice_len, row_len);
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < slice_len; t += gridDim.x * 256) {
+        const int64_t j = s0 + t;
+        float2 v = make_float2(0.f, 0.f);
+        if (t < li && j >= 0 && j < xlen) {
+            const float2 a = r[t], b = x[j];
+            v = make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+        }
+        out[i * slice_len + t] = v;
+    }
+}
+
+// generic gather of equal-length slices: out[i][t] = x[starts[i] + t]  (or start0 + i*inc when starts == NULL)
+// starts_stride = 2 reads the start column of an (N, 2) [start, end) bounds array and limits row i to end-start.
+__global__ __launch_bounds__(256) void k_copy_slices(const float2* __restrict__ x, int64_t xlen,
+                                                     const int32_t* __restrict__ starts, int32_t starts_stride,
+                                                     int64_t start0, int64_t inc, int32_t len,
+                                                     float2* __restrict__ out) {
+    const int64_t i = blockIdx.y;
+    const int64_t s0 = starts ? (int64_t)starts[i * starts_stride] : start0 + i * inc;
+    const int li = (starts && starts_stride == 2) ? min(len, starts[i * 2 + 1] - starts[i * 2]) : len;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < len; t += gridDim.x * 256) {
+        const int64_t j = s0 + t;
+        out[i * len + t] = (t < li && j >= 0 && j < xlen) ? x[j] : make_float2(0.f, 0.f);
+    }
+}
+
+// copy groups: y[ys[b] + i] = x[xs[b] + i], i < len[b]   (cupyExtensions.py:17-38)
+__global__ __launch_bounds__(256) void k_copy_groups(const float2* __restrict__ x, float2* __restrict__ y,
+                                                     const int32_t* __restrict__ xs, const int32_t* __restrict__ ys,
+                                                     const int32_t* __restrict__ lens) {
+    const int b = blockIdx.x;
+    const int64_t xo = xs[b], yo = ys[b];
+    for (int i = threadIdx.x; i < lens[b]; i += 256) y[yo + i] = x[xo + i];
+}
+
+// findLocalMaxima: ordered compaction in two passes (flags -> host-free ordered scan is overkill for the
+// sparse peak lists this is used for): pass 1 marks, pass 2 is an ordered atomic-free single-workgroup scan.
+__global__ __launch_bounds__(256) void k_local_max_flags(const float* __restrict__ x, int64_t n, float min_height,
+                                                         uint8_t* __restrict__ flags) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float y = x[i];
+    const float l = i > 0 ? x[i - 1] : 0.f;
+    const float r = i + 1 < n ? x[i + 1] : 0.f;
+    flags[i] = (y > min_height && y > l && y > r) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(1024) void k_compact_flags(const uint8_t* __restrict__ flags, int64_t n, int32_t max_out,
+                                                        int32_t* __restrict__ idx, int32_t* __restrict__ count) {
+    __shared__ int32_t s_wave[16];
+    __shared__ int32_t s_base;
+    if (threadIdx.x == 0) s_base = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t c = 0; c < n; c += 1024) {
+        const int64_t i = c + threadIdx.x;
+        const int f = (i < n) ? flags[i] : 0;
+        const unsigned long long m = __ballot(f);
+        const int within = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wave[wave] = __popcll(m);
+        __syncthreads();
+        int off = s_base;
+        for (int w = 0; w < wave; ++w) off += s_wave[w];
+        if (f && off + within < max_out) idx[off + within] = (int32_t)i;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int t = 0;
+            for (int w = 0; w < 16; ++w) t += s_wave[w];
+            s_base += t;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *count = s_base;
+}
+
+// ---------------------------------------------------------------------------------------
+// FIR == scipy.signal.lfilter(taps, 1, x) on complex64 with real float32 taps, optional carried-in
+// history (`delay` = the dlen samples preceding x) and decimation out[k] = y[k*dsr + phase].
+// Taps and the input window of the tile are staged in LDS.
+// ---------------------------------------------------------------------------------------
+constexpr int FIR_TILE = 1024;  // outputs (before decimation) per workgroup
+
+__global__ __launch_bounds__(256) void k_fir(const float2* __restrict__ x, int64_t n, const float* __restrict__ taps,
+                                             int32_t ntaps, const float2* __restrict__ delay, int32_t dlen,
+                                             int32_t dsr, int32_t phase, float2* __restrict__ out, int64_t nout) {
+    extern __shared__ float s_fir[];
+    float* s_taps = s_fir;                                              // ntaps
+    float2* s_in = reinterpret_cast<float2*>(s_fir + ((ntaps + 1) & ~1));  // FIR_TILE + ntaps - 1
+    const int64_t i0 = (int64_t)blockIdx.x * FIR_TILE;  // first un-decimated output index of the tile
+    for (int t = threadIdx.x; t < ntaps; t += 256) s_taps[t] = taps[t];
+    const int span = FIR_TILE + ntaps - 1;
+    for (int t = threadIdx.x; t < span; t += 256) {
+        const int64_t j = i0 - (ntaps - 1) + t;  // input index
+        float2 v = make_float2(0.f, 0.f);
+        if (j >= 0) {
+            if (j < n) v = x[j];
+        } else if (delay && -j <= dlen) {
+            v = delay[dlen + j];
+        }
+        s_in[t] = v;
+    }
+    __syncthreads();
+    for (int l = threadIdx.x; l < FIR_TILE; l += 256) {
+        const int64_t i = i0 + l;
+        if (i >= n) break;
+        if (dsr > 1 && ((i - phase) % dsr != 0 || i < phase)) continue;
+        float ar = 0.f, ai = 0.f;
+        // y[i] = sum_k taps[k] x[i-k];  x[i-k] sits at s_in[l + ntaps-1 - k]
+        const float2* w = s_in + l + ntaps - 1;
+        for (int k = 0; k < ntaps; ++k) {
+            const float c = s_taps[k];
+            ar += c * w[-k].x;
+            ai += c * w[-k].y;
+        }
+        const int64_t o = (i - phase) / dsr;
+        if (o < nout) out[o] = make_float2(ar, ai);
+    }
+}
+
+// upfirdn == scipy.signal.upfirdn(taps, x, up, down) per row; out[r][o] = sum_k taps[k] xu[o*down - k],
+// xu = x upsampled by `up` (zeros between samples).  Optional |.| output.
+__global__ __launch_bounds__(256) void k_upfirdn(const float2* __restrict__ x, int64_t n, const float* __restrict__ taps,
+                                                 int32_t ntaps, int32_t up, int32_t down, int64_t nout,
+                                                 float2* __restrict__ out, float* __restrict__ out_abs) {
+    extern __shared__ float s_tp[];
+    for (int t = threadIdx.x; t < ntaps; t += 256) s_tp[t] = taps[t];
+    __syncthreads();
+    const int64_t row = blockIdx.y;
+    const float2* xr = x + row * n;
+    const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (o >= nout) return;
+    const int64_t pos = o * down;  // index into the upsampled stream
+    // taps index k must satisfy (pos - k) % up == 0 and 0 <= (pos-k)/up < n
+    int64_t k = pos % up;
+    float ar = 0.f, ai = 0.f;
+    for (; k < ntaps; k += up) {
+        const int64_t j = (pos - k) / up;
+        if (pos - k < 0) break;
+        if (j < n) {
+            const float c = s_tp[k];
+            const float2 v = xr[j];
+            ar += c * v.x;
+            ai += c * v.y;
+        }
+    }
+    if (out) out[row * nout + o] = make_float2(ar, ai);
+    if (out_abs) out_abs[row * nout + o] = sqrtf(ar * ar + ai * ai);
+}
+
+// elementwise complex row-broadcast multiply: y[r][i] = x[r][i] * v[i]  (CZT pre/post chirps, spectra)
+__global__ __launch_bounds__(256) void k_rows_mul_vec(const float2* __restrict__ x, int64_t in_pitch, int64_t in_off,
+                                                      const float2* __restrict__ v, int64_t len,
+                                                      float2* __restrict__ y, int64_t out_pitch, int64_t pad_to,
+                                                      float scale) {
+    const int64_t r = blockIdx.y;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < pad_to; i += (int64_t)gridDim.x * 256) {
+        float2 o = make_float2(0.f, 0.f);
+        if (i < len) {
+            const float2 a = x[r * in_pitch + in_off + i], b = v[i];
+            o = make_float2((a.x * b.x - a.y * b.y) * scale, (a.x * b.y + a.y * b.x) * scale);
+        }
+        y[r * out_pitch + i] = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_scale(float2* __restrict__ y, int64_t n, float scale) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        float2 v = y[i];
+        y[i] = make_float2(v.x * scale, v.y * scale);
+    }
+}
+
+// ---- engine add-ons: complex QF output and the across-template maximum -------------------
+// cqf[h][i] = P[h][i] * sqrt(tscale[t] * inv_e[i])   (TemplateCrossCorrelator layout, xcorrRoutines.py:352-357)
+__global__ __launch_bounds__(256) void k_complex_norm(const float2* __restrict__ pbuf, int32_t pitch, int32_t nfreq,
+                                                      const float* __restrict__ tscale,
+                                                      const float* __restrict__ inv_e, int64_t num_shifts,
+                                                      int32_t step, int32_t blk0, int32_t nhyp,
+                                                      float2* __restrict__ cqf) {
+    const int z = blockIdx.z, h = blockIdx.y;
+    const int blk = blk0 + z;
+    const int sl = blockIdx.x * 256 + threadIdx.x;
+    const int64_t rel = (int64_t)blk * step + sl;
+    if (sl >= step || rel >= num_shifts) return;
+    const float2 p = pbuf[((int64_t)z * nhyp + h) * pitch + sl];
+    const float g = sqrtf(tscale[h / nfreq]) * sqrtf(inv_e[rel]);
+    cqf[(int64_t)h * num_shifts + rel] = make_float2(p.x * g, p.y * g);
+}
+
+// per column i of complex (rows, n): max_r |z[r][i]| and its first row index
+__global__ __launch_bounds__(256) void k_colmax_abs(const float2* __restrict__ z, int32_t rows, int64_t n,
+                                                    float* __restrict__ maxv, int32_t* __restrict__ arg) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float bv = -1.f;
+    int32_t bi = 0;
+    for (int r = 0; r < rows; ++r) {
+        const float2 a = z[(int64_t)r * n + i];
+        // |z| via float64 so that the float32 result is the correctly rounded one (== numpy/hypotf)
+        const float v = (float)sqrt((double)a.x * (double)a.x + (double)a.y * (double)a.y);
+        if (v > bv) {
+            bv = v;
+            bi = r;
+        }
+    }
+    maxv[i] = bv;
+    arg[i] = bi;
+}
+
+// ---------------------------------------------------------------------------------------
+// launch wrappers
+// ---------------------------------------------------------------------------------------
+static inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
+
+void launch_sliding_multiply(const float2* x, int32_t xlen, const float2* y, int64_t ylen, const double* prefix,
+                             int64_t start, int64_t step, int64_t rows, double coef, int32_t zero_oor, float2* z,
+                             hipStream_t st) {
+    const unsigned gx = std::min<unsigned>(cdiv(xlen, 256), 64);
+    for (int64_t r0 = 0; r0 < rows; r0 += 65535) {
+        const int64_t nr = std::min<int64_t>(65535, rows - r0);
+        hipLaunchKernelGGL(k_sliding_multiply, dim3(gx, (unsigned)nr), dim3(256), 0, st, x, xlen, y, ylen, prefix,
+                           start + r0 * step, step, coef, zero_oor, z + r0 * (int64_t)xlen);
+    }
+}
+
+void launch_rows_argmax(const float2* z, int64_t rows, int64_t len, int32_t use_normsq, float scale, uint32_t* argmax,
+                        float* maxv, float* plane, hipStream_t st) {
+    if (rows <= 0) return;
+    hipLaunchKernelGGL(k_rows_argmax, dim3((unsigned)rows), dim3(256), 0, st, z, len, use_normsq, scale, argmax, maxv,
+                       plane);
+}
+
+void launch_magnsq(const void* x, int64_t n, int in_c128, void* out, int out_f64, hipStream_t st) {
+    const unsigned g = std::min<unsigned>(cdiv(n, 256), 256 * 16);
+    if (!in_c128 && !out_f64)
+        hipLaunchKernelGGL((k_magnsq<float2, float>), dim3(g), dim3(256), 0, st, (const float2*)x, n, (float*)out);
+    else if (!in_c128 && out_f64)
+        hipLaunchKernelGGL((k_magnsq<float2, double>), dim3(g), dim3(256), 0, st, (const float2*)x, n, (double*)out);
+    else
+        hipLaunchKernelGGL((k_magnsq<double2, double>), dim3(g), dim3(256), 0, st, (const double2*)x, n, (double*)out);
+}
+
+int64_t moving_num_tiles(int64_t n) { return (n + 1 + MA_TILE - 1) / MA_TILE; }
+
+void scan_tiles(double* tile_sums, int64_t ntiles, hipStream_t st);  // caf_kernels.hip
+
+void launch_moving_average(const float* x, int64_t n, int32_t L, int32_t sum_instead, double* tile_sums,
+                           double* prefix, float* out, hipStream_t st) {
+    const int64_t nt = moving_num_tiles(n);
+    hipLaunchKernelGGL(k_moving_sum_prefix, dim3((unsigned)nt), dim3(MA_THREADS), 0, st, x, n, tile_sums);
+    scan_tiles(tile_sums, nt, st);
+    hipLaunchKernelGGL(k_moving_prefix_write, dim3((unsigned)nt), dim3(MA_THREADS), 0, st, x, n, tile_sums, prefix);
+    hipLaunchKernelGGL(k_moving_from_prefix, dim3(cdiv(n, 256)), dim3(256), 0, st, prefix, n, L, sum_instead, out);
+}
+
+void launch_complex_moving_sum(const float2* x, int64_t n, int32_t L, float* out, hipStream_t st) {
+    const int64_t nout = n - L + 1;
+    const size_t sm = (size_t)(256 * 8 + L - 1 + 8) * sizeof(float2);
+    hipLaunchKernelGGL(k_complex_moving_sum, dim3(cdiv(nout, 256 * 8)), dim3(256), sm, st, x, n, L, out);
+}
+
+void launch_multi_template_dot(const float2* tm, const float* te, int32_t ntm, int32_t L, const float2* x, int64_t xlen,
+                               const double* prefix, int64_t start, int64_t nslides, int32_t* tidx, float* qf2,
+                               hipStream_t st) {
+    const size_t sm = (size_t)(2 * L + MT_SLIDES) * sizeof(float2);
+    hipLaunchKernelGGL(k_multi_template_dot, dim3(cdiv(nslides, MT_SLIDES)), dim3(256), sm, st, tm, te, ntm, L, x, xlen,
+                       prefix, start, nslides, tidx, qf2);
+}
+
+void launch_multiply_indexed_rows(const float2* x, int64_t xlen, const float2* rows, int32_t row_len,
+                                  const int32_t* slice_start, const int32_t* slice_lens, const int32_t* row_idx,
+                                  int32_t slice_len, int64_t nslices, float2* out, hipStream_t st) {
+    const unsigned gx = std::min<unsigned>(cdiv(slice_len, 256), 64);
+    for (int64_t r0 = 0; r0 < nslices; r0 += 65535) {
+        const int64_t nr = std::min<int64_t>(65535, nslices - r0);
+        hipLaunchKernelGGL(k_multiply_indexed_rows, dim3(gx, (unsigned)nr), dim3(256), 0, st, x, xlen, rows, row_len,
+                           slice_start + r0, slice_lens ? slice_lens + r0 : nullptr, row_idx + r0, slice_len,
+                           out + r0 * (int64_t)slice_len);
+    }
+}
+
+void launch_copy_slices(const float2* x, int64_t xlen, const int32_t* starts, int32_t starts_stride, int64_t start0,
+                        int64_t inc, int32_t len, int64_t rows, float2* out, hipStream_t st) {
+    const unsigned gx = std::min<unsigned>(cdiv(len, 256), 64);
+    for (int64_t r0 = 0; r0 < rows; r0 += 65535) {
+        const int64_t nr = std::min<int64_t>(65535, rows - r0);
+        hipLaunchKernelGGL(k_copy_slices, dim3(gx, (unsigned)nr), dim3(256), 0, st, x, xlen,
+                           starts ? starts + r0 * starts_stride : nullptr, starts_stride, start0 + r0 * inc, inc, len,
+                           out + r0 * (int64_t)len);
+    }
+}
+
+void launch_copy_groups(const float2* x, float2* y, const int32_t* xs, const int32_t* ys, const int32_t* lens,
+                        int32_t ngroups, hipStream_t st) {
+    if (ngroups > 0) hipLaunchKernelGGL(k_copy_groups, dim3(ngroups), dim3(256), 0, st, x, y, xs, ys, lens);
+}
+
+void launch_find_local_maxima(const float* x, int64_t n, float min_height, uint8_t* flags, int32_t max_out,
+                              int32_t* idx, int32_t* count, hipStream_t st) {
+    hipLaunchKernelGGL(k_local_max_flags, dim3(cdiv(n, 256)), dim3(256), 0, st, x, n, min_height, flags);
+    hipLaunchKernelGGL(k_compact_flags, dim3(1), dim3(1024), 0, st, flags, n, max_out, idx, count);
+}
+
+void launch_fir(const float2* x, int64_t n, const float* taps, int32_t ntaps, const float2* delay, int32_t dlen,
+                int32_t dsr, int32_t phase, float2* out, int64_t nout, hipStream_t st) {
+    const size_t sm = (size_t)((ntaps + 1) & ~1) * sizeof(float) + (size_t)(FIR_TILE + ntaps) * sizeof(float2);
+    hipLaunchKernelGGL(k_fir, dim3(cdiv(n, FIR_TILE)), dim3(256), sm, st, x, n, taps, ntaps, delay, dlen, dsr, phase, out,
+                       nout);
+}
+
+void launch_upfirdn(const float2* x, int64_t rows, int64_t n, const float* taps, int32_t ntaps, int32_t up, int32_t down,
+                    int64_t nout, float2* out, float* out_abs, hipStream_t st) {
+    hipLaunchKernelGGL(k_upfirdn, dim3(cdiv(nout, 256), (unsigned)rows), dim3(256), (size_t)ntaps * sizeof(float), st, x,
+                       n, taps, ntaps, up, down, nout, out, out_abs);
+}
+
+void launch_rows_mul_vec(const float2* x, int64_t in_pitch, int64_t in_off, const float2* v, int64_t len, float2* y,
+                         int64_t out_pitch, int64_t pad_to, int64_t rows, float scale, hipStream_t st) {
+    const unsigned gx = std::min<unsigned>(cdiv(pad_to, 256), 256);
+    for (int64_t r0 = 0; r0 < rows; r0 += 65535) {
+        const int64_t nr = std::min<int64_t>(65535, rows - r0);
+        hipLaunchKernelGGL(k_rows_mul_vec, dim3(gx, (unsigned)nr), dim3(256), 0, st, x + r0 * in_pitch, in_pitch, in_off, v,
+                           len, y + r0 * out_pitch, out_pitch, pad_to, scale);
+    }
+}
+
+void launch_complex_norm(const float2* pbuf, int32_t pitch, int32_t nfreq, const float* tscale, const float* inv_e,
+                         int64_t num_shifts, int32_t step, int32_t blk0, int32_t nblk, int32_t nhyp, float2* cqf,
+                         hipStream_t st) {
+    hipLaunchKernelGGL(k_complex_norm, dim3(cdiv(step, 256), nhyp, nblk), dim3(256), 0, st, pbuf, pitch, nfreq, tscale,
+                       inv_e, num_shifts, step, blk0, nhyp, cqf);
+}
+
+void launch_scale(float2* y, int64_t n, float scale, hipStream_t st) {
+    if (n > 0) hipLaunchKernelGGL(k_scale, dim3(std::min<unsigned>(cdiv(n, 256), 4096)), dim3(256), 0, st, y, n, scale);
+}
+
+void launch_colmax_abs(const float2* z, int32_t rows, int64_t n, float* maxv, int32_t* arg, hipStream_t st) {
+    hipLaunchKernelGGL(k_colmax_abs, dim3(cdiv(n, 256)), dim3(256), 0, st, z, rows, n, maxv, arg);
+}
+
+}  // namespace caf

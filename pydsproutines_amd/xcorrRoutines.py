@@ -1,0 +1,625 @@
+"""Drop-in host layer: the reference's xcorr call signatures (xcorrRoutines.py,
+cython_ext/CyIppXcorrFFT, cython_ext/CyGroupXcorrFFT, pybinds/ippGroupXcorrCZT) in front of
+libcaf.so.  Same names, argument meaning, return dtypes / shapes and error behaviour; every
+number is computed on the MI355X (no NumPy fallback -- a missing library or GPU raises).
+
+Two device strategies sit behind these entry points:
+  * hypothesis engine (``CAFPlan``): overlap-save FFT correlation per (template, frequency)
+    hypothesis -- used when the frequency set is restricted (GroupXcorr*, cztXcorr,
+    TemplateCrossCorrelator, fastXcorr without frequency search);
+  * per-delay path (``caf_xcorr_perdelay``): sliding product -> N-point row FFT -> |.|^2 / argmax
+    -- the reference's literal algorithm, used when every FFT bin of every delay is wanted
+    (fastXcorr freqsearch branches, cp_fastXcorr*, CyIppXcorrFFT).
+
+GPU arithmetic is complex64/float32 (energies float64); float64/complex128 outputs of the CPU
+signatures are widened copies of those results.
+"""
+
+import ctypes as ct
+
+import numpy as np
+
+from . import _lib
+from .caf import CAFPlan
+from .cupyExtensions import (  # noqa: F401  (re-exported like `from cupyExtensions import *` upstream)
+    cupyArgmaxAbsRows_complex64,
+    cupyComplexMagnSq,
+    cupyCopyGroups32fc,
+    cupyCopyIncrementalEqualSlicesToMatrix_32fc,
+    fftRows,
+    multiplySlidesNormalised,
+    multiTemplateSlidingDotProduct,
+)
+from .devarray import DeviceArray, asarray, empty, requireDeviceArray, requireDtype
+from .filterRoutines import cupyMovingAverage  # noqa: F401
+from .signalCreationRoutines import makeFreq
+from .spectralRoutines import CZTCached, CZTCachedGPU, next_fast_len  # noqa: F401
+
+_MAX_PLANE_ELEMS = 1 << 27  # bound on (delays x bins) elements materialised per device call
+
+
+# ------------------------------------------------------------------------------------------
+# small helpers
+# ------------------------------------------------------------------------------------------
+def _c64(a):
+    return np.ascontiguousarray(a, dtype=np.complex64)
+
+
+def _runs(shifts):
+    """Split an index array into maximal arithmetic-progression runs: [(offset, start, step, count)]."""
+    s = np.asarray(shifts, dtype=np.int64).reshape(-1)
+    out, i, n = [], 0, s.size
+    while i < n:
+        if i + 1 >= n:
+            out.append((i, int(s[i]), 1, 1))
+            break
+        step = int(s[i + 1] - s[i])
+        j = i + 1
+        while j + 1 < n and int(s[j + 1] - s[j]) == step:
+            j += 1
+        if step == 0:
+            step = 1
+            j = i
+        out.append((i, int(s[i]), step, j - i + 1))
+        i = j + 1
+    return out
+
+
+def _perdelay(d_cut, n, d_rx, rx_len, start, step, num, zero_oor, want_qf2, want_idx, want_caf, want_ccaf):
+    """One caf_xcorr_perdelay call; returns host arrays."""
+    lib = _lib.load()
+    qf2 = empty(num, np.float32) if want_qf2 else None
+    idx = empty(num, np.int32) if want_idx else None
+    caf = empty((num, n), np.float32) if want_caf else None
+    ccaf = empty((num, n), np.complex64) if want_ccaf else None
+    p = lambda a: ct.c_void_p(a.ptr) if a is not None else None  # noqa: E731
+    _lib.check(
+        lib.caf_xcorr_perdelay(p(d_cut), n, p(d_rx), rx_len, int(start), int(step), int(num), 1 if zero_oor else 0,
+                               p(qf2), p(idx), p(caf), p(ccaf), 0, None),
+        "caf_xcorr_perdelay",
+    )
+    g = lambda a: a.get() if a is not None else None  # noqa: E731
+    return g(qf2), g(idx), g(caf), g(ccaf)
+
+
+def _engine_range(shifts):
+    s = np.asarray(shifts, dtype=np.int64)
+    lo, hi = int(s.min()), int(s.max())
+    return lo, hi - lo + 1, s - lo
+
+
+# ------------------------------------------------------------------------------------------
+# fastXcorr and relatives (host-array signatures)
+# ------------------------------------------------------------------------------------------
+def fastXcorr(cutout, rx, freqsearch=False, outputCAF=False, shifts=None, absResult=True):
+    """ref: xcorrRoutines.py:460-580 -- all six branches, same return dtypes:
+    A float64[S]; A' complex128[S]; B (float64[S], uint32[S]); B' (complex128[S], uint32[S]);
+    C float64[S, N]; C' complex128[S, N]."""
+    cutout = np.asarray(cutout)
+    rx = np.asarray(rx)
+    n = len(cutout)
+    if shifts is None:
+        shifts = np.arange(len(rx) - n + 1)
+    shifts = np.asarray(shifts)
+    ns = len(shifts)
+    if ns and (shifts.min() < 0 or shifts.max() + n > len(rx)):
+        raise ValueError("shifts must keep the cutout inside rx")
+    d_rx = asarray(_c64(rx))
+
+    if not freqsearch:
+        out = np.zeros(ns, dtype=np.float64 if absResult else np.complex128)
+        if ns == 0:
+            return out
+        lo, cnt, rel = _engine_range(shifts)
+        plan = CAFPlan(_c64(cutout), max_rx_len=len(rx), bins=[0], grid=1 << int(np.ceil(np.log2(max(n, 2)))))
+        res = plan.run(d_rx, shift_start=lo, num_shifts=cnt, rows=absResult, peak=False, cqf=not absResult)
+        if absResult:
+            out[:] = res.row_max.get()[0][rel]
+        else:
+            # branch A' is sum(conj(rx) * cutout) (np.vdot order, :503): the conjugate of the engine's value
+            out[:] = np.conj(res.cqf.get()[0, 0][rel])
+        plan.close()
+        return out
+
+    d_cut = asarray(_c64(cutout).conj())
+    if not outputCAF:
+        out = np.zeros(ns, dtype=np.float64 if absResult else np.complex128)
+        fidx = np.zeros(ns, dtype=np.uint32)
+    else:
+        out = np.zeros((ns, n), dtype=np.float64 if absResult else np.complex128)
+    chunk = max(1, _MAX_PLANE_ELEMS // n)
+    for off, start, step, count in _runs(shifts):
+        for c0 in range(0, count, chunk):
+            c = min(chunk, count - c0)
+            sl = slice(off + c0, off + c0 + c)
+            s0 = start + c0 * step
+            if not outputCAF and absResult:
+                q, fi, _, _ = _perdelay(d_cut, n, d_rx, len(rx), s0, step, c, False, True, True, False, False)
+                out[sl], fidx[sl] = q, fi.astype(np.uint32)
+            elif not outputCAF:
+                _, fi, _, cc = _perdelay(d_cut, n, d_rx, len(rx), s0, step, c, False, False, True, False, True)
+                fidx[sl] = fi.astype(np.uint32)
+                out[sl] = cc[np.arange(c), fi]
+            elif absResult:
+                out[sl] = _perdelay(d_cut, n, d_rx, len(rx), s0, step, c, False, False, False, True, False)[2]
+            else:
+                out[sl] = _perdelay(d_cut, n, d_rx, len(rx), s0, step, c, False, False, False, False, True)[3]
+    if not outputCAF:
+        return out, fidx
+    return out
+
+
+def cztXcorr(cutout, rx, f_searchMin, f_searchMax, fs, cztStep=0.1, outputCAF=False, shifts=None):
+    """ref: xcorrRoutines.py:413-457.  The frequency grid is the reference's CZT grid
+    f1 + i*cztStep, i < int((f2-f1)/cztStep + 1); evaluated as explicit hypotheses."""
+    cutout = np.asarray(cutout)
+    rx = np.asarray(rx)
+    n = cutout.size
+    k = int((f_searchMax - f_searchMin) / cztStep + 1)
+    f_search = np.arange(k) * cztStep + f_searchMin
+    if shifts is None:
+        shifts = np.arange(len(rx) - n + 1)
+    shifts = np.asarray(shifts)
+    lo, cnt, rel = _engine_range(shifts)
+    plan = CAFPlan(_c64(cutout), max_rx_len=len(rx), freqs_norm=f_search / fs)
+    d_rx = asarray(_c64(rx))
+    if outputCAF:
+        res = plan.run(d_rx, shift_start=lo, num_shifts=cnt, surface=True, rows=False, peak=False)
+        out = res.surface.get()[0][rel].astype(np.float64)
+        plan.close()
+        return out, f_search
+    res = plan.run(d_rx, shift_start=lo, num_shifts=cnt, rows=True, peak=False, cqf=True)
+    mi = res.row_arg.get()[0][rel]
+    cq = res.cqf.get()[0]  # (k, cnt)
+    result = cq[mi, rel].astype(rx.dtype if np.iscomplexobj(rx) else np.complex64)
+    plan.close()
+    return result, f_search[mi].astype(np.float64)
+
+
+class _GroupEngine:
+    """Shared machinery of the grouped-template classes: composite template + cached CAFPlan."""
+
+    def _setup(self, tmpl_groups, rel_starts, lengths, autoConj, bins=None, grid=None, freqs_norm=None):
+        rel_starts = np.asarray(rel_starts, dtype=np.int64)
+        lengths = np.asarray(lengths, dtype=np.int64)
+        self._span = int(np.max(rel_starts + lengths))
+        comp = np.zeros(self._span, np.complex64)
+        for g, (r, l) in enumerate(zip(rel_starts, lengths)):
+            comp[r : r + l] = tmpl_groups[g][:l]
+        self._comp, self._rel, self._len = comp, rel_starts, lengths
+        self._autoConj, self._bins, self._grid, self._fn = autoConj, bins, grid, freqs_norm
+        self._plan, self._plan_len = None, -1
+
+    def _get_plan(self, rx_len):
+        if self._plan is None or rx_len > self._plan_len:
+            if self._plan is not None:
+                self._plan.close()
+            self._plan = CAFPlan(self._comp, max_rx_len=rx_len, bins=self._bins, grid=self._grid,
+                                 freqs_norm=self._fn, group_starts=self._rel, group_lens=self._len,
+                                 autoConj=self._autoConj)
+            self._plan_len = rx_len
+        return self._plan
+
+    def _run(self, rx, shifts, **kw):
+        rx = np.asarray(rx)
+        plan = self._get_plan(len(rx))
+        lo, cnt, rel = _engine_range(shifts)
+        res = plan.run(asarray(_c64(rx)), shift_start=lo, num_shifts=cnt, **kw)
+        return res, rel
+
+
+class GroupXcorr(_GroupEngine):
+    """ref: xcorrRoutines.py:852-954.  Composite template (groups), explicit frequency list.
+    ``xcorr`` returns (QF^2 float64[S], peak frequency in Hz float64[S])."""
+
+    def __init__(self, y, starts, lengths, freqs, fs, autoConj=True, autoZeroStarts=True):
+        y = np.asarray(y)
+        starts = np.asarray(starts)
+        lengths = np.asarray(lengths)
+        assert starts.size == lengths.size
+        self.starts = starts - starts[0] if autoZeroStarts else starts
+        self.lengths = lengths
+        self.numGroups = starts.size
+        self.freqs = np.asarray(freqs, dtype=np.float64)
+        self.fs = fs
+        groups = [_c64(y[s : s + l]) for s, l in zip(starts, lengths)]
+        self.yconcat = np.hstack([g.conj() if autoConj else g for g in groups])
+        self.yconcatNormSq = float(np.sum(np.abs(self.yconcat.astype(np.complex128)) ** 2))
+        self._setup(groups, self.starts - self.starts[0], lengths, autoConj, freqs_norm=self.freqs / fs)
+        self._first = int(self.starts[0])
+
+    def xcorr(self, rx, shifts=None):
+        rx = np.asarray(rx)
+        if shifts is None:
+            shifts = np.arange(len(rx) - (self.starts[-1] + self.lengths[-1]) + 1)
+        else:
+            shifts = np.asarray(shifts)
+            assert shifts[-1] + self.starts[-1] + self.lengths[-1] < rx.size
+        res, rel = self._run(rx, shifts + self._first, rows=True, peak=False)
+        xc = res.row_max.get()[0][rel].astype(np.float64)
+        return xc, self.freqs[res.row_arg.get()[0][rel]]
+
+
+class GroupXcorrCZT(_GroupEngine):
+    """ref: xcorrRoutines.py:957-1039.  ``xcorr`` returns (QF^2 float64[S, k], cztFreq)."""
+
+    def __init__(self, y, starts, lengths, f1, f2, binWidth, fs, autoConj=True, autoZeroStarts=True):
+        y = np.asarray(y)
+        starts = np.asarray(starts)
+        lengths = np.asarray(lengths)
+        assert starts.size == lengths.size
+        self.starts = starts - starts[0] if autoZeroStarts else starts
+        self.lengths = lengths
+        self.numGroups = starts.size
+        self.fs = fs
+        self.f1, self.f2, self.binWidth = f1, f2, binWidth
+        self.maxLength = int(np.max(lengths))
+        groups = [_c64(y[s : s + l]) for s, l in zip(starts, lengths)]
+        self.ystackNormSq = float(sum(np.sum(np.abs(g.astype(np.complex128)) ** 2) for g in groups))
+        self._k = int((f2 - f1) / binWidth + 1)
+        self._freq = np.arange(f1, f2 + binWidth / 2, binWidth)
+        self._setup(groups, self.starts - self.starts[0], lengths, autoConj, freqs_norm=self._freq[: self._k] / fs)
+        self._first = int(self.starts[0])
+
+    def xcorr(self, rx, shifts=None):
+        rx = np.asarray(rx)
+        if shifts is None:
+            shifts = np.arange(len(rx) - (self.starts[-1] + self.lengths[-1]) + 1)
+        else:
+            shifts = np.asarray(shifts)
+            assert shifts[-1] + self.starts[-1] + self.lengths[-1] < rx.size
+        res, rel = self._run(rx, shifts + self._first, surface=True, rows=False, peak=False)
+        return res.surface.get()[0][rel].astype(np.float64), self._freq
+
+
+class GroupXcorrFFT(_GroupEngine):
+    """ref: xcorrRoutines.py:1047-1262.  Equal-length groups on the makeFreq(fftlen, fs) grid.
+    ``xcorr`` -> (float64[S], uint32[S]) or float64[S, fftlen]; ``xcorrGPU`` takes a DeviceArray."""
+
+    def __init__(self, ygroups, starts, fs, autoConj=True, fftlen=None, autoZeroStarts=True):
+        ygroups = np.asarray(ygroups)
+        starts = np.asarray(starts)
+        assert starts.size == ygroups.shape[0]
+        self.starts = starts - starts[0] if autoZeroStarts else starts
+        self.numGroups = starts.size
+        self.fs = fs
+        self.ygroupLen = ygroups.shape[1]
+        self.fftlen = self.ygroupLen if fftlen is None else int(fftlen)
+        self.ygroupNormSq = float(np.sum(np.abs(ygroups.astype(np.complex128)) ** 2))
+        self.ygroups = ygroups.conj() if autoConj else ygroups
+        self.fftfreq = makeFreq(self.fftlen, self.fs)
+        groups = [_c64(g) for g in ygroups]
+        lens = np.full(self.numGroups, self.ygroupLen)
+        pow2 = (self.fftlen & (self.fftlen - 1)) == 0
+        if pow2:
+            self._setup(groups, self.starts - self.starts[0], lens, autoConj, bins=np.arange(self.fftlen),
+                        grid=self.fftlen)
+        else:
+            self._setup(groups, self.starts - self.starts[0], lens, autoConj,
+                        freqs_norm=np.arange(self.fftlen) / self.fftlen)
+        self._first = int(self.starts[0])
+
+    def _default_shifts(self, n):
+        return np.arange(n - (self.starts[-1] + self.fftlen) + 1)
+
+    def xcorr(self, rx, shifts=None, flattenToTime=True):
+        rx = rx.get() if isinstance(rx, DeviceArray) else np.asarray(rx)
+        if shifts is None:
+            shifts = self._default_shifts(len(rx))
+        else:
+            shifts = np.asarray(shifts)
+            assert shifts[-1] + self.starts[-1] + self.fftlen < rx.size
+        if flattenToTime:
+            res, rel = self._run(rx, shifts + self._first, rows=True, peak=False)
+            return res.row_max.get()[0][rel].astype(np.float64), res.row_arg.get()[0][rel].astype(np.uint32)
+        res, rel = self._run(rx, shifts + self._first, surface=True, rows=False, peak=False)
+        return res.surface.get()[0][rel].astype(np.float64)
+
+    def xcorrThreads(self, rx, shifts=None, NUM_THREADS=4):
+        return self.xcorr(rx, shifts, flattenToTime=False)
+
+    def xcorrGPU(self, rx, shifts=None, flattenToTime=True):
+        requireDeviceArray(rx)
+        out = self.xcorr(rx, shifts, flattenToTime)
+        if flattenToTime:
+            return asarray(out[0]), asarray(out[1])
+        return asarray(out)
+
+
+# ------------------------------------------------------------------------------------------
+# device-array (cupy-signature) entry points
+# ------------------------------------------------------------------------------------------
+class TemplateCrossCorrelator:
+    """ref: xcorrRoutines.py:277-371.  T templates, no frequency scan; returns QF (not QF^2):
+    complex64 (T, M-L+1), or with returnMax (float32 QF[M-L+1], int64 templateIdx[M-L+1])."""
+
+    def __init__(self, templates, inputSize):
+        self._inputSize = int(inputSize)
+        requireDeviceArray(templates)
+        if not templates.ndim == 2:
+            raise ValueError("Templates must be a 2D array; 1 row for 1 template.")
+        self._templateOrigLength = templates.shape[1]
+        tm = templates.get()
+        self._templateNorms = asarray(np.sqrt(np.sum(np.abs(tm.astype(np.complex128)) ** 2, axis=1)).astype(np.float32))
+        L = self._templateOrigLength
+        self._plan = CAFPlan(_c64(tm), max_rx_len=self._inputSize, bins=[0],
+                             grid=1 << int(np.ceil(np.log2(max(L, 2)))))
+
+    def correlate(self, x, returnMax=False):
+        requireDeviceArray(x)
+        if x.ndim != 1 or x.size != self._inputSize:
+            raise ValueError("x must be 1D of length %d" % self._inputSize)
+        requireDtype(np.complex64, x)
+        res = self._plan.run(x, rows=False, peak=False, cqf=True)
+        T = self._plan.T
+        S = self._inputSize - self._templateOrigLength + 1
+        nout = res.cqf.reshape(T, S)
+        if not returnMax:
+            return nout
+        qf = empty(S, np.float32)
+        ti = empty(S, np.int32)
+        _lib.check(_lib.load().caf_colmax_abs(ct.c_void_p(nout.ptr), T, S, ct.c_void_p(qf.ptr), ct.c_void_p(ti.ptr), None))
+        return qf, asarray(ti.get().astype(np.int64))
+
+
+def cp_fastXcorr(cutout, rx, freqsearch=True, outputCAF=False, shifts=None, absResult=True, BATCH=1024, copyToCpu=True):
+    """ref: xcorrRoutines.py:29-167.  Only the frequency-scanning / flattened / abs branch exists
+    upstream (the others print "Not implemented.").  Returns (float64 QF^2[S], uint32 bin[S])."""
+    if isinstance(cutout, DeviceArray):
+        cutout = cutout.get()
+    d_rx = rx if isinstance(rx, DeviceArray) else asarray(_c64(rx))
+    if np.dtype(cutout.dtype) != d_rx.dtype:
+        raise Exception("Cutout and Rx must be same type, please cast one of them manually.")
+    n = len(cutout)
+    if shifts is None:
+        shifts = np.arange(d_rx.size - n + 1)
+    if not freqsearch or outputCAF or not absResult:
+        print("Not implemented.")
+        return None
+    shifts = np.asarray(shifts)
+    d_cut = asarray(_c64(cutout).conj())
+    out = np.zeros(len(shifts), np.float64)
+    fidx = np.zeros(len(shifts), np.uint32)
+    for off, start, step, count in _runs(shifts):
+        q, fi, _, _ = _perdelay(d_cut, n, d_rx, d_rx.size, start, step, count, False, True, True, False, False)
+        out[off : off + count], fidx[off : off + count] = q, fi.astype(np.uint32)
+    if copyToCpu:
+        return out, fidx
+    return asarray(out), asarray(fidx)
+
+
+def cp_fastXcorr_v2(cutout, rx, startIdx=0, idxlen=None, THREADS_PER_BLOCK=32, numSlidesPerBlk=None, cztObj=None,
+                    flattenCAF=False, BATCH=None):
+    """ref: xcorrRoutines.py:169-274.  Kernel chain on device arrays: sliding normalised product
+    (template NOT conjugated here, as upstream) -> row FFT or CZT -> argmax | |.|^2.
+    Returns (uint32 freqIdx, float32 qf2) -- order swapped vs v1, as upstream -- or the float32
+    (idxlen, N | k) plane.  Every batch writes its own rows (the upstream multi-batch indexing slip
+    at :263-265 is not reproduced)."""
+    requireDeviceArray(cutout)
+    requireDeviceArray(rx)
+    if idxlen is None:
+        idxlen = rx.size - cutout.size - startIdx + 1
+    if cztObj is not None and cztObj.m != cutout.size:
+        raise ValueError("CZT object input length doesn't match the cutout array size")
+    if BATCH is None:
+        BATCH = idxlen
+    ncols = cutout.size if cztObj is None else cztObj.k
+    BATCH = max(1, min(int(BATCH), max(1, _MAX_PLANE_ELEMS // max(cutout.size, ncols))))
+    if flattenCAF:
+        d_freqIdx = empty(idxlen, np.uint32)
+        d_qf2 = empty(idxlen, np.float32)
+    else:
+        d_out = empty((idxlen, ncols), np.float32)
+    fi = 0
+    lib = _lib.load()
+    while fi < idxlen:
+        nb = min(BATCH, idxlen - fi)
+        d_pdts = multiplySlidesNormalised(cutout, rx, startIdx + fi, nb)
+        d_spec = fftRows(d_pdts, out=d_pdts) if cztObj is None else cztObj.runMany(d_pdts)
+        if flattenCAF:
+            cupyArgmaxAbsRows_complex64(d_spec, d_argmax=d_freqIdx[fi : fi + nb], d_max=d_qf2[fi : fi + nb],
+                                        returnMaxValues=True, useNormSqInstead=True)
+        else:
+            _lib.check(lib.caf_complex_magnsq(ct.c_void_p(d_spec.ptr), d_spec.size, 0, ct.c_void_p(d_out[fi : fi + nb].ptr),
+                                              0, None))
+        _lib.check(lib.caf_stream_sync(None))
+        fi += nb
+    if flattenCAF:
+        return d_freqIdx, d_qf2
+    return d_out
+
+
+# ------------------------------------------------------------------------------------------
+# native-class signatures (Cython / pybind twins upstream)
+# ------------------------------------------------------------------------------------------
+class CyIppXcorrFFT:
+    """ref: cython_ext/CyIppXcorrFFT/CyIppXcorrFFT.pyx:6-83, IppXcorrFFT.cpp:94-194.
+    ``xcorr(rx, startIdx, endIdx, step)`` -> (float32 QF^2, int32 bin); delays whose window leaves
+    rx give (0.0, 0) instead of an error.  ``num_threads`` is accepted and ignored (one GPU)."""
+
+    def __init__(self, cutout, num_threads=1, autoConj=True):
+        cutout = np.asarray(cutout)
+        if cutout.dtype != np.complex64 or cutout.ndim != 1:
+            raise ValueError("Buffer dtype mismatch, expected 1-D complex64 cutout")
+        self._n = cutout.size
+        self._d_cut = asarray(cutout.conj() if autoConj else cutout)
+        self._last = None
+
+    def xcorr(self, rx, startIdx, endIdx, step):
+        rx = np.asarray(rx)
+        if rx.dtype != np.complex64 or rx.ndim != 1:
+            raise ValueError("Buffer dtype mismatch, expected 1-D complex64 rx")
+        length = len(np.arange(startIdx, endIdx, step))
+        if length == 0:
+            return np.zeros(0, np.float32), np.zeros(0, np.int32)
+        q, fi, _, _ = _perdelay(self._d_cut, self._n, asarray(rx), rx.size, startIdx, step, length, True, True, True,
+                                False, False)
+        self._last = (q, fi)
+        return q, fi
+
+    def results(self):
+        return self._last
+
+
+class CyGroupXcorrFFT(_GroupEngine):
+    """ref: cython_ext/CyGroupXcorrFFT/CyGroupXcorrFFT.pyx:6-65, GroupXcorrFFT.cpp:3-203.
+    ``xcorr(rx, shifts, NUM_THREADS)`` -> float32 (S, fftlen) (always the full plane)."""
+
+    def __init__(self, ygroups, offsets, fs, fftlen=-1, autoConj=True):
+        ygroups = np.asarray(ygroups)
+        offsets = np.asarray(offsets)
+        if ygroups.dtype != np.complex64 or ygroups.ndim != 2:
+            raise ValueError("ygroups must be 2-D complex64")
+        if offsets.dtype != np.int32:
+            raise ValueError("offsets must be int32")
+        L = ygroups.shape[1]
+        self.fftlen = L if fftlen == -1 else int(fftlen)
+        if self.fftlen < L:
+            raise ValueError("INVALID_FFTLEN: fftlen must be >= group length")
+        rel = offsets.astype(np.int64) - int(offsets[0])
+        lens = np.full(ygroups.shape[0], L)
+        if (self.fftlen & (self.fftlen - 1)) == 0:
+            self._setup([g for g in ygroups], rel, lens, autoConj, bins=np.arange(self.fftlen), grid=self.fftlen)
+        else:
+            self._setup([g for g in ygroups], rel, lens, autoConj, freqs_norm=np.arange(self.fftlen) / self.fftlen)
+
+    def xcorr(self, rx, shifts, NUM_THREADS=1):
+        rx = np.asarray(rx)
+        shifts = np.asarray(shifts)
+        if rx.dtype != np.complex64 or shifts.dtype != np.int32:
+            raise ValueError("rx must be complex64 and shifts int32")
+        res, rel = self._run(rx, shifts, surface=True, rows=False, peak=False)
+        return res.surface.get()[0][rel]
+
+
+class pbIppGroupXcorrCZT(_GroupEngine):
+    """ref: pybinds/ippGroupXcorrCZT (pbGroupXcorrCZT.cpp:7-40, GroupXcorrCZT.cpp:4-375).
+    addGroup / addGroupsFromArray / resetGroups / xcorr(x, shiftStart, shiftStep, numShifts)
+    -> float32 (numShifts, k); the reference's range_error / invalid_argument become
+    IndexError / ValueError."""
+
+    def __init__(self, maxlen, f1, f2, fstep, fs, NUM_THREADS=1):
+        if NUM_THREADS < 1:
+            raise ValueError("Number of threads must be greater than 0")
+        self._N, self._f1, self._f2, self._fstep, self._fs = int(maxlen), f1, f2, fstep, fs
+        self._k = int((f2 - f1) / fstep + 1)
+        self._threads = NUM_THREADS
+        self.resetGroups()
+
+    def getNumThreads(self):
+        return self._threads
+
+    def resetGroups(self):
+        self._gstarts, self._groups = [], []
+        self._plan, self._plan_len = None, -1
+
+    def addGroup(self, start, group, autoConj=True):
+        group = np.asarray(group)
+        if group.dtype != np.complex64:
+            raise TypeError("group must be complex64")
+        length = group.size
+        for gs, g in zip(self._gstarts, self._groups):
+            ge = gs + g.size
+            if gs <= start < ge:
+                raise IndexError("Group start overlaps with existing group! [%d,%d)" % (gs, ge))
+            if gs <= start + length < ge:
+                raise IndexError("Group end overlaps with existing group! [%d,%d)" % (gs, ge))
+        if length > self._N:
+            raise IndexError("Length of group exceeds maximum length")
+        self._gstarts.append(int(start))
+        self._groups.append(group.conj() if autoConj else group.copy())
+        self._plan = None
+
+    def addGroupsFromArray(self, starts, lengths, arr, autoConj=True):
+        starts = np.asarray(starts)
+        lengths = np.asarray(lengths)
+        m = int(starts.min())
+        for s, l in zip(starts, lengths):
+            self.addGroup(int(s) - m, np.asarray(arr)[s : s + l], autoConj)
+
+    def xcorr(self, x, shiftStart, shiftStep, numShifts):
+        x = np.asarray(x)
+        if x.dtype != np.complex64:
+            raise TypeError("x must be complex64")
+        if shiftStep < 0:
+            raise ValueError("shiftStep cannot be negative")
+        if not self._groups:
+            raise IndexError("No groups have been defined!")
+        for gs, g in zip(self._gstarts, self._groups):
+            xi = shiftStart + gs
+            if xi < 0:
+                raise IndexError("Shifts accesses negative indices!")
+            if xi + numShifts * shiftStep + g.size >= x.size:
+                raise IndexError("Input length is insufficient for search range!")
+        if self._plan is None:
+            order = np.argsort(self._gstarts)
+            gst = np.asarray(self._gstarts)[order]
+            lens = np.asarray([self._groups[i].size for i in order])
+            freqs = (self._f1 + np.arange(self._k) * self._fstep) / self._fs
+            # stored groups are already conjugated when autoConj was requested
+            self._base = int(gst[0])
+            self._setup([self._groups[i] for i in order], gst - gst[0], lens, False, freqs_norm=freqs)
+        shifts = shiftStart + self._base + shiftStep * np.arange(numShifts)
+        res, rel = self._run(x, shifts, surface=True, rows=False, peak=False)
+        return res.surface.get()[0][rel]
+
+
+# ------------------------------------------------------------------------------------------
+# small helpers of the reference API
+# ------------------------------------------------------------------------------------------
+def argmax2d(m):
+    """ref: xcorrRoutines.py:815-830."""
+    return np.unravel_index(np.argmax(m), m.shape)
+
+
+def calcQF2(x, y):
+    """ref: xcorrRoutines.py:833-848 (host helper for two aligned arrays)."""
+    x = np.asarray(x)
+    y = np.asarray(y)
+    if x.ndim == 1 and y.ndim == 1:
+        return np.abs(np.vdot(x, y)) ** 2 / np.linalg.norm(x) ** 2 / np.linalg.norm(y) ** 2
+    if x.ndim == 2 and y.ndim == 2:
+        xe = np.linalg.norm(x, axis=1) ** 2
+        ye = np.linalg.norm(y, axis=1) ** 2
+        return np.abs(np.sum(x * y.conj(), axis=1)) ** 2 / xe / ye
+
+
+def convertQF2toSNR(qf2):
+    """ref: xcorrRoutines.py:723-725."""
+    return qf2 / (1.0 - qf2)
+
+
+def convertQF2toEffSNR(qf2):
+    """ref: xcorrRoutines.py:728-730."""
+    return 2.0 * qf2 / (1.0 - qf2)
+
+
+def convertEffSNRtoQF2(effSNR):
+    """ref: xcorrRoutines.py:733-735."""
+    return effSNR / (2 + effSNR)
+
+
+def expectedEffSNR(snr1, snr2=np.inf, OSR=1):
+    """ref: xcorrRoutines.py:738-755 (Stein)."""
+    return 1.0 / (0.5 * (1 / snr1 + 1 / snr2 + 1 / snr1 / snr2)) / OSR
+
+
+def sigmaDTO(signalBW, noiseBW, integTime, effSNR):
+    """ref: xcorrRoutines.py:758-764."""
+    return 1.0 / (np.pi / np.sqrt(3) * signalBW) / np.sqrt(noiseBW * integTime * effSNR)
+
+
+def sigmaDFO(noiseBW, integTime, effSNR):
+    """ref: xcorrRoutines.py:767-772."""
+    return 0.55 / integTime / np.sqrt(noiseBW * integTime * effSNR)
+
+
+def computeFastXcorrComplexity(N, K=1):
+    """ref: xcorrRoutines.py:2084-2097."""
+    return K * N * np.log2(N)
+
+
+def computeGroupXcorrCZTcomplexity(m, L, n, K=1):
+    """ref: xcorrRoutines.py:2100-2121."""
+    Lc = next_fast_len(L + n)
+    return K * m * 2 * Lc * np.log2(Lc)

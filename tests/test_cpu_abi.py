@@ -1,0 +1,75 @@
+"""CPU tests of the drop-in boundary: libcaf.so loads, exports exactly what include/caf.h declares,
+the Python host imports, and the product path fails loudly (no fallback) without a GPU."""
+
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "caf.h")).read()
+    return sorted(set(re.findall(r"CAF_EXPORT\s+int32_t\s+(caf_\w+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from pydsproutines_amd import _lib
+
+    lib = _lib.load()
+    names = _declared()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), "libcaf.so does not export %s" % n
+    # the Python binding table and the header agree
+    assert sorted(_lib.EXPORTED_SYMBOLS) == names
+    assert lib.caf_abi_version() >> 16 == 1
+
+
+def test_struct_layouts_match_header():
+    from pydsproutines_amd import _lib
+
+    # caf_plan_desc: 2 i32, ptr, 2 i32, 2 ptr, 2 i32, ptr, i32(+pad), ptr, i64, 2 i32
+    assert ctypes.sizeof(_lib.CafPlanDesc) == 88
+    assert ctypes.sizeof(_lib.CafOutputs) == 7 * ctypes.sizeof(ctypes.c_void_p)
+    assert _lib.CafPlanDesc.max_rx_len.offset == 72
+
+
+def test_host_modules_import_and_validate_without_gpu():
+    from pydsproutines_amd import _lib, xcorrRoutines as X
+    from pydsproutines_amd.signalCreationRoutines import makeFreq, randPSKsyms
+    from pydsproutines_amd.spectralRoutines import next_fast_len
+    from pydsproutines_amd.timingRoutines import Timer
+    from pydsproutines_amd.verifyRoutines import compareValues
+
+    np.testing.assert_array_equal(makeFreq(8, 8.0), [0, 1, 2, 3, -4, -3, -2, -1])
+    syms, bits = randPSKsyms(16, 4, dtype=np.complex64)
+    assert syms.dtype == np.complex64 and np.allclose(np.abs(syms), 1)
+    assert next_fast_len(4097) == 4116 and next_fast_len(30) == 30
+    raw, frac = compareValues(np.array([1.0, 2.0]), np.array([1.0, 2.5]), verbose=False)
+    assert raw == 0.5 and frac == 0.25
+    t = Timer()
+    t.start()
+    assert t.end(showSteps=False) >= 0
+    assert X.argmax2d(np.array([[1, 5], [7, 2]])) == (1, 0)
+    assert X.convertEffSNRtoQF2(X.convertQF2toEffSNR(0.3)) == pytest.approx(0.3)
+    assert X.calcQF2(np.array([1, 1j]), np.array([1, 1j])) == pytest.approx(1.0)
+    assert [r[1:] for r in X._runs([3, 4, 5, 9, 12, 15, 20])] == [(3, 1, 3), (9, 3, 3), (20, 1, 1)]
+    if _lib.device_count() == 0:
+        # the product path must fail loudly when there is no GPU: no CPU fallback exists
+        with pytest.raises(RuntimeError):
+            X.fastXcorr(np.ones(8, np.complex64), np.ones(64, np.complex64))
+        with pytest.raises(RuntimeError):
+            X.GroupXcorr(np.ones(32, np.complex64), np.array([0]), np.array([8]), np.array([0.0]), 1.0).xcorr(
+                np.ones(64, np.complex64))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "pydsproutines_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert not re.search(r"^\s*(import|from)\s+oracle\b", src, re.M), fn
