@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log2-block", type=int, default=0)
     ap.add_argument("--blocks-per-batch", type=int, default=0)
+    ap.add_argument("--engine", default="auto", choices=["auto", "fused", "rocfft"])
     ap.add_argument("--no-surface", action="store_true", help="peak-only mode (no CAF surface written)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -116,7 +117,7 @@ def main():
     surface_on = not args.no_surface
 
     plan = CAFPlan(tmpl.cpu().numpy(), max_rx_len=M_RX, bins=bins, grid=N_TMPL, log2_block=args.log2_block,
-                   blocks_per_batch=args.blocks_per_batch)
+                   blocks_per_batch=args.blocks_per_batch, engine=args.engine)
     # outputs live in torch-owned HBM so the peak table can go straight into the RCCL all-gather
     res = CAFResult()
     t_surface = torch.empty((1, S, F_BINS), dtype=torch.float32, device=device) if surface_on else None
@@ -177,15 +178,34 @@ def main():
         msamples = world * S / (elapsed / args.steps) / 1e6
         B, step_len, nb = plan.block, plan.step, plan.blocks_per_batch
         # algorithmic bytes per launch: one launch processes nb rx blocks
-        mul_bytes = nb * 8.0 * B * (F_BINS + 2)                       # write F rows, read X and H0 once
-        cells = nb * step_len * F_BINS
-        mag_bytes = cells * (8.0 + (4.0 if surface_on else 0.0)) + nb * step_len * (4.0 + 8.0)
+        fused = plan.engine_used == "fused"
+        nblk_total = -(-S // step_len)
+        blocks_per_launch = nblk_total / max(1, -(-nblk_total // nb))  # average (the last batch may be short)
+        cells = blocks_per_launch * step_len * F_BINS
+        if fused:
+            # fused kernel: reads X once per hypothesis group, writes |y|^2 (4 B/cell, 64-delay tiles)
+            tiles = -(-step_len // 64)
+            mul_bytes = blocks_per_launch * (tiles * 64 * F_BINS * 4.0 + 8.0 * B * (F_BINS / 64.0 + 1))
+            # transpose kernel: reads the tiles, writes the surface (+ row results)
+            mag_bytes = cells * (4.0 + (4.0 if surface_on else 0.0)) + blocks_per_launch * step_len * (4.0 + 8.0)
+            # standard FFT operation count + the X*H products + |.|^2
+            flops_per_launch = blocks_per_launch * F_BINS * (5.0 * B * np.log2(B) + 6.0 * B + 3.0 * step_len)
+        else:
+            mul_bytes = blocks_per_launch * 8.0 * B * (F_BINS + 2)      # write F rows, read X and H0 once
+            mag_bytes = cells * (8.0 + (4.0 if surface_on else 0.0)) + blocks_per_launch * step_len * (4.0 + 8.0)
         st = {}
         for name, alg in (("spectral_conj_multiply", mul_bytes), ("magsq_norm_argmax", mag_bytes)):
             ms, n = stages[name]
             avg = ms / max(n, 1)
             st[name] = {"avg_ms": avg, "launches": n, "alg_bytes_per_launch": alg,
                         "achieved_GBs": alg / (avg * 1e-3) / 1e9 if avg > 0 else 0.0}
+        if fused:
+            st["spectral_conj_multiply"]["kernel"] = "k_fused_caf (multiply + LDS inverse FFT + |.|^2)"
+            st["spectral_conj_multiply"]["alg_flops_per_launch"] = flops_per_launch
+            st["spectral_conj_multiply"]["achieved_TFLOPs"] = (
+                flops_per_launch / (st["spectral_conj_multiply"]["avg_ms"] * 1e-3) / 1e12
+                if st["spectral_conj_multiply"]["avg_ms"] > 0 else 0.0)
+            st["magsq_norm_argmax"]["kernel"] = "k_transpose_norm_argmax"
         for name in ("fft_forward(rocFFT)", "fft_inverse(rocFFT)", "energy_prefix", "gather_blocks", "peak_reduce"):
             ms, n = stages[name]
             st[name] = {"avg_ms": ms / max(n, 1), "launches": n}
@@ -196,8 +216,10 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("config") == {"block": B, "blocks_per_batch": nb, "surface": surface_on}:
-                    traffic = tj.get(dom)
+                for entry in tj.get("entries", []):
+                    if entry.get("config") == {"engine": plan.engine_used, "block": B, "blocks_per_batch": nb,
+                                               "surface": surface_on}:
+                        traffic = entry.get(dom)
             except Exception:
                 traffic = None
         combined_bytes = (st["spectral_conj_multiply"]["alg_bytes_per_launch"] + st["magsq_norm_argmax"]["alg_bytes_per_launch"])
@@ -223,11 +245,32 @@ def main():
             },
             "correlations_per_s": world * F_BINS / (elapsed / args.steps),
             "caf_cells_per_s": world * S * F_BINS / (elapsed / args.steps),
-            "roofline": {
-                "kernel": dom, "bound": "hbm", "achieved": st[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": st[dom]["achieved_GBs"] / HBM_PEAK_GBS, "traffic": traffic,
-                "avg_launch_ms": st[dom]["avg_ms"], "alg_bytes_per_launch": st[dom]["alg_bytes_per_launch"],
+            "roofline": (
+                {
+                    # the fused FFT kernel is bound by the f32 vector ALUs / LDS, not by HBM: price it against
+                    # the chip's f32 peak (157.3 TFLOP/s vector == f32 MFMA rate, MI355X_MICROARCH.md)
+                    "kernel": "k_fused_caf", "bound": "mfma", "achieved": st[dom]["achieved_TFLOPs"],
+                    "peak": 157.3, "unit": "TFLOP/s", "frac": st[dom]["achieved_TFLOPs"] / 157.3, "traffic": traffic,
+                    "avg_launch_ms": st[dom]["avg_ms"], "alg_flops_per_launch": st[dom]["alg_flops_per_launch"],
+                    "note": "f32 FFT butterflies on the vector ALUs (no MFMA instruction is used); the figure is "
+                            "the standard 5*B*log2(B) FFT count + X*H products + |.|^2 against the 157.3 TF f32 peak",
+                }
+                if fused and dom == "spectral_conj_multiply" else
+                {
+                    "kernel": st[dom].get("kernel", dom), "bound": "hbm", "achieved": st[dom]["achieved_GBs"],
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": st[dom]["achieved_GBs"] / HBM_PEAK_GBS,
+                    "traffic": traffic, "avg_launch_ms": st[dom]["avg_ms"],
+                    "alg_bytes_per_launch": st[dom]["alg_bytes_per_launch"],
+                }
+            ),
+            "roofline_hbm_kernel": {
+                "kernel": st["magsq_norm_argmax"].get("kernel", "k_magsq_norm_argmax"), "bound": "hbm",
+                "achieved": st["magsq_norm_argmax"]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": st["magsq_norm_argmax"]["achieved_GBs"] / HBM_PEAK_GBS,
+                "avg_launch_ms": st["magsq_norm_argmax"]["avg_ms"],
+                "alg_bytes_per_launch": st["magsq_norm_argmax"]["alg_bytes_per_launch"],
             },
+            "engine": plan.engine_used,
             "roofline_conjmul_plus_magsq": {
                 "achieved": combined_bytes / (combined_ms * 1e-3) / 1e9 if combined_ms > 0 else 0.0,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -99,7 +99,19 @@ typedef struct caf_plan_desc {
     int64_t max_rx_len;        /* largest rx length (samples) execute() will be given             */
     int32_t log2_block;        /* overlap-save FFT size B = 2^log2_block; 0 => library default    */
     int32_t blocks_per_batch;  /* rx blocks processed per launch group; 0 => library default      */
+    int32_t engine;            /* CAF_ENGINE_AUTO / _ROCFFT / _FUSED (see below)                  */
+    int32_t reserved;          /* must be 0                                                       */
 } caf_plan_desc;
+
+/* Inverse-transform engine of the hypothesis plan.
+ *   ROCFFT: spectral multiply kernel -> batched rocFFT inverse -> |.|^2 kernel (any block size);
+ *   FUSED : one hand-written kernel does multiply + 16384-point inverse FFT in LDS + |.|^2, a second
+ *           one transposes/normalises/argmaxes; needs template_len <= 8192, (bins mode) grid | 16384,
+ *           and cannot produce d_cqf.
+ *   AUTO  : FUSED when its conditions hold and log2_block is 0 or 14, else ROCFFT. */
+#define CAF_ENGINE_AUTO 0
+#define CAF_ENGINE_ROCFFT 1
+#define CAF_ENGINE_FUSED 2
 
 CAF_EXPORT int32_t caf_plan_create(caf_plan* plan, const caf_plan_desc* desc);
 CAF_EXPORT int32_t caf_plan_destroy(caf_plan plan);
@@ -107,6 +119,9 @@ CAF_EXPORT int32_t caf_plan_destroy(caf_plan plan);
 /* Geometry chosen by the plan: block size B, valid outputs per block, batch, workspace bytes. */
 CAF_EXPORT int32_t caf_plan_info(caf_plan plan, int32_t* block, int32_t* step, int32_t* blocks_per_batch,
                                  int64_t* workspace_bytes);
+
+/* Engine actually selected by the plan: CAF_ENGINE_ROCFFT or CAF_ENGINE_FUSED. */
+CAF_EXPORT int32_t caf_plan_engine(caf_plan plan, int32_t* engine);
 
 /* Outputs of one execute (any pointer may be NULL = not wanted). */
 typedef struct caf_outputs {

@@ -27,6 +27,9 @@ CAF_ERR_NODEVICE = 5
 
 CAF_FREQ_BINS = 0
 CAF_FREQ_NORM = 1
+CAF_ENGINE_AUTO = 0
+CAF_ENGINE_ROCFFT = 1
+CAF_ENGINE_FUSED = 2
 CAF_NUM_STAGES = 7
 STAGE_NAMES = (
     "energy_prefix",
@@ -56,6 +59,8 @@ class CafPlanDesc(ct.Structure):
         ("max_rx_len", ct.c_int64),
         ("log2_block", ct.c_int32),
         ("blocks_per_batch", ct.c_int32),
+        ("engine", ct.c_int32),
+        ("reserved", ct.c_int32),
     ]
 
 
@@ -92,6 +97,7 @@ _SIGNATURES = {
     "caf_plan_create": [ct.POINTER(_P), ct.POINTER(CafPlanDesc)],
     "caf_plan_destroy": [_P],
     "caf_plan_info": [_P, ct.POINTER(_I32), ct.POINTER(_I32), ct.POINTER(_I32), ct.POINTER(_I64)],
+    "caf_plan_engine": [_P, ct.POINTER(_I32)],
     "caf_plan_execute": [_P, _P, _I64, _I64, _I64, ct.POINTER(CafOutputs), _P],
     "caf_plan_profile": [_P, _I32],
     "caf_plan_profile_get": [_P, ct.POINTER(ct.c_double), ct.POINTER(_I64)],

@@ -51,6 +51,7 @@ class CAFPlan:
         log2_block=0,
         blocks_per_batch=0,
         device=None,
+        engine="auto",
     ):
         lib = _lib.load()
         _lib.require_device()
@@ -90,6 +91,11 @@ class CAFPlan:
         self.F = int(d.num_freqs)
         d.max_rx_len = int(max_rx_len)
         d.log2_block, d.blocks_per_batch = int(log2_block), int(blocks_per_batch)
+        try:
+            d.engine = {"auto": _lib.CAF_ENGINE_AUTO, "rocfft": _lib.CAF_ENGINE_ROCFFT, "fused": _lib.CAF_ENGINE_FUSED}[engine]
+        except KeyError:
+            raise ValueError("engine must be 'auto', 'rocfft' or 'fused'")
+        self.engine = engine
         h = ct.c_void_p()
         _lib.check(lib.caf_plan_create(ct.byref(h), ct.byref(d)), "caf_plan_create")
         self._h = h
@@ -97,6 +103,9 @@ class CAFPlan:
         blk, step, nb, ws = ct.c_int32(), ct.c_int32(), ct.c_int32(), ct.c_int64()
         _lib.check(lib.caf_plan_info(h, ct.byref(blk), ct.byref(step), ct.byref(nb), ct.byref(ws)))
         self.block, self.step, self.blocks_per_batch, self.workspace_bytes = blk.value, step.value, nb.value, ws.value
+        eng = ct.c_int32()
+        _lib.check(lib.caf_plan_engine(h, ct.byref(eng)))
+        self.engine_used = "fused" if eng.value == _lib.CAF_ENGINE_FUSED else "rocfft"
 
     def close(self):
         h, self._h = getattr(self, "_h", None), None

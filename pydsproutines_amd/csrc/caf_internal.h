@@ -82,6 +82,15 @@ void launch_complex_norm(const float2* pbuf, int32_t pitch, int32_t nfreq, const
                          int64_t num_shifts, int32_t step, int32_t blk0, int32_t nblk, int32_t nhyp, float2* cqf,
                          hipStream_t st);
 void launch_scale(float2* y, int64_t n, float scale, hipStream_t st);
+
+// caf_fused.hip
+void launch_fused_caf(const float2* xb, const float2* hc, const int32_t* shifts, const float2* tw1,
+                      const float2* tw23, int32_t table_mode, int32_t nfreq, int32_t nhyp, int32_t hyp_per_wg,
+                      int32_t nblk, int32_t tiles_per_blk, float* vt, hipStream_t st);
+void launch_transpose_norm_argmax(const float* vt, int32_t ntmpl, int32_t nfreq, const float* tscale,
+                                  const float* inv_e, int64_t num_shifts, int64_t shift_start, int32_t step,
+                                  int32_t blk0, int32_t nblk, int32_t tiles_per_blk, float* surface, float* row_max,
+                                  int32_t* row_arg, PeakRec* partial, int64_t partial_per_tmpl, hipStream_t st);
 void launch_colmax_abs(const float2* z, int32_t rows, int64_t n, float* maxv, int32_t* arg, hipStream_t st);
 
 // rocFFT wrapper shared by the plan and the ops (caf_fft.hip)

@@ -35,6 +35,10 @@ struct caf_plan_t {
     float2* d_xb = nullptr;
     float2* d_pbuf = nullptr;
     PeakRec* d_partial = nullptr;
+    bool fused = false;
+    float* d_vt = nullptr;
+    float2* d_tw1 = nullptr;
+    float2* d_tw23 = nullptr;
     FftPlan fwd, inv;
     int64_t workspace_bytes = 0;
     // profiling
@@ -97,7 +101,8 @@ struct caf_plan_t {
         pool.clear();
         fwd.destroy();
         inv.destroy();
-        void* ptrs[] = {d_hc, d_shifts, d_tscale, d_gstart, d_glen, d_tile_sums, d_prefix, d_inv_e, d_xb, d_pbuf, d_partial};
+        void* ptrs[] = {d_hc,  d_shifts, d_tscale, d_gstart,  d_glen, d_tile_sums, d_prefix,
+                        d_inv_e, d_xb,   d_pbuf,   d_partial, d_vt,   d_tw1,       d_tw23};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
     }
@@ -216,8 +221,16 @@ static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
     for (int g = 0; g < p->G; ++g)
         CAF_REQUIRE(gs[g] >= 0 && gl[g] >= 1 && (int64_t)gs[g] + gl[g] <= N, "group outside the template span");
 
+    // engine: the fused LDS-resident kernel works on 16384-point blocks
+    CAF_REQUIRE(d->engine >= CAF_ENGINE_AUTO && d->engine <= CAF_ENGINE_FUSED && d->reserved == 0, "bad engine field");
+    const bool fused_ok = N <= 8192 && (d->freq_mode != CAF_FREQ_BINS || (d->grid >= 1 && 16384 % d->grid == 0)) &&
+                          (d->log2_block == 0 || d->log2_block == 14);
+    CAF_REQUIRE(d->engine != CAF_ENGINE_FUSED || fused_ok,
+                "fused engine needs template_len <= 8192, grid | 16384 and log2_block 0 or 14");
+    p->fused = (d->engine == CAF_ENGINE_FUSED) || (d->engine == CAF_ENGINE_AUTO && fused_ok);
+
     // block size: B = 2^k, B >= 2N (>= 50 % valid outputs); default 16 N clipped to [2^12, 2^18]
-    int lb = d->log2_block;
+    int lb = p->fused ? 14 : d->log2_block;
     const int lmin = ilog2_ceil(2 * (int64_t)N);
     if (lb <= 0) {
         lb = std::min(std::max(ilog2_ceil(16 * (int64_t)N), 12), 18);
@@ -255,17 +268,24 @@ static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
 
     // batch: aim at ~128 MiB of hypothesis products in flight
     const int64_t total_blocks = (d->max_rx_len - N + 1 + p->step - 1) / p->step;
+    p->tiles_per_blk = (p->step + MAG_S - 1) / MAG_S;
     int nb = d->blocks_per_batch;
     if (nb <= 0) {
-        const int64_t per_block = (int64_t)T * F * p->pitch * 8;
-        nb = (int)std::max<int64_t>(1, std::min<int64_t>(64, ((int64_t)128 << 20) / per_block));
+        if (p->fused) {
+            // |y|^2 tiles of a batch: up to 18 GiB of the 288 GB HBM, so that config C2 (17.3 GB) is ONE
+            // launch of 5460 workgroups (21.3 rounds over 256 CUs: small tail) instead of many short ones
+            const int64_t per_block = (int64_t)p->tiles_per_blk * T * F * 64 * 4;
+            nb = (int)std::max<int64_t>(1, std::min<int64_t>(65535, ((int64_t)18 << 30) / per_block));
+        } else {
+            const int64_t per_block = (int64_t)T * F * p->pitch * 8;
+            nb = (int)std::max<int64_t>(1, std::min<int64_t>(64, ((int64_t)128 << 20) / per_block));
+        }
     }
     nb = (int)std::min<int64_t>(nb, std::max<int64_t>(1, total_blocks));
     p->nb = nb;
     p->max_blocks = (total_blocks + nb - 1) / nb * nb;
-    p->tiles_per_blk = (p->step + MAG_S - 1) / MAG_S;
     p->partial_per_tmpl = p->max_blocks * p->tiles_per_blk;
-    p->hyp_per_wg = (int)std::min<int64_t>(16, (int64_t)T * F);
+    p->hyp_per_wg = (int)std::min<int64_t>(p->fused ? 64 : 16, (int64_t)T * F);
 
     // device buffers
     int rc;
@@ -280,7 +300,27 @@ static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
     // all rx block spectra are produced up front, fwd_chunk blocks per rocFFT launch
     p->fwd_chunk = (int)std::min<int64_t>(32, p->max_blocks);
     if ((rc = p->alloc(&p->d_xb, (p->max_blocks + p->fwd_chunk) * B))) return rc;
-    if ((rc = p->alloc(&p->d_pbuf, (int64_t)nb * T * F * p->pitch))) return rc;
+    if (p->fused) {
+        if ((rc = p->alloc(&p->d_vt, (int64_t)nb * p->tiles_per_blk * T * F * 64))) return rc;
+        if ((rc = p->alloc(&p->d_tw1, 16 * 1024))) return rc;
+        if ((rc = p->alloc(&p->d_tw23, 16 * 64 + 16 * 4))) return rc;
+        // inter-pass twiddles of the 16*16*16*4 decomposition, computed in f64 (caf_fused.hip)
+        std::vector<std::complex<float>> tw1(16 * 1024), tw23(16 * 64 + 16 * 4);
+        auto cis = [](double num, double den) {
+            const double ph = 2.0 * M_PI * std::fmod(num, den) / den;
+            return std::complex<float>((float)std::cos(ph), (float)std::sin(ph));
+        };
+        for (int n1 = 0; n1 < 16; ++n1)
+            for (int m2 = 0; m2 < 1024; ++m2) tw1[n1 * 1024 + m2] = cis((double)n1 * m2, 16384.0);
+        for (int n2 = 0; n2 < 16; ++n2)
+            for (int c = 0; c < 64; ++c) tw23[n2 * 64 + c] = cis((double)n2 * c, 1024.0);
+        for (int n3 = 0; n3 < 16; ++n3)
+            for (int dd = 0; dd < 4; ++dd) tw23[1024 + n3 * 4 + dd] = cis((double)n3 * dd, 64.0);
+        CAF_HIP_TRY(hipMemcpy(p->d_tw1, tw1.data(), tw1.size() * 8, hipMemcpyHostToDevice));
+        CAF_HIP_TRY(hipMemcpy(p->d_tw23, tw23.data(), tw23.size() * 8, hipMemcpyHostToDevice));
+    } else {
+        if ((rc = p->alloc(&p->d_pbuf, (int64_t)nb * T * F * p->pitch))) return rc;
+    }
     if ((rc = p->alloc(&p->d_partial, (int64_t)T * p->partial_per_tmpl))) return rc;
 
     // template spectra: u = auto_conj ? tmpl : conj(tmpl);  u_f[n] = u[n] exp(+j 2 pi nu_f n);
@@ -334,7 +374,7 @@ static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
     CAF_HIP_TRY(hipMemcpy(p->d_glen, gl.data(), gl.size() * 4, hipMemcpyHostToDevice));
 
     if ((rc = p->fwd.create(false, (size_t)B, (size_t)p->fwd_chunk, (size_t)B))) return rc;
-    if ((rc = p->inv.create(true, (size_t)B, (size_t)nb * T * F, (size_t)p->pitch))) return rc;
+    if (!p->fused && (rc = p->inv.create(true, (size_t)B, (size_t)nb * T * F, (size_t)p->pitch))) return rc;
     p->workspace_bytes += (int64_t)p->fwd.work_bytes + (int64_t)p->inv.work_bytes;
     return CAF_OK;
 }
@@ -370,6 +410,12 @@ int32_t caf_plan_info(caf_plan plan, int32_t* block, int32_t* step, int32_t* blo
     if (step) *step = plan->step;
     if (blocks_per_batch) *blocks_per_batch = plan->nb;
     if (workspace_bytes) *workspace_bytes = plan->workspace_bytes;
+    return CAF_OK;
+}
+
+int32_t caf_plan_engine(caf_plan plan, int32_t* engine) {
+    CAF_REQUIRE(plan && engine, "NULL argument");
+    *engine = plan->fused ? CAF_ENGINE_FUSED : CAF_ENGINE_ROCFFT;
     return CAF_OK;
 }
 
@@ -414,7 +460,7 @@ int32_t caf_plan_execute(caf_plan p, const float* d_rx, int64_t rx_len, int64_t 
     const int64_t nblk = (num_shifts + p->step - 1) / p->step;
     const int64_t nblk_pad = (nblk + p->nb - 1) / p->nb * p->nb;
     // overlap-save blocks of rx -> spectra X[b] for every block of this call
-    const int64_t nfwd = (nblk_pad + p->fwd_chunk - 1) / p->fwd_chunk;
+    const int64_t nfwd = ((p->fused ? nblk : nblk_pad) + p->fwd_chunk - 1) / p->fwd_chunk;
     p->stage_begin(1, st);
     launch_gather_blocks(rx, rx_len, shift_start, p->step, p->B, (int32_t)(nfwd * p->fwd_chunk), p->d_xb, st);
     p->stage_end(st);
@@ -424,7 +470,22 @@ int32_t caf_plan_execute(caf_plan p, const float* d_rx, int64_t rx_len, int64_t 
         p->stage_end(st);
         if (rc) return rc;
     }
-    for (int64_t b0 = 0; b0 < nblk; b0 += p->nb) {
+    if (p->fused) {
+        CAF_REQUIRE(!out->d_cqf, "the fused engine has no complex-QF output (create the plan with CAF_ENGINE_ROCFFT)");
+        for (int64_t b0 = 0; b0 < nblk; b0 += p->nb) {
+            const int32_t nbk = (int32_t)std::min<int64_t>(p->nb, nblk - b0);
+            p->stage_begin(3, st);
+            launch_fused_caf(p->d_xb + b0 * (int64_t)p->B, p->d_hc, p->d_shifts, p->d_tw1, p->d_tw23,
+                             p->mul_mode == 2 ? 1 : 0, F, T * F, p->hyp_per_wg, nbk, p->tiles_per_blk, p->d_vt, st);
+            p->stage_end(st);
+            p->stage_begin(5, st);
+            launch_transpose_norm_argmax(p->d_vt, T, F, p->d_tscale, p->d_inv_e, num_shifts, shift_start, p->step,
+                                         (int32_t)b0, nbk, p->tiles_per_blk, out->d_surface, out->d_row_max,
+                                         out->d_row_arg, want_peak ? p->d_partial : nullptr, p->partial_per_tmpl, st);
+            p->stage_end(st);
+        }
+    }
+    for (int64_t b0 = 0; !p->fused && b0 < nblk; b0 += p->nb) {
         int rc;
         p->stage_begin(3, st);
         launch_spectral_mul(p->mul_mode, p->d_xb + b0 * (int64_t)p->B, p->d_hc, p->d_shifts, p->B, p->pitch, F, T * F, p->hyp_per_wg, p->nb,
@@ -450,7 +511,8 @@ int32_t caf_plan_execute(caf_plan p, const float* d_rx, int64_t rx_len, int64_t 
     if (want_peak) {
         p->stage_begin(6, st);
         // only the records of the blocks touched by this call are valid
-        launch_peak_reduce(p->d_partial, nblk_pad * p->tiles_per_blk, p->partial_per_tmpl, T, out->d_peak_val,
+        launch_peak_reduce(p->d_partial, (p->fused ? nblk : nblk_pad) * p->tiles_per_blk, p->partial_per_tmpl, T,
+                           out->d_peak_val,
                            out->d_peak_delay, out->d_peak_freq, st);
         p->stage_end(st);
     }

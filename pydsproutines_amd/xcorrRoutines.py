@@ -111,7 +111,8 @@ def fastXcorr(cutout, rx, freqsearch=False, outputCAF=False, shifts=None, absRes
         if ns == 0:
             return out
         lo, cnt, rel = _engine_range(shifts)
-        plan = CAFPlan(_c64(cutout), max_rx_len=len(rx), bins=[0], grid=1 << int(np.ceil(np.log2(max(n, 2)))))
+        plan = CAFPlan(_c64(cutout), max_rx_len=len(rx), bins=[0], grid=1 << int(np.ceil(np.log2(max(n, 2)))),
+                       engine="auto" if absResult else "rocfft")  # complex QF needs the rocFFT engine
         res = plan.run(d_rx, shift_start=lo, num_shifts=cnt, rows=absResult, peak=False, cqf=not absResult)
         if absResult:
             out[:] = res.row_max.get()[0][rel]
@@ -161,7 +162,8 @@ def cztXcorr(cutout, rx, f_searchMin, f_searchMax, fs, cztStep=0.1, outputCAF=Fa
         shifts = np.arange(len(rx) - n + 1)
     shifts = np.asarray(shifts)
     lo, cnt, rel = _engine_range(shifts)
-    plan = CAFPlan(_c64(cutout), max_rx_len=len(rx), freqs_norm=f_search / fs)
+    plan = CAFPlan(_c64(cutout), max_rx_len=len(rx), freqs_norm=f_search / fs,
+                   engine="auto" if outputCAF else "rocfft")
     d_rx = asarray(_c64(rx))
     if outputCAF:
         res = plan.run(d_rx, shift_start=lo, num_shifts=cnt, surface=True, rows=False, peak=False)
@@ -343,7 +345,7 @@ class TemplateCrossCorrelator:
         self._templateNorms = asarray(np.sqrt(np.sum(np.abs(tm.astype(np.complex128)) ** 2, axis=1)).astype(np.float32))
         L = self._templateOrigLength
         self._plan = CAFPlan(_c64(tm), max_rx_len=self._inputSize, bins=[0],
-                             grid=1 << int(np.ceil(np.log2(max(L, 2)))))
+                             grid=1 << int(np.ceil(np.log2(max(L, 2)))), engine="rocfft")
 
     def correlate(self, x, returnMax=False):
         requireDeviceArray(x)

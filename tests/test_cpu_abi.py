@@ -32,8 +32,9 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     from pydsproutines_amd import _lib
 
-    # caf_plan_desc: 2 i32, ptr, 2 i32, 2 ptr, 2 i32, ptr, i32(+pad), ptr, i64, 2 i32
-    assert ctypes.sizeof(_lib.CafPlanDesc) == 88
+    # caf_plan_desc: 2 i32, ptr, 2 i32, 2 ptr, 2 i32, ptr, i32(+pad), ptr, i64, 4 i32
+    assert ctypes.sizeof(_lib.CafPlanDesc) == 96
+    assert _lib.CafPlanDesc.engine.offset == 88
     assert ctypes.sizeof(_lib.CafOutputs) == 7 * ctypes.sizeof(ctypes.c_void_p)
     assert _lib.CafPlanDesc.max_rx_len.offset == 72
 

@@ -178,3 +178,60 @@ def test_argument_validation():
         plan.run(asarray(np.ones(2000, np.complex64)))  # longer than max_rx_len
     with pytest.raises(TypeError):
         plan.run(np.ones(500, np.complex64))  # host array where a device array is required
+
+
+@pytest.mark.parametrize("engine", ["fused", "rocfft"])
+def test_engines_agree_with_oracle(engine, golden):
+    """Both inverse-transform engines (hand-written LDS FFT kernel / rocFFT) against the oracle:
+    on-grid shift mode, explicit-frequency table mode with groups, multi-template, ragged tail."""
+    from pydsproutines_amd import CAFPlan, asarray
+
+    g = golden("c2_mini")
+    t, rx, bins, sh = g["template"], g["rx"], g["bins"], g["shifts"]
+    plan = CAFPlan(t, max_rx_len=rx.size, bins=bins, grid=t.size, engine=engine)
+    assert plan.block == (16384 if engine == "fused" else plan.block)
+    res = plan.run(asarray(rx), surface=True)
+    surf = res.surface.get()[0]
+    tol = _surface_check(surf[sh], g["caf"])
+    _argmax_check(res.row_arg.get()[0][sh], res.row_max.get()[0][sh], g["caf"], tol)
+    assert (int(res.peak_delay.get()[0]), int(bins[res.peak_freq.get()[0]])) == (int(g["d0"][0]), int(g["k0"][0]))
+    np.testing.assert_array_equal(res.row_max.get()[0], surf.max(axis=1))
+    np.testing.assert_array_equal(res.row_arg.get()[0], np.argmax(surf, axis=1))
+
+    # several blocks of 16384 with a ragged tail, 3 templates x 70 bins (2 chunks of hypotheses)
+    rng = np.random.default_rng(77)
+    n, m, T = 512, 40000, 3
+    tm = np.stack([qpsk(rng, n) for _ in range(T)])
+    rx2 = cn(rng, m)
+    spots = [(1000, 3), (17000, -20), (39000, 34)]
+    for i, (d0, k0) in enumerate(spots):
+        rx2[d0 : d0 + n] += (2 * tm[i] * np.exp(2j * np.pi * k0 * np.arange(n) / n)).astype(np.complex64)
+    b2 = np.arange(-35, 35)
+    plan2 = CAFPlan(tm, max_rx_len=m, bins=b2, grid=n, engine=engine, blocks_per_batch=2)
+    r2 = plan2.run(asarray(rx2), surface=True)
+    rows = np.concatenate((np.arange(0, 200), np.arange(15800, 17100), np.arange(m - n + 1 - 300, m - n + 1)))
+    for i, (d0, k0) in enumerate(spots):
+        ref = O.caf_bins(tm[i], rx2, b2, rows)
+        s_i = r2.surface.get()[i]
+        tol = _surface_check(s_i[rows], ref)
+        _argmax_check(r2.row_arg.get()[i][rows], r2.row_max.get()[i][rows], ref, tol)
+        assert (int(r2.peak_delay.get()[i]), int(b2[r2.peak_freq.get()[i]])) == (d0, k0)
+
+    # table mode + groups
+    gg = golden("groupxcorr_small")
+    fs = float(gg["fs"][0])
+    y, starts, lengths, rxg, freqs, shg = gg["y"], gg["starts"], gg["lengths"], gg["rx"], gg["freqs"], gg["shifts"]
+    rel = starts - starts[0]
+    comp = np.zeros(int(rel[-1] + lengths[-1]), np.complex64)
+    for s, r, l in zip(starts, rel, lengths):
+        comp[r : r + l] = y[s : s + l]
+    plan3 = CAFPlan(comp, max_rx_len=rxg.size, freqs_norm=freqs / fs, group_starts=rel, group_lens=lengths, engine=engine)
+    r3 = plan3.run(asarray(rxg), shift_start=int(shg[0]), num_shifts=shg.size, surface=True)
+    ref3 = O.GroupXcorr(y, starts, lengths, freqs, fs).caf(rxg, shg)
+    _surface_check(r3.surface.get()[0], ref3)
+    assert int(r3.peak_delay.get()[0]) == 777 and freqs[int(r3.peak_freq.get()[0])] == 6.0
+    if engine == "fused":
+        with pytest.raises(ValueError):
+            plan3.run(asarray(rxg), cqf=True)  # complex QF is a rocFFT-engine output
+        with pytest.raises(ValueError):
+            CAFPlan(np.ones(9000, np.complex64), max_rx_len=40000, bins=[0], grid=16384, engine="fused")
