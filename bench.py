@@ -63,7 +63,7 @@ def cpu_baseline(rx_host, tmpl_host, bins, budget_s=12.0):
         oracle.caf_bins(tmpl_host, rx_host, bins, sh)
         done += 512
         el = time.perf_counter() - t0
-        if el > budget_s or done >= (1 << 20):
+        if el > budget_s or done >= (1 << 19):
             break
     return {
         "value": done / el / 1e6,
@@ -280,7 +280,7 @@ def main():
             "stages": st,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(rx[: D0 + 70000].cpu().numpy(), tmpl.cpu().numpy(), bins)
+            out["cpu_baseline"] = cpu_baseline(rx[: D0 + 560000].cpu().numpy(), tmpl.cpu().numpy(), bins)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -21,13 +21,13 @@
 // barrier per pass is needed.  LDS image: element (n1, row, col) at n1*1090 + row*68 + col
 // (complex64); the 68/1090 pitches keep the strided reads of passes 3 and 4 off the same banks.
 // 512 threads (2 waves per SIMD, 256-VGPR budget), two butterflies per thread and pass.
+#include <cstdlib>
+
 #include "caf_internal.h"
 
 namespace caf {
 
 constexpr int FB = 16384;              // fused block size
-constexpr int FT = 512;                // threads per workgroup (8 waves)
-constexpr int BPT = 1024 / FT;         // radix-16 butterflies per thread and pass
 constexpr int F_ROW = 68;              // sub-row pitch (64 used)
 constexpr int F_N1 = 16 * F_ROW + 2;   // pitch between n1 planes (1090)
 constexpr int F_LDS_DATA = 16 * F_N1;  // complex elements
@@ -90,19 +90,32 @@ __device__ __forceinline__ void idft16(float2 (&v)[16]) {
 }
 
 // |y|^2 tiles: vt[blk_local][s_tile][h][64]  (s_tile = delay/64 inside the block)
+// FT threads per workgroup (512: 2 waves/SIMD, 256-VGPR budget; 1024: 4 waves/SIMD, 128 VGPRs);
+// BPT = 1024 / FT radix-16 butterflies per thread and pass.
+template <int FT>
 __global__ __launch_bounds__(FT) void k_fused_caf(const float2* __restrict__ xb,       // [blocks][FB] spectra
                                                   const float2* __restrict__ hc,       // [T][FB] or [T*F][FB]
                                                   const int32_t* __restrict__ shifts,  // [F] (shift modes)
                                                   const float2* __restrict__ tw1,      // [16][1024]
                                                   const float2* __restrict__ tw23,     // [16][64] then [16][4]
                                                   int32_t table_mode, int32_t nfreq, int32_t nhyp, int32_t hyp_per_wg,
-                                                  int32_t tiles_per_blk, float* __restrict__ vt) {
+                                                  int32_t nblk, int32_t tiles_per_blk, float* __restrict__ vt) {
+    constexpr int BPT = 1024 / FT;
     __shared__ __attribute__((aligned(16))) float2 s_d[F_LDS_DATA];
     __shared__ float2 s_tw2[16 * 64];
     __shared__ float2 s_tw3[16 * 4];
     const int tid = threadIdx.x;
-    const int blk = blockIdx.y;
-    const int h0 = blockIdx.x * hyp_per_wg;
+    // XCD-aware mapping (speed only): workgroups are dealt round-robin over the 8 XCDs, so linear id L runs
+    // on XCD L % 8.  All hypothesis groups of one rx block are given to the SAME XCD (block b -> XCD b % 8,
+    // its groups on consecutive slots of that XCD), so the block spectrum X that every group re-reads per
+    // hypothesis is served by one 4 MiB L2 instead of being replicated (and thrashed) in several.
+    const int ngroups = (nhyp + hyp_per_wg - 1) / hyp_per_wg;
+    const int lin = blockIdx.x;
+    const int q = lin >> 3;
+    const int blk = (q / ngroups) * 8 + (lin & 7);
+    const int grp = q - (q / ngroups) * ngroups;
+    if (blk >= nblk) return;
+    const int h0 = grp * hyp_per_wg;
     const int h1 = min(h0 + hyp_per_wg, nhyp);
 
     for (int i = tid; i < 1024; i += FT) s_tw2[i] = tw23[i];
@@ -265,8 +278,8 @@ __global__ __launch_bounds__(FT) void k_fused_caf(const float2* __restrict__ xb,
 // hypotheses (32 KiB, 16-byte loads, 8 in flight per lane) through an LDS transpose; surface rows
 // leave as 512-byte segments.
 // ----------------------------------------------------------------------------------------
-constexpr int TR_F = 128;
-
+// TR_F = hypotheses per LDS chunk: 256 (66 KB tile, whole 1-KiB surface rows at F = 256) or 128 (33 KB).
+template <int TR_F, bool NT_STORE>
 __global__ __launch_bounds__(256) void k_transpose_norm_argmax(
     const float* __restrict__ vt, int32_t ntmpl, int32_t nfreq, const float* __restrict__ tscale,
     const float* __restrict__ inv_e, int64_t num_shifts, int64_t shift_start, int32_t step, int32_t blk0,
@@ -313,15 +326,15 @@ __global__ __launch_bounds__(256) void k_transpose_norm_argmax(
     }
     for (int f0 = 0; f0 < nfreq; f0 += TR_F) {
         const int nf = min(TR_F, nfreq - f0);
-        float4 q[8];
+        float4 q[TR_F / 16];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < TR_F / 16; ++i) {
             const int fl = i * 16 + (threadIdx.x >> 4);
             q[i] = (fl < nf) ? *reinterpret_cast<const float4*>(vin + (int64_t)(f0 + fl) * 64 + s4)
                              : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < TR_F / 16; ++i) {
             const int fl = i * 16 + (threadIdx.x >> 4);
             // invalid delays (g < 0) are stored as -1 so that they never win the argmax
             s_tile[s4 + 0][fl] = g[0] < 0.f ? -1.f : q[i].x * g[0];
@@ -342,7 +355,12 @@ __global__ __launch_bounds__(256) void k_transpose_norm_argmax(
                     const int fl = lane + 64 * c;
                     if (fl < nf) {
                         const float v = s_tile[row][fl];
-                        if (srow) srow[fl] = v;
+                        if (srow) {
+                            if (NT_STORE)
+                                __builtin_nontemporal_store(v, &srow[fl]);  // write-once stream: keep it out of L2
+                            else
+                                srow[fl] = v;
+                        }
                         if (v > b) {
                             b = v;
                             bidx = f0 + fl;
@@ -408,18 +426,52 @@ __global__ __launch_bounds__(256) void k_transpose_norm_argmax(
 void launch_fused_caf(const float2* xb, const float2* hc, const int32_t* shifts, const float2* tw1,
                       const float2* tw23, int32_t table_mode, int32_t nfreq, int32_t nhyp, int32_t hyp_per_wg,
                       int32_t nblk, int32_t tiles_per_blk, float* vt, hipStream_t st) {
-    const dim3 grid((nhyp + hyp_per_wg - 1) / hyp_per_wg, nblk);
-    hipLaunchKernelGGL(k_fused_caf, grid, dim3(FT), 0, st, xb, hc, shifts, tw1, tw23, table_mode, nfreq, nhyp,
-                       hyp_per_wg, tiles_per_blk, vt);
+    const int ngroups = (nhyp + hyp_per_wg - 1) / hyp_per_wg;
+    const dim3 grid((unsigned)(ngroups * 8 * ((nblk + 7) / 8)));  // 1-D, XCD-aware mapping inside the kernel
+    // CAF_FUSED_THREADS=512 selects the 2-waves/SIMD variant (A/B switch; 1024 measured faster)
+    static const int threads = [] {
+        const char* e = getenv("CAF_FUSED_THREADS");
+        return (e && atoi(e) == 512) ? 512 : 1024;
+    }();
+    if (threads == 512)
+        hipLaunchKernelGGL(k_fused_caf<512>, grid, dim3(512), 0, st, xb, hc, shifts, tw1, tw23, table_mode, nfreq,
+                           nhyp, hyp_per_wg, nblk, tiles_per_blk, vt);
+    else
+        hipLaunchKernelGGL(k_fused_caf<1024>, grid, dim3(1024), 0, st, xb, hc, shifts, tw1, tw23, table_mode, nfreq,
+                           nhyp, hyp_per_wg, nblk, tiles_per_blk, vt);
 }
 
 void launch_transpose_norm_argmax(const float* vt, int32_t ntmpl, int32_t nfreq, const float* tscale,
                                   const float* inv_e, int64_t num_shifts, int64_t shift_start, int32_t step,
                                   int32_t blk0, int32_t nblk, int32_t tiles_per_blk, float* surface, float* row_max,
                                   int32_t* row_arg, PeakRec* partial, int64_t partial_per_tmpl, hipStream_t st) {
-    hipLaunchKernelGGL(k_transpose_norm_argmax, dim3(tiles_per_blk, ntmpl, nblk), dim3(256), 0, st, vt, ntmpl, nfreq,
-                       tscale, inv_e, num_shifts, shift_start, step, blk0, tiles_per_blk, surface, row_max, row_arg,
-                       partial, partial_per_tmpl);
+    // CAF_TR_F=64|256 selects another chunk width (A/B switch; 128 measured fastest at F = 256:
+    // 256 halves the occupancy, 64 halves the store segments)
+    static const int trf = [] {
+        const char* e = getenv("CAF_TR_F");
+        return e ? atoi(e) : 128;
+    }();
+    static const int nts = [] {
+        const char* e = getenv("CAF_NT_STORE");
+        return e ? atoi(e) : 0;
+    }();
+    const dim3 grid(tiles_per_blk, ntmpl, nblk);
+    if (trf == 256 && nfreq > 128)
+        hipLaunchKernelGGL((k_transpose_norm_argmax<256, false>), grid, dim3(256), 0, st, vt, ntmpl, nfreq, tscale,
+                           inv_e, num_shifts, shift_start, step, blk0, tiles_per_blk, surface, row_max, row_arg,
+                           partial, partial_per_tmpl);
+    else if (trf == 64)
+        hipLaunchKernelGGL((k_transpose_norm_argmax<64, false>), grid, dim3(256), 0, st, vt, ntmpl, nfreq, tscale,
+                           inv_e, num_shifts, shift_start, step, blk0, tiles_per_blk, surface, row_max, row_arg,
+                           partial, partial_per_tmpl);
+    else if (nts)
+        hipLaunchKernelGGL((k_transpose_norm_argmax<128, true>), grid, dim3(256), 0, st, vt, ntmpl, nfreq, tscale,
+                           inv_e, num_shifts, shift_start, step, blk0, tiles_per_blk, surface, row_max, row_arg,
+                           partial, partial_per_tmpl);
+    else
+        hipLaunchKernelGGL((k_transpose_norm_argmax<128, false>), grid, dim3(256), 0, st, vt, ntmpl, nfreq, tscale,
+                           inv_e, num_shifts, shift_start, step, blk0, tiles_per_blk, surface, row_max, row_arg,
+                           partial, partial_per_tmpl);
 }
 
 }  // namespace caf
