@@ -97,6 +97,12 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    # Rehearsal switch (NOT the measured configuration): BENCH_REHEARSE_GLOO=1 runs the N-rank code path
+    # with every rank on GPU 0 and the peak-table all-gather over gloo, so the multi-rank logic can be
+    # exercised on a one-GPU box.  The driver's runs use one GPU per rank and RCCL.
+    rehearse = os.environ.get("BENCH_REHEARSE_GLOO") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
@@ -104,7 +110,10 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        if rehearse:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=device)
 
     from pydsproutines_amd import CAFPlan, _lib
     from pydsproutines_amd.caf import CAFResult
@@ -140,7 +149,8 @@ def main():
         plan.run(rx, surface=surface_on, rows=True, peak=True, stream=stream, out=res)
         if world > 1:
             # the only collective of the path: RCCL all-gather of the (delay, freq, |peak|) rows
-            gathered["table"] = sharding.all_gather_peak_table(t_peak.view(1, 3), world)
+            rows = t_peak.view(1, 3).cpu() if rehearse else t_peak.view(1, 3)
+            gathered["table"] = sharding.all_gather_peak_table(rows, world)
 
     def fence():
         if world > 1:
@@ -166,7 +176,7 @@ def main():
     plan.profile(False)
 
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
         tb = gathered["table"].cpu().numpy()

@@ -324,15 +324,22 @@ __global__ __launch_bounds__(256) void k_transpose_norm_argmax(
         bv[r] = -1.f;
         bi[r] = 0;
     }
-    for (int f0 = 0; f0 < nfreq; f0 += TR_F) {
+    // Per-lane running best over the columns this lane visits (lane + 64 c of every chunk); the
+    // cross-lane reduction is done once per row after the last chunk.  The next chunk's loads are issued
+    // before the store phase of the current one, so HBM reads stay in flight while rows are written.
+    float4 q[TR_F / 16];
+    auto load_chunk = [&](int f0) {
         const int nf = min(TR_F, nfreq - f0);
-        float4 q[TR_F / 16];
 #pragma unroll
         for (int i = 0; i < TR_F / 16; ++i) {
             const int fl = i * 16 + (threadIdx.x >> 4);
             q[i] = (fl < nf) ? *reinterpret_cast<const float4*>(vin + (int64_t)(f0 + fl) * 64 + s4)
                              : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+    };
+    load_chunk(0);
+    for (int f0 = 0; f0 < nfreq; f0 += TR_F) {
+        const int nf = min(TR_F, nfreq - f0);
 #pragma unroll
         for (int i = 0; i < TR_F / 16; ++i) {
             const int fl = i * 16 + (threadIdx.x >> 4);
@@ -343,12 +350,11 @@ __global__ __launch_bounds__(256) void k_transpose_norm_argmax(
             s_tile[s4 + 3][fl] = g[3] < 0.f ? -1.f : q[i].w * g[3];
         }
         __syncthreads();
+        if (f0 + TR_F < nfreq) load_chunk(f0 + TR_F);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = wave + 4 * r;
             if (row < nrows) {
-                float b = -1.f;
-                int32_t bidx = 0;
                 float* srow = surface ? surface + ((int64_t)t * num_shifts + rel0 + row) * nfreq + f0 : nullptr;
 #pragma unroll
                 for (int c = 0; c < TR_F / 64; ++c) {
@@ -361,28 +367,28 @@ __global__ __launch_bounds__(256) void k_transpose_norm_argmax(
                             else
                                 srow[fl] = v;
                         }
-                        if (v > b) {
-                            b = v;
-                            bidx = f0 + fl;
+                        if (v > bv[r]) {  // columns are visited in increasing order: first maximum wins
+                            bv[r] = v;
+                            bi[r] = f0 + fl;
                         }
                     }
-                }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    const float ov = __shfl_xor(b, o, 64);
-                    const int32_t oi = __shfl_xor(bidx, o, 64);
-                    if (ov > b || (ov == b && oi < bidx)) {
-                        b = ov;
-                        bidx = oi;
-                    }
-                }
-                if (b > bv[r]) {
-                    bv[r] = b;
-                    bi[r] = bidx;
                 }
             }
         }
         __syncthreads();
+    }
+    // one cross-lane reduction per row: highest value, lowest frequency index on ties
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv[r], o, 64);
+            const int32_t oi = __shfl_xor(bi[r], o, 64);
+            if (ov > bv[r] || (ov == bv[r] && oi < bi[r])) {
+                bv[r] = ov;
+                bi[r] = oi;
+            }
+        }
     }
     if (lane == 0) {
 #pragma unroll

@@ -283,27 +283,37 @@ __global__ __launch_bounds__(MAG_THREADS) void k_magsq_norm_argmax(
         bi[r] = 0;
     }
 
+    // A wave owns the hypothesis rows fl = wave + 4 k of a chunk: all MAG_F/4 loads of a chunk are issued
+    // before any is used, and the next chunk's loads are issued before the store phase of the current
+    // one, so HBM reads stay in flight while rows are written.  Each lane keeps a running best over the
+    // columns it visits; the cross-lane reduction happens once per row after the last chunk.
+    constexpr int LOADS = MAG_F / (MAG_THREADS / 64);
+    float2 q[LOADS];
+    auto load_chunk = [&](int f0) {
+        const int nf = min(MAG_F, nfreq - f0);
+#pragma unroll
+        for (int k = 0; k < LOADS; ++k) {
+            const int fl = wave + k * (MAG_THREADS / 64);
+            q[k] = (lane_ok && fl < nf) ? pin[(int64_t)(f0 + fl) * pitch] : make_float2(0.f, 0.f);
+        }
+    };
+    load_chunk(0);
+    const float gsc = ts * ie;
     for (int f0 = 0; f0 < nfreq; f0 += MAG_F) {
         const int nf = min(MAG_F, nfreq - f0);
         // phase 1: hypothesis rows -> LDS tile (transposed)
-#pragma unroll 8
-        for (int fl = wave; fl < nf; fl += MAG_THREADS / 64) {
-            float v = -1.f;
-            if (lane_ok) {
-                const float2 p = pin[(int64_t)(f0 + fl) * pitch];
-                v = (p.x * p.x + p.y * p.y) * ts * ie;
-            }
-            s_tile[lane][fl] = v;
+#pragma unroll
+        for (int k = 0; k < LOADS; ++k) {
+            const int fl = wave + k * (MAG_THREADS / 64);
+            s_tile[lane][fl] = lane_ok ? (q[k].x * q[k].x + q[k].y * q[k].y) * gsc : -1.f;
         }
         __syncthreads();
-        // phase 2: delay rows -> surface, running argmax
+        if (f0 + MAG_F < nfreq) load_chunk(f0 + MAG_F);
+        // phase 2: delay rows -> surface, per-lane running argmax
 #pragma unroll
         for (int r = 0; r < ROWS_PER_WAVE; ++r) {
             const int row = wave + r * (MAG_THREADS / 64);
             if (row < nrows) {
-                Best b;
-                b.v = -1.f;
-                b.i = 0;
                 float* srow = surface ? surface + ((int64_t)t * num_shifts + rel0 + row) * nfreq + f0 : nullptr;
 #pragma unroll
                 for (int c = 0; c < MAG_F / 64; ++c) {
@@ -311,20 +321,24 @@ __global__ __launch_bounds__(MAG_THREADS) void k_magsq_norm_argmax(
                     if (fl < nf) {
                         const float v = s_tile[row][fl];
                         if (srow) srow[fl] = v;
-                        if (v > b.v) {
-                            b.v = v;
-                            b.i = f0 + fl;
+                        if (v > bv[r]) {  // columns are visited in increasing order: first maximum wins
+                            bv[r] = v;
+                            bi[r] = f0 + fl;
                         }
                     }
-                }
-                b = wave_best(b);
-                if (b.v > bv[r]) {
-                    bv[r] = b.v;
-                    bi[r] = b.i;
                 }
             }
         }
         __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS_PER_WAVE; ++r) {
+        Best b;
+        b.v = bv[r];
+        b.i = bi[r];
+        b = wave_best(b);
+        bv[r] = b.v;
+        bi[r] = b.i;
     }
     // per-row results -> LDS -> coalesced stores; tile best -> partial record
     if (lane == 0) {
