@@ -227,6 +227,10 @@ CAF_EXPORT int32_t caf_upfirdn(const float* d_x, int64_t rows, int64_t n, const 
 CAF_EXPORT int32_t caf_czt_run_many(const float* d_x, int64_t rows, int32_t m, int32_t k, int32_t nfft,
                                     const float* d_aa, const float* d_fv, const float* d_ww, float* d_out,
                                     void* stream);
+/* IQ ingest: interleaved int16 I/Q -> complex64 * scale on the device, i.e. the
+ * np.fromfile(int16).astype(float32).view(complex64) of usrpRoutines.simpleBinRead (usrpRoutines.py:51-67)
+ * done after the (half-size) H2D copy as in benchmarks/benchmark_cupyCopyAndConvert.py:17-25 */
+CAF_EXPORT int32_t caf_iq16_to_c64(const int16_t* d_iq, int64_t num_samples, float scale, float* d_out, void* stream);
 /* per column of a complex64 (rows, n) matrix: max_r |z| and the first row attaining it
  * (TemplateCrossCorrelator.correlate(returnMax=True), xcorrRoutines.py:361-371) */
 CAF_EXPORT int32_t caf_colmax_abs(const float* d_z, int32_t rows, int64_t n, float* d_max, int32_t* d_arg, void* stream);

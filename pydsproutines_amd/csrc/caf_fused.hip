@@ -204,7 +204,9 @@ __global__ __launch_bounds__(FT) void k_fused_caf(const float2* __restrict__ xb,
             for (int n2 = 0; n2 < 16; ++n2) s_d[base + n2 * F_ROW] = v[n2];
             __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();
+        // No workgroup barrier here: plane n1 = idx >> 6 is written in pass 2 and read in pass 3 by the SAME
+        // wave (wave w owns planes w, w + FT/64, ...), and a wave's LDS operations complete in order.
+        __builtin_amdgcn_wave_barrier();
         // ---- pass 3: DFT16 over c, in place (n1 = idx >> 6, n2 = (idx >> 2) & 15, d = idx & 3) ----
 #pragma unroll
         for (int j = 0; j < BPT; ++j) {

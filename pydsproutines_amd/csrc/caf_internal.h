@@ -82,6 +82,7 @@ void launch_complex_norm(const float2* pbuf, int32_t pitch, int32_t nfreq, const
                          int64_t num_shifts, int32_t step, int32_t blk0, int32_t nblk, int32_t nhyp, float2* cqf,
                          hipStream_t st);
 void launch_scale(float2* y, int64_t n, float scale, hipStream_t st);
+void launch_iq16_to_c64(const short* in, int64_t nsamp, float scale, float2* out, hipStream_t st);
 
 // caf_fused.hip
 void launch_fused_caf(const float2* xb, const float2* hc, const int32_t* shifts, const float2* tw1,

@@ -331,6 +331,15 @@ int32_t caf_czt_run_many(const float* d_x, int64_t rows, int32_t m, int32_t k, i
     return CAF_OK;
 }
 
+int32_t caf_iq16_to_c64(const int16_t* d_iq, int64_t num_samples, float scale, float* d_out, void* stream) {
+    CAF_REQUIRE(d_iq && d_out && num_samples >= 0, "caf_iq16_to_c64: bad arguments");
+    CAF_REQUIRE((reinterpret_cast<uintptr_t>(d_iq) & 7) == 0 && (reinterpret_cast<uintptr_t>(d_out) & 15) == 0,
+                "caf_iq16_to_c64: d_iq must be 8-byte and d_out 16-byte aligned");
+    launch_iq16_to_c64(d_iq, num_samples, scale, (float2*)d_out, (hipStream_t)stream);
+    CAF_HIP_TRY(hipGetLastError());
+    return CAF_OK;
+}
+
 int32_t caf_colmax_abs(const float* d_z, int32_t rows, int64_t n, float* d_max, int32_t* d_arg, void* stream) {
     CAF_REQUIRE(d_z && d_max && d_arg && rows >= 1 && n >= 1, "caf_colmax_abs: bad arguments");
     launch_colmax_abs((const float2*)d_z, rows, n, d_max, d_arg, (hipStream_t)stream);

@@ -471,6 +471,26 @@ __global__ __launch_bounds__(256) void k_scale(float2* __restrict__ y, int64_t n
     }
 }
 
+// interleaved int16 IQ -> complex64 (usrpRoutines.simpleBinRead's .astype(float32).view(complex64),
+// usrpRoutines.py:51-67, done on the device as in benchmarks/benchmark_cupyCopyAndConvert.py:17-25):
+// 4 B read + 8 B write per sample; one thread converts 4 samples (16-B load, 2 x 16-B stores).
+__global__ __launch_bounds__(256) void k_iq16_to_c64(const short* __restrict__ in, int64_t nsamp, float scale,
+                                                     float2* __restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * 256 * 4;
+    for (int64_t s = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; s < nsamp; s += stride) {
+        if (s + 4 <= nsamp) {
+            const short4 a = *reinterpret_cast<const short4*>(in + 2 * s);
+            const short4 b = *reinterpret_cast<const short4*>(in + 2 * s + 4);
+            float4 o0 = make_float4(a.x * scale, a.y * scale, a.z * scale, a.w * scale);
+            float4 o1 = make_float4(b.x * scale, b.y * scale, b.z * scale, b.w * scale);
+            *reinterpret_cast<float4*>(out + s) = o0;
+            *reinterpret_cast<float4*>(out + s + 2) = o1;
+        } else {
+            for (int64_t k = s; k < nsamp; ++k) out[k] = make_float2(in[2 * k] * scale, in[2 * k + 1] * scale);
+        }
+    }
+}
+
 // ---- engine add-ons: complex QF output and the across-template maximum -------------------
 // cqf[h][i] = P[h][i] * sqrt(tscale[t] * inv_e[i])   (TemplateCrossCorrelator layout, xcorrRoutines.py:352-357)
 __global__ __launch_bounds__(256) void k_complex_norm(const float2* __restrict__ pbuf, int32_t pitch, int32_t nfreq,
@@ -630,6 +650,12 @@ void launch_complex_norm(const float2* pbuf, int32_t pitch, int32_t nfreq, const
                          hipStream_t st) {
     hipLaunchKernelGGL(k_complex_norm, dim3(cdiv(step, 256), nhyp, nblk), dim3(256), 0, st, pbuf, pitch, nfreq, tscale,
                        inv_e, num_shifts, step, blk0, nhyp, cqf);
+}
+
+void launch_iq16_to_c64(const short* in, int64_t nsamp, float scale, float2* out, hipStream_t st) {
+    if (nsamp > 0)
+        hipLaunchKernelGGL(k_iq16_to_c64, dim3(std::min<unsigned>(cdiv(nsamp, 1024), 8192)), dim3(256), 0, st, in, nsamp,
+                           scale, out);
 }
 
 void launch_scale(float2* y, int64_t n, float scale, hipStream_t st) {

@@ -1,0 +1,77 @@
+"""GPU tests: config-5 pipeline (coarse CAF -> top-k local maxima -> CZT fine zoom) against the oracle's
+cztXcorr, and the int16 IQ ingest kernel (bit-exact)."""
+
+import numpy as np
+import pytest
+
+import oracle as O
+from oracle import kernels as K
+from conftest import cn, qpsk
+
+pytestmark = pytest.mark.gpu
+
+
+def test_c5_caf_plus_czt_zoom():
+    from pydsproutines_amd import CAFPlan, asarray
+    from pydsproutines_amd.zoom import caf_with_zoom, czt_zoom, topk_local_maxima
+
+    rng = np.random.default_rng(55)
+    n, m, fs = 1024, 200_000, 1024.0  # bins are 1 Hz wide
+    t = qpsk(rng, n)
+    rx = (0.5 * cn(rng, m)).astype(np.complex64)
+    planted = [(20_000, 3.30, 1.0), (77_777, -7.65, 0.8), (150_001, 11.02, 0.6), (180_500, 0.48, 0.4)]
+    for d, f, a in planted:
+        rx[d : d + n] += (a * t * np.exp(2j * np.pi * f * np.arange(n) / fs)).astype(np.complex64)
+    bins = np.arange(-16, 16)
+    d_rx = asarray(rx)
+    plan = CAFPlan(t, max_rx_len=m, bins=bins, grid=n)
+    res = plan.run(d_rx, rows=True, peak=True)
+    out = caf_with_zoom(t, d_rx, res, bins, n, fs, k=4, span_bins=1.0, step_bins=1.0 / 64)
+    assert sorted(o["delay"] for o in out) == [d for d, _, _ in planted]
+    cq = [o["coarse_qf2"] for o in out]
+    assert cq == sorted(cq, reverse=True)  # best first (coarse value descending)
+    truth = {d: (f, a) for d, f, a in planted}
+    for o in out:
+        d = o["delay"]
+        f, a = truth[d]
+        assert abs(o["coarse_bin"] - f) <= 0.51
+        assert abs(o["fine_freq"] - f) <= 1.0 / 64 + 1e-9
+        assert o["fine_qf2"] >= o["coarse_qf2"] - 1e-6  # the fine grid contains (or brackets) the coarse bin
+        # oracle: cztXcorr on the same grid at that delay
+        ref, fr = O.cztXcorr(t, rx, o["coarse_bin"] - 1.0, o["coarse_bin"] + 1.0, fs, cztStep=1.0 / 64, outputCAF=True,
+                             shifts=np.array([d]))
+        assert abs(ref[0].max() - o["fine_qf2"]) <= 1e-4
+        assert abs(fr[int(np.argmax(ref[0]))] - o["fine_freq"]) <= 1e-9
+    # the building blocks on their own
+    idx, vals = topk_local_maxima(res.row_max[0], 3, 0.05)
+    oi = K.topk_peaks(res.row_max[0].get(), 0.05, 3)
+    np.testing.assert_array_equal(idx, oi)
+    ff, fq, planes = czt_zoom(t, d_rx, [planted[1][0]], [-8.0], fs, 1.0, 1.0 / 32)
+    ref, fr = O.cztXcorr(t, rx, -9.0, -7.0, fs, cztStep=1.0 / 32, outputCAF=True, shifts=np.array([planted[1][0]]))
+    np.testing.assert_allclose(planes[0], ref[0], atol=1e-4)
+    with pytest.raises(ValueError):
+        topk_local_maxima(res.row_max[0], 3, 0.0, maxNumPeaks=100)  # too many candidates for the buffer
+
+
+def test_iq16_ingest(tmp_path):
+    from pydsproutines_amd import asarray
+    from pydsproutines_amd.usrpRoutines import iq16_to_complex64, simpleBinRead, simpleBinReadToDevice
+
+    rng = np.random.default_rng(66)
+    for n in (0, 1, 3, 4, 1023, 100_003):
+        raw = rng.integers(-32768, 32768, 2 * n, dtype=np.int16)
+        got = iq16_to_complex64(asarray(raw)).get()
+        np.testing.assert_array_equal(got, raw.astype(np.float32).view(np.complex64))  # bit-exact
+    raw = rng.integers(-2048, 2048, 2 * 5000, dtype=np.int16)
+    np.testing.assert_array_equal(iq16_to_complex64(asarray(raw), 1.0 / 2048).get(),
+                                  (raw.astype(np.float32) * np.float32(1.0 / 2048)).view(np.complex64))
+    p = tmp_path / "iq.bin"
+    raw.tofile(p)
+    np.testing.assert_array_equal(simpleBinRead(str(p)), raw.astype(np.float32).view(np.complex64))
+    np.testing.assert_array_equal(simpleBinRead(str(p), numSamps=100, offset=40),
+                                  raw[20:220].astype(np.float32).view(np.complex64))
+    assert simpleBinReadToDevice(str(p), 10).shape == (10,)
+    with pytest.raises(TypeError):
+        simpleBinRead(str(p), in_dtype=np.complex64)
+    with pytest.raises(TypeError):
+        iq16_to_complex64(asarray(raw.astype(np.int32)))
