@@ -92,7 +92,7 @@ __device__ __forceinline__ void idft16(float2 (&v)[16]) {
 // |y|^2 tiles: vt[blk_local][s_tile][h][64]  (s_tile = delay/64 inside the block)
 // FT threads per workgroup (512: 2 waves/SIMD, 256-VGPR budget; 1024: 4 waves/SIMD, 128 VGPRs);
 // BPT = 1024 / FT radix-16 butterflies per thread and pass.
-template <int FT>
+template <int FT, bool STAGGER>
 __global__ __launch_bounds__(FT) void k_fused_caf(const float2* __restrict__ xb,       // [blocks][FB] spectra
                                                   const float2* __restrict__ hc,       // [T][FB] or [T*F][FB]
                                                   const int32_t* __restrict__ shifts,  // [F] (shift modes)
@@ -101,6 +101,7 @@ __global__ __launch_bounds__(FT) void k_fused_caf(const float2* __restrict__ xb,
                                                   int32_t table_mode, int32_t nfreq, int32_t nhyp, int32_t hyp_per_wg,
                                                   int32_t nblk, int32_t tiles_per_blk, float* __restrict__ vt) {
     constexpr int BPT = 1024 / FT;
+    const bool early = (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) != 0;  // wave-uniform
     __shared__ __attribute__((aligned(16))) float2 s_d[F_LDS_DATA];
     __shared__ float2 s_tw2[16 * 64];
     __shared__ float2 s_tw3[16 * 4];
@@ -189,6 +190,26 @@ __global__ __launch_bounds__(FT) void k_fused_caf(const float2* __restrict__ xb,
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
+        row_of(more ? h + 1 : h);  // unconditional refill (the last one is redundant): no select keeps pr alive
+        // Stagger (MI355X_MICROARCH.md, 'Two waves per SIMD', item 9): all 16 waves run the same program between
+        // the same barriers, so their LDS bursts and their VALU bursts coincide.  The odd waves therefore refill
+        // pr (global loads + X*H products) HERE, the even waves during pass 4: the two halves go through the
+        // LDS-heavy and the VALU-heavy parts of passes 2-3 out of phase.
+        if (STAGGER && early) {
+#pragma unroll
+            for (int j = 0; j < BPT; ++j) {
+                float2 xn[16], hn[16];
+                int lzj = 0;
+                asm volatile("" : "+v"(lzj));
+#pragma unroll
+                for (int a = 0; a < 16; ++a) {
+                    xn[a] = ld2(xp, (uint32_t)(1024 * a + j * FT + tid + lzj));
+                    hn[a] = ld2(hrow_cur, (uint32_t)(((1024 * a + tid + j * FT - sh_cur) & (FB - 1)) + lzj));
+                }
+#pragma unroll
+                for (int a = 0; a < 16; ++a) pr[j][a] = cmul(xn[a], hn[a]);
+            }
+        }
         // ---- pass 2: DFT16 over b, in place (n1 = idx >> 6, col = idx & 63) ----
 #pragma unroll
         for (int j = 0; j < BPT; ++j) {
@@ -223,7 +244,6 @@ __global__ __launch_bounds__(FT) void k_fused_caf(const float2* __restrict__ xb,
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
-        row_of(more ? h + 1 : h);  // unconditional refill (the last one is redundant): no select keeps pr alive
         // ---- pass 4: DFT4 over d ; |y|^2 -> vt tiles (lanes <-> consecutive delays) ----
 #pragma unroll
         for (int j = 0; j < BPT; ++j) {
@@ -234,10 +254,12 @@ __global__ __launch_bounds__(FT) void k_fused_caf(const float2* __restrict__ xb,
             float2 xn[16], hn[16];
             int lzj = 0;  // opaque zero created HERE: keeps butterfly j's loads from being merged with j-1's
             asm volatile("" : "+v"(lzj));
+            if (!(STAGGER && early)) {
 #pragma unroll
-            for (int a = 0; a < 16; ++a) {
-                xn[a] = ld2(xp, (uint32_t)(1024 * a + j * FT + tid + lzj));
-                hn[a] = ld2(hrow_cur, (uint32_t)(((1024 * a + tid + j * FT - sh_cur) & (FB - 1)) + lzj));
+                for (int a = 0; a < 16; ++a) {
+                    xn[a] = ld2(xp, (uint32_t)(1024 * a + j * FT + tid + lzj));
+                    hn[a] = ld2(hrow_cur, (uint32_t)(((1024 * a + tid + j * FT - sh_cur) & (FB - 1)) + lzj));
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -265,8 +287,10 @@ __global__ __launch_bounds__(FT) void k_fused_caf(const float2* __restrict__ xb,
                 }
                 __builtin_amdgcn_sched_barrier(0);  // keep the four sub-steps from being co-scheduled (registers)
             }
+            if (!(STAGGER && early)) {
 #pragma unroll
-            for (int a = 0; a < 16; ++a) pr[j][a] = cmul(xn[a], hn[a]);
+                for (int a = 0; a < 16; ++a) pr[j][a] = cmul(xn[a], hn[a]);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -441,12 +465,22 @@ void launch_fused_caf(const float2* xb, const float2* hc, const int32_t* shifts,
         const char* e = getenv("CAF_FUSED_THREADS");
         return (e && atoi(e) == 512) ? 512 : 1024;
     }();
+    // CAF_FUSED_STAGGER=1 enables the odd/even wave stagger (A/B switch).  Measured on MI355X: 23.7 ms vs
+    // 13.6 ms without it -- keeping pr alive through passes 2-3 pushes the kernel from 115 to 128 VGPRs
+    // plus 45 dwords of scratch, which costs far more than the de-synchronisation gains.  Off by default.
+    static const int stagger = [] {
+        const char* e = getenv("CAF_FUSED_STAGGER");
+        return e ? atoi(e) : 0;
+    }();
     if (threads == 512)
-        hipLaunchKernelGGL(k_fused_caf<512>, grid, dim3(512), 0, st, xb, hc, shifts, tw1, tw23, table_mode, nfreq,
-                           nhyp, hyp_per_wg, nblk, tiles_per_blk, vt);
+        hipLaunchKernelGGL((k_fused_caf<512, false>), grid, dim3(512), 0, st, xb, hc, shifts, tw1, tw23, table_mode,
+                           nfreq, nhyp, hyp_per_wg, nblk, tiles_per_blk, vt);
+    else if (stagger)
+        hipLaunchKernelGGL((k_fused_caf<1024, true>), grid, dim3(1024), 0, st, xb, hc, shifts, tw1, tw23, table_mode,
+                           nfreq, nhyp, hyp_per_wg, nblk, tiles_per_blk, vt);
     else
-        hipLaunchKernelGGL(k_fused_caf<1024>, grid, dim3(1024), 0, st, xb, hc, shifts, tw1, tw23, table_mode, nfreq,
-                           nhyp, hyp_per_wg, nblk, tiles_per_blk, vt);
+        hipLaunchKernelGGL((k_fused_caf<1024, false>), grid, dim3(1024), 0, st, xb, hc, shifts, tw1, tw23, table_mode,
+                           nfreq, nhyp, hyp_per_wg, nblk, tiles_per_blk, vt);
 }
 
 void launch_transpose_norm_argmax(const float* vt, int32_t ntmpl, int32_t nfreq, const float* tscale,
