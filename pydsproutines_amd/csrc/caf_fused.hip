@@ -3,8 +3,8 @@
 //
 // Why: with rocFFT in the middle, every hypothesis product makes four HBM passes
 // (multiply write, two FFT passes read+write, |.|^2 read) = ~55 B per CAF cell.  Here the product
-// never leaves the CU: X (the block spectrum) lives in registers for the whole hypothesis loop, the
-// template spectrum row is prefetched from L2 one hypothesis ahead, the 16384-point transform runs
+// never leaves the CU: the block spectrum X and the template-spectrum row are read from L2 (XCD-aware
+// block mapping keeps X in ONE L2) and multiplied one hypothesis ahead, the 16384-point transform runs
 // in the 160 KB LDS of a CDNA4 CU, and only |y|^2 (4 B per cell, coalesced 256-B rows) goes to HBM.
 // A second kernel (k_transpose_norm_argmax) turns the hypothesis-major |y|^2 tiles into the
 // delay-major QF^2 surface + per-delay argmax + peak.  Replaces the same reference stages as
@@ -20,7 +20,8 @@
 // Passes 2 and 3 read and write the same LDS addresses per butterfly (in place), so only one
 // barrier per pass is needed.  LDS image: element (n1, row, col) at n1*1090 + row*68 + col
 // (complex64); the 68/1090 pitches keep the strided reads of passes 3 and 4 off the same banks.
-// 512 threads (2 waves per SIMD, 256-VGPR budget), two butterflies per thread and pass.
+// Default: 1024 threads (4 waves per SIMD, 116 VGPRs), one butterfly per thread and pass; the
+// 512-thread / two-butterfly variant is kept as an A/B switch (measured 20 % slower).
 #include <cstdlib>
 
 #include "caf_internal.h"
@@ -211,37 +212,51 @@ __global__ __launch_bounds__(FT) void k_fused_caf(const float2* __restrict__ xb,
             }
         }
         // ---- pass 2: DFT16 over b, in place (n1 = idx >> 6, col = idx & 63) ----
+        // all of a thread's butterflies are read first, so the LDS reads of butterfly j+1 fly under the
+        // arithmetic of butterfly j (they touch disjoint addresses)
+        {
+            float2 v[BPT][16];
 #pragma unroll
-        for (int j = 0; j < BPT; ++j) {
-            const int idx = tid + j * FT;
-            const int base = (idx >> 6) * F_N1 + (idx & 63);
-            float2 v[16];
+            for (int j = 0; j < BPT; ++j) {
+                const int idx = tid + j * FT;
+                const int base = (idx >> 6) * F_N1 + (idx & 63);
 #pragma unroll
-            for (int b = 0; b < 16; ++b) v[b] = s_d[base + b * F_ROW];
-            idft16(v);
+                for (int b = 0; b < 16; ++b) v[j][b] = s_d[base + b * F_ROW];
+            }
 #pragma unroll
-            for (int n2 = 1; n2 < 16; ++n2) v[n2] = cmul(v[n2], s_tw2[n2 * 64 + (idx & 63) + lz]);
+            for (int j = 0; j < BPT; ++j) {
+                const int idx = tid + j * FT;
+                const int base = (idx >> 6) * F_N1 + (idx & 63);
+                idft16(v[j]);
 #pragma unroll
-            for (int n2 = 0; n2 < 16; ++n2) s_d[base + n2 * F_ROW] = v[n2];
-            __builtin_amdgcn_sched_barrier(0);
+                for (int n2 = 1; n2 < 16; ++n2) v[j][n2] = cmul(v[j][n2], s_tw2[n2 * 64 + (idx & 63) + lz]);
+#pragma unroll
+                for (int n2 = 0; n2 < 16; ++n2) s_d[base + n2 * F_ROW] = v[j][n2];
+            }
         }
         // No workgroup barrier here: plane n1 = idx >> 6 is written in pass 2 and read in pass 3 by the SAME
         // wave (wave w owns planes w, w + FT/64, ...), and a wave's LDS operations complete in order.
         __builtin_amdgcn_wave_barrier();
         // ---- pass 3: DFT16 over c, in place (n1 = idx >> 6, n2 = (idx >> 2) & 15, d = idx & 3) ----
+        {
+            float2 v[BPT][16];
 #pragma unroll
-        for (int j = 0; j < BPT; ++j) {
-            const int idx = tid + j * FT;
-            const int base = (idx >> 6) * F_N1 + ((idx >> 2) & 15) * F_ROW + (idx & 3);
-            float2 v[16];
+            for (int j = 0; j < BPT; ++j) {
+                const int idx = tid + j * FT;
+                const int base = (idx >> 6) * F_N1 + ((idx >> 2) & 15) * F_ROW + (idx & 3);
 #pragma unroll
-            for (int c = 0; c < 16; ++c) v[c] = s_d[base + 4 * c];
-            idft16(v);
+                for (int c = 0; c < 16; ++c) v[j][c] = s_d[base + 4 * c];
+            }
 #pragma unroll
-            for (int n3 = 1; n3 < 16; ++n3) v[n3] = cmul(v[n3], s_tw3[n3 * 4 + (idx & 3) + lz]);
+            for (int j = 0; j < BPT; ++j) {
+                const int idx = tid + j * FT;
+                const int base = (idx >> 6) * F_N1 + ((idx >> 2) & 15) * F_ROW + (idx & 3);
+                idft16(v[j]);
 #pragma unroll
-            for (int n3 = 0; n3 < 16; ++n3) s_d[base + 4 * n3] = v[n3];
-            __builtin_amdgcn_sched_barrier(0);
+                for (int n3 = 1; n3 < 16; ++n3) v[j][n3] = cmul(v[j][n3], s_tw3[n3 * 4 + (idx & 3) + lz]);
+#pragma unroll
+                for (int n3 = 0; n3 < 16; ++n3) s_d[base + 4 * n3] = v[j][n3];
+            }
         }
         __syncthreads();
         // ---- pass 4: DFT4 over d ; |y|^2 -> vt tiles (lanes <-> consecutive delays) ----
