@@ -227,6 +227,10 @@ CAF_EXPORT int32_t caf_upfirdn(const float* d_x, int64_t rows, int64_t n, const 
 CAF_EXPORT int32_t caf_czt_run_many(const float* d_x, int64_t rows, int32_t m, int32_t k, int32_t nfft,
                                     const float* d_aa, const float* d_fv, const float* d_ww, float* d_out,
                                     void* stream);
+/* multiArgmax3d_uint32 (argmax.cu:11-81, cupyExtensions.py:225-265): per item of a (items, d1, d2, d3) uint32
+ * array, the three indices of its maximum (first flat index on ties) -> d_argmax[items][3], d_max[items] */
+CAF_EXPORT int32_t caf_argmax3d_u32(const uint32_t* d_x, int64_t num_items, int32_t dim1, int32_t dim2, int32_t dim3,
+                                    uint32_t* d_argmax, uint32_t* d_max, void* stream);
 /* IQ ingest: interleaved int16 I/Q -> complex64 * scale on the device, i.e. the
  * np.fromfile(int16).astype(float32).view(complex64) of usrpRoutines.simpleBinRead (usrpRoutines.py:51-67)
  * done after the (half-size) H2D copy as in benchmarks/benchmark_cupyCopyAndConvert.py:17-25 */

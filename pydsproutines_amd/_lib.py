@@ -117,6 +117,7 @@ _SIGNATURES = {
     "caf_fir_lfilter": [_P, _I64, _P, _I32, _P, _I32, _I32, _I32, _P, _I64, _P],
     "caf_upfirdn": [_P, _I64, _I64, _P, _I32, _I32, _I32, _P, _P, _I64, _P],
     "caf_czt_run_many": [_P, _I64, _I32, _I32, _I32, _P, _P, _P, _P, _P],
+    "caf_argmax3d_u32": [_P, _I64, _I32, _I32, _I32, _P, _P, _P],
     "caf_iq16_to_c64": [_P, _I64, ct.c_float, _P, _P],
     "caf_colmax_abs": [_P, _I32, _I64, _P, _P, _P],
 }

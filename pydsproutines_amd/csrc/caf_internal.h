@@ -83,6 +83,8 @@ void launch_complex_norm(const float2* pbuf, int32_t pitch, int32_t nfreq, const
                          hipStream_t st);
 void launch_scale(float2* y, int64_t n, float scale, hipStream_t st);
 void launch_iq16_to_c64(const short* in, int64_t nsamp, float scale, float2* out, hipStream_t st);
+void launch_argmax3d_u32(const uint32_t* x, int64_t items, int32_t d1, int32_t d2, int32_t d3, uint32_t* argmax,
+                         uint32_t* maxv, hipStream_t st);
 
 // caf_fused.hip
 void launch_fused_caf(const float2* xb, const float2* hc, const int32_t* shifts, const float2* tw1,

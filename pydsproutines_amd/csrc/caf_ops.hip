@@ -331,6 +331,16 @@ int32_t caf_czt_run_many(const float* d_x, int64_t rows, int32_t m, int32_t k, i
     return CAF_OK;
 }
 
+int32_t caf_argmax3d_u32(const uint32_t* d_x, int64_t num_items, int32_t dim1, int32_t dim2, int32_t dim3,
+                         uint32_t* d_argmax, uint32_t* d_max, void* stream) {
+    CAF_REQUIRE(d_x && d_argmax && num_items >= 0 && dim1 >= 1 && dim2 >= 1 && dim3 >= 1, "caf_argmax3d_u32: bad arguments");
+    CAF_REQUIRE((int64_t)dim1 * dim2 * dim3 < ((int64_t)1 << 32) && num_items < ((int64_t)1 << 31),
+                "caf_argmax3d_u32: item too large");
+    launch_argmax3d_u32(d_x, num_items, dim1, dim2, dim3, d_argmax, d_max, (hipStream_t)stream);
+    CAF_HIP_TRY(hipGetLastError());
+    return CAF_OK;
+}
+
 int32_t caf_iq16_to_c64(const int16_t* d_iq, int64_t num_samples, float scale, float* d_out, void* stream) {
     CAF_REQUIRE(d_iq && d_out && num_samples >= 0, "caf_iq16_to_c64: bad arguments");
     CAF_REQUIRE((reinterpret_cast<uintptr_t>(d_iq) & 7) == 0 && (reinterpret_cast<uintptr_t>(d_out) & 15) == 0,

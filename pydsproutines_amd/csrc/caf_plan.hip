@@ -298,7 +298,8 @@ static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
     if ((rc = p->alloc(&p->d_prefix, d->max_rx_len + 1))) return rc;
     if ((rc = p->alloc(&p->d_inv_e, d->max_rx_len))) return rc;
     // all rx block spectra are produced up front, fwd_chunk blocks per rocFFT launch
-    p->fwd_chunk = (int)std::min<int64_t>(32, p->max_blocks);
+    // (~32 MiB of spectra per forward launch: 256 blocks of 16384, 64 blocks of 65536, ...)
+    p->fwd_chunk = (int)std::min<int64_t>(std::max<int64_t>(1, ((int64_t)1 << 22) / B), p->max_blocks);
     if ((rc = p->alloc(&p->d_xb, (p->max_blocks + p->fwd_chunk) * B))) return rc;
     if (p->fused) {
         if ((rc = p->alloc(&p->d_vt, (int64_t)nb * p->tiles_per_blk * T * F * 64))) return rc;

@@ -105,6 +105,51 @@ __global__ __launch_bounds__(256) void k_rows_argmax(const float2* __restrict__ 
     }
 }
 
+// multiArgmax3d_uint32 (argmax.cu:11-81): per item, argmax over the last three dimensions of a
+// (items, d1, d2, d3) uint32 array -> the three indices (+ the maximum).  First flat index on ties;
+// an all-zero item reports (0, 0, 0) like the reference's zero-initialised workspace.
+__global__ __launch_bounds__(256) void k_argmax3d_u32(const uint32_t* __restrict__ x, int32_t d1, int32_t d2, int32_t d3,
+                                                      uint32_t* __restrict__ argmax, uint32_t* __restrict__ maxv) {
+    __shared__ uint32_t s_v[4];
+    __shared__ uint32_t s_i[4];
+    const int64_t n = (int64_t)d1 * d2 * d3;
+    const uint32_t* xi = x + (int64_t)blockIdx.x * n;
+    uint32_t bv = 0, bi = 0;
+    for (int64_t t = threadIdx.x; t < n; t += 256) {
+        const uint32_t v = xi[t];
+        if (v > bv) {
+            bv = v;
+            bi = (uint32_t)t;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t ov = __shfl_xor(bv, o, 64);
+        const uint32_t oi = __shfl_xor(bi, o, 64);
+        if (ov > bv || (ov == bv && oi < bi)) {
+            bv = ov;
+            bi = oi;
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_v[threadIdx.x >> 6] = bv;
+        s_i[threadIdx.x >> 6] = bi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (s_v[w] > bv || (s_v[w] == bv && s_i[w] < bi)) {
+                bv = s_v[w];
+                bi = s_i[w];
+            }
+        argmax[blockIdx.x * 3 + 0] = bi / (uint32_t)(d2 * d3);
+        argmax[blockIdx.x * 3 + 1] = (bi / (uint32_t)d3) % (uint32_t)d2;
+        argmax[blockIdx.x * 3 + 2] = bi % (uint32_t)d3;
+        if (maxv) maxv[blockIdx.x] = bv;
+    }
+}
+
 // |x|^2, elementwise.  IN: 0 complex64, 1 complex128.  OUT: 0 float32, 1 float64.
 template <typename TIn, typename TOut>
 __global__ __launch_bounds__(256) void k_magnsq(const TIn* __restrict__ x, int64_t n, TOut* __restrict__ out) {
@@ -650,6 +695,12 @@ void launch_complex_norm(const float2* pbuf, int32_t pitch, int32_t nfreq, const
                          hipStream_t st) {
     hipLaunchKernelGGL(k_complex_norm, dim3(cdiv(step, 256), nhyp, nblk), dim3(256), 0, st, pbuf, pitch, nfreq, tscale,
                        inv_e, num_shifts, step, blk0, nhyp, cqf);
+}
+
+void launch_argmax3d_u32(const uint32_t* x, int64_t items, int32_t d1, int32_t d2, int32_t d3, uint32_t* argmax,
+                         uint32_t* maxv, hipStream_t st) {
+    if (items > 0)
+        hipLaunchKernelGGL(k_argmax3d_u32, dim3((unsigned)items), dim3(256), 0, st, x, d1, d2, d3, argmax, maxv);
 }
 
 void launch_iq16_to_c64(const short* in, int64_t nsamp, float scale, float2* out, hipStream_t st) {

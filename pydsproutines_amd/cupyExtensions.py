@@ -93,6 +93,22 @@ def cupyCopyIncrementalEqualSlicesToMatrix_32fc(d_x, startIdx, increment, rowLen
 
 
 # ---- argmax / magnitude -------------------------------------------------------------------
+def cupyArgmax3d_uint32(d_x, THREADS_PER_BLOCK=128, alsoReturnMaxValue=False):
+    """ref: cupyExtensions.py:225-265, argmax.cu:11-81.  Argmax over the last 3 dims of a 4-D uint32 array."""
+    if d_x.dtype != np.uint32:
+        raise TypeError("d_x must be uint32.")
+    if d_x.ndim != 4:
+        raise ValueError("d_x must be 4-d. Argmax taken over the last 3 dimensions.")
+    numItems, dim1, dim2, dim3 = d_x.shape
+    d_argmax = empty((numItems, 3), np.uint32)
+    d_max = empty(numItems, np.uint32) if alsoReturnMaxValue else None
+    _lib.check(_lib.load().caf_argmax3d_u32(_p(d_x), numItems, dim1, dim2, dim3, _p(d_argmax), _p(d_max), None))
+    if alsoReturnMaxValue:
+        return d_argmax, d_max
+    return d_argmax
+
+
+
 def cupyArgmaxAbsRows_complex64(d_x, d_argmax=None, d_max=None, returnMaxValues=False, THREADS_PER_BLOCK=128,
                                 useNormSqInstead=False):
     """ref: cupyExtensions.py:268-319, argmax.cu:93-153.  Row-wise argmax of |x| (or |x|^2)."""

@@ -474,3 +474,26 @@ def test_czt_objects(golden):
     np.testing.assert_allclose(czt(gc["czt_x"], -30.0, 30.0, 0.25, fs), gc["czt_y"], atol=2e-3)
     with pytest.raises(TypeError):
         czg.run(gc["many_x"][0])
+
+
+def test_argmax3d_uint32():
+    """cupyArgmax3d_uint32 (cupyExtensions.py:225-265): argmax over the last 3 dims, integer-exact."""
+    from pydsproutines_amd import asarray
+    from pydsproutines_amd.cupyExtensions import cupyArgmax3d_uint32
+
+    rng = np.random.default_rng(61)
+    x = rng.integers(0, 2**31, (7, 5, 11, 13), dtype=np.uint32)
+    x[3] = 0  # all-zero item -> (0, 0, 0), max 0
+    x[5, 2, 4, 6] = x[5, 4, 10, 12] = np.uint32(2**32 - 1)  # tie -> first flat index
+    am, mx = cupyArgmax3d_uint32(asarray(x), alsoReturnMaxValue=True)
+    flat = x.reshape(7, -1)
+    want = np.stack(np.unravel_index(np.argmax(flat, axis=1), x.shape[1:]), axis=1).astype(np.uint32)
+    assert am.dtype == np.uint32 and am.shape == (7, 3)
+    np.testing.assert_array_equal(am.get(), want)
+    np.testing.assert_array_equal(mx.get(), flat.max(axis=1))
+    assert tuple(am.get()[5]) == (2, 4, 6) and tuple(am.get()[3]) == (0, 0, 0)
+    np.testing.assert_array_equal(cupyArgmax3d_uint32(asarray(x)).get(), want)
+    with pytest.raises(TypeError):
+        cupyArgmax3d_uint32(asarray(x.astype(np.int32)))
+    with pytest.raises(ValueError):
+        cupyArgmax3d_uint32(asarray(x[0]))
