@@ -156,7 +156,6 @@ __global__ __launch_bounds__(FT) void k_fused_caf(const float2* __restrict__ xb,
                             ld2(hrow_cur, (uint32_t)((1024 * a + tid + j * FT - sh_cur) & (FB - 1))));
 
     for (int h = h0; h < h1; ++h) {
-        __syncthreads();  // previous hypothesis' pass-4 reads are done (and the LDS tables are in place)
         const bool more = h + 1 < h1;
         // h*64 as an opaque scalar: otherwise loop-strength-reduction turns the 32 store addresses of pass 4
         // into 32 64-bit induction variables (64 VGPRs + 32 adds per hypothesis)
@@ -167,28 +166,33 @@ __global__ __launch_bounds__(FT) void k_fused_caf(const float2* __restrict__ xb,
         // ---- pass 1: P = X * Hc_h ; DFT16 over a ; twiddle w^n1 ; write A[n1][m2] ----
         // One butterfly at a time (32 live data registers).  pr is dead after this pass and is refilled
         // with the next hypothesis' products during pass 4, the low-pressure phase.
+        // The register-only part (DFT16 + twiddles) runs BEFORE the barrier that protects the LDS image, so it
+        // overlaps with slower waves still finishing pass 4 of the previous hypothesis.
+        float2 v1[BPT][16];
 #pragma unroll
         for (int j = 0; j < BPT; ++j) {
-            float2 v[16];
 #pragma unroll
-            for (int a = 0; a < 16; ++a) v[a] = pr[j][a];
-            idft16(v);
+            for (int a = 0; a < 16; ++a) v1[j][a] = pr[j][a];
+            idft16(v1[j]);
             float2 p = w[j];
             // opaque to the optimiser: otherwise the 15 powers (and the LDS twiddles below) are hoisted out
             // of the hypothesis loop as loop invariants and cost ~180 persistent registers
             asm volatile("" : "+v"(p.x), "+v"(p.y));
             const float2 wj = p;
-            v[1] = cmul(v[1], p);
+            v1[j][1] = cmul(v1[j][1], p);
 #pragma unroll
             for (int n1 = 2; n1 < 16; ++n1) {
                 p = cmul(p, wj);
-                v[n1] = cmul(v[n1], p);
+                v1[j][n1] = cmul(v1[j][n1], p);
             }
+        }
+        __syncthreads();  // previous hypothesis' pass-4 reads are done (and the LDS tables are in place)
+#pragma unroll
+        for (int j = 0; j < BPT; ++j) {
             const int m2 = tid + j * FT;
             const int off = (m2 >> 6) * F_ROW + (m2 & 63);
 #pragma unroll
-            for (int n1 = 0; n1 < 16; ++n1) s_d[n1 * F_N1 + off] = v[n1];
-            __builtin_amdgcn_sched_barrier(0);
+            for (int n1 = 0; n1 < 16; ++n1) s_d[n1 * F_N1 + off] = v1[j][n1];
         }
         __syncthreads();
         row_of(more ? h + 1 : h);  // unconditional refill (the last one is redundant): no select keeps pr alive
