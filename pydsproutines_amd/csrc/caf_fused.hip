@@ -3,8 +3,8 @@
 //
 // Why: with rocFFT in the middle, every hypothesis product makes four HBM passes
 // (multiply write, two FFT passes read+write, |.|^2 read) = ~55 B per CAF cell.  Here the product
-// never leaves the CU: the block spectrum X and the template-spectrum row are read from L2 (XCD-aware
-// block mapping keeps X in ONE L2) and multiplied one hypothesis ahead, the 16384-point transform runs
+// never leaves the CU: the block spectrum X stays in registers for the whole hypothesis loop, the
+// template-spectrum row is read from L2 and multiplied one hypothesis ahead, the 16384-point transform runs
 // in the 160 KB LDS of a CDNA4 CU, and only |y|^2 (4 B per cell, coalesced 256-B rows) goes to HBM.
 // A second kernel (k_transpose_norm_argmax) turns the hypothesis-major |y|^2 tiles into the
 // delay-major QF^2 surface + per-delay argmax + peak.  Replaces the same reference stages as
@@ -20,7 +20,7 @@
 // Passes 2 and 3 read and write the same LDS addresses per butterfly (in place), so only one
 // barrier per pass is needed.  LDS image: element (n1, row, col) at n1*1090 + row*68 + col
 // (complex64); the 68/1090 pitches keep the strided reads of passes 3 and 4 off the same banks.
-// Default: 1024 threads (4 waves per SIMD, 116 VGPRs), one butterfly per thread and pass; the
+// Default: 1024 threads (4 waves per SIMD, 102 VGPRs), one butterfly per thread and pass; the
 // 512-thread / two-butterfly variant is kept as an A/B switch (measured 20 % slower).
 #include <cstdlib>
 
@@ -93,7 +93,7 @@ __device__ __forceinline__ void idft16(float2 (&v)[16]) {
 // |y|^2 tiles: vt[blk_local][s_tile][h][64]  (s_tile = delay/64 inside the block)
 // FT threads per workgroup (512: 2 waves/SIMD, 256-VGPR budget; 1024: 4 waves/SIMD, 128 VGPRs);
 // BPT = 1024 / FT radix-16 butterflies per thread and pass.
-template <int FT, bool STAGGER>
+template <int FT>
 __global__ __launch_bounds__(FT) void k_fused_caf(const float2* __restrict__ xb,       // [blocks][FB] spectra
                                                   const float2* __restrict__ hc,       // [T][FB] or [T*F][FB]
                                                   const int32_t* __restrict__ shifts,  // [F] (shift modes)
@@ -102,7 +102,6 @@ __global__ __launch_bounds__(FT) void k_fused_caf(const float2* __restrict__ xb,
                                                   int32_t table_mode, int32_t nfreq, int32_t nhyp, int32_t hyp_per_wg,
                                                   int32_t nblk, int32_t tiles_per_blk, float* __restrict__ vt) {
     constexpr int BPT = 1024 / FT;
-    const bool early = (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) != 0;  // wave-uniform
     __shared__ __attribute__((aligned(16))) float2 s_d[F_LDS_DATA];
     __shared__ float2 s_tw2[16 * 64];
     __shared__ float2 s_tw3[16 * 4];
@@ -143,16 +142,20 @@ __global__ __launch_bounds__(FT) void k_fused_caf(const float2* __restrict__ xb,
             hrow_cur = hc + (int64_t)t * FB;
         }
     };
-    // pr[j][a] = X[1024 a + m2] * Hc_h[1024 a + m2]: the input of pass 1, produced one hypothesis ahead.
-    // X is re-read from L2 with every row of Hc (keeping it in registers would cost 64 VGPRs for the
-    // whole loop); only the 64 product registers stay live across passes 1-4.
+    // pr[j][a] = X[1024 a + m2] * Hc_h[1024 a + m2]: the input of pass 1, produced one hypothesis ahead
+    // (during pass 4 of the previous one) from the persistent X registers and a freshly loaded Hc row.
     float2 pr[BPT][16];
+    float2 xr[BPT][16];  // block spectrum, persistent
+#pragma unroll
+    for (int j = 0; j < BPT; ++j)
+#pragma unroll
+        for (int a = 0; a < 16; ++a) xr[j][a] = ld2(xp, (uint32_t)(1024 * a + j * FT + tid));
     row_of(h0);
 #pragma unroll
     for (int j = 0; j < BPT; ++j)
 #pragma unroll
         for (int a = 0; a < 16; ++a)
-            pr[j][a] = cmul(ld2(xp, (uint32_t)(1024 * a + j * FT + tid)),
+            pr[j][a] = cmul(xr[j][a],
                             ld2(hrow_cur, (uint32_t)((1024 * a + tid + j * FT - sh_cur) & (FB - 1))));
 
     for (int h = h0; h < h1; ++h) {
@@ -196,25 +199,6 @@ __global__ __launch_bounds__(FT) void k_fused_caf(const float2* __restrict__ xb,
         }
         __syncthreads();
         row_of(more ? h + 1 : h);  // unconditional refill (the last one is redundant): no select keeps pr alive
-        // Stagger (MI355X_MICROARCH.md, 'Two waves per SIMD', item 9): all 16 waves run the same program between
-        // the same barriers, so their LDS bursts and their VALU bursts coincide.  The odd waves therefore refill
-        // pr (global loads + X*H products) HERE, the even waves during pass 4: the two halves go through the
-        // LDS-heavy and the VALU-heavy parts of passes 2-3 out of phase.
-        if (STAGGER && early) {
-#pragma unroll
-            for (int j = 0; j < BPT; ++j) {
-                float2 xn[16], hn[16];
-                int lzj = 0;
-                asm volatile("" : "+v"(lzj));
-#pragma unroll
-                for (int a = 0; a < 16; ++a) {
-                    xn[a] = ld2(xp, (uint32_t)(1024 * a + j * FT + tid + lzj));
-                    hn[a] = ld2(hrow_cur, (uint32_t)(((1024 * a + tid + j * FT - sh_cur) & (FB - 1)) + lzj));
-                }
-#pragma unroll
-                for (int a = 0; a < 16; ++a) pr[j][a] = cmul(xn[a], hn[a]);
-            }
-        }
         // ---- pass 2: DFT16 over b, in place (n1 = idx >> 6, col = idx & 63) ----
         // all of a thread's butterflies are read first, so the LDS reads of butterfly j+1 fly under the
         // arithmetic of butterfly j (they touch disjoint addresses)
@@ -241,6 +225,14 @@ __global__ __launch_bounds__(FT) void k_fused_caf(const float2* __restrict__ xb,
         // No workgroup barrier here: plane n1 = idx >> 6 is written in pass 2 and read in pass 3 by the SAME
         // wave (wave w owns planes w, w + FT/64, ...), and a wave's LDS operations complete in order.
         __builtin_amdgcn_wave_barrier();
+        // next hypothesis' template-spectrum row: issued before pass 3 so that the L2 latency is covered by
+        // the pass-3 butterfly and the pass-4 work
+        float2 hn[BPT][16];
+#pragma unroll
+        for (int j = 0; j < BPT; ++j)
+#pragma unroll
+            for (int a = 0; a < 16; ++a)
+                hn[j][a] = ld2(hrow_cur, (uint32_t)(((1024 * a + tid + j * FT - sh_cur) & (FB - 1)) + lz));
         // ---- pass 3: DFT16 over c, in place (n1 = idx >> 6, n2 = (idx >> 2) & 15, d = idx & 3) ----
         {
             float2 v[BPT][16];
@@ -269,17 +261,8 @@ __global__ __launch_bounds__(FT) void k_fused_caf(const float2* __restrict__ xb,
             const int idx = tid + j * FT;
             const int n1 = idx & 15, n2 = (idx >> 4) & 15, q = idx >> 8;
             const int base = n1 * F_N1 + n2 * F_ROW;
-            // next hypothesis' inputs for butterfly j: the loads fly while this butterfly's pass-4 work runs
-            float2 xn[16], hn[16];
-            int lzj = 0;  // opaque zero created HERE: keeps butterfly j's loads from being merged with j-1's
-            asm volatile("" : "+v"(lzj));
-            if (!(STAGGER && early)) {
-#pragma unroll
-                for (int a = 0; a < 16; ++a) {
-                    xn[a] = ld2(xp, (uint32_t)(1024 * a + j * FT + tid + lzj));
-                    hn[a] = ld2(hrow_cur, (uint32_t)(((1024 * a + tid + j * FT - sh_cur) & (FB - 1)) + lzj));
-                }
-            }
+            // next hypothesis' template-spectrum row for butterfly j: the loads fly while this butterfly's
+            // pass-4 work runs
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -306,10 +289,8 @@ __global__ __launch_bounds__(FT) void k_fused_caf(const float2* __restrict__ xb,
                 }
                 __builtin_amdgcn_sched_barrier(0);  // keep the four sub-steps from being co-scheduled (registers)
             }
-            if (!(STAGGER && early)) {
 #pragma unroll
-                for (int a = 0; a < 16; ++a) pr[j][a] = cmul(xn[a], hn[a]);
-            }
+            for (int a = 0; a < 16; ++a) pr[j][a] = cmul(xr[j][a], hn[j][a]);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -484,22 +465,12 @@ void launch_fused_caf(const float2* xb, const float2* hc, const int32_t* shifts,
         const char* e = getenv("CAF_FUSED_THREADS");
         return (e && atoi(e) == 512) ? 512 : 1024;
     }();
-    // CAF_FUSED_STAGGER=1 enables the odd/even wave stagger (A/B switch).  Measured on MI355X: 23.7 ms vs
-    // 13.6 ms without it -- keeping pr alive through passes 2-3 pushes the kernel from 115 to 128 VGPRs
-    // plus 45 dwords of scratch, which costs far more than the de-synchronisation gains.  Off by default.
-    static const int stagger = [] {
-        const char* e = getenv("CAF_FUSED_STAGGER");
-        return e ? atoi(e) : 0;
-    }();
     if (threads == 512)
-        hipLaunchKernelGGL((k_fused_caf<512, false>), grid, dim3(512), 0, st, xb, hc, shifts, tw1, tw23, table_mode,
-                           nfreq, nhyp, hyp_per_wg, nblk, tiles_per_blk, vt);
-    else if (stagger)
-        hipLaunchKernelGGL((k_fused_caf<1024, true>), grid, dim3(1024), 0, st, xb, hc, shifts, tw1, tw23, table_mode,
-                           nfreq, nhyp, hyp_per_wg, nblk, tiles_per_blk, vt);
+        hipLaunchKernelGGL(k_fused_caf<512>, grid, dim3(512), 0, st, xb, hc, shifts, tw1, tw23, table_mode, nfreq,
+                           nhyp, hyp_per_wg, nblk, tiles_per_blk, vt);
     else
-        hipLaunchKernelGGL((k_fused_caf<1024, false>), grid, dim3(1024), 0, st, xb, hc, shifts, tw1, tw23, table_mode,
-                           nfreq, nhyp, hyp_per_wg, nblk, tiles_per_blk, vt);
+        hipLaunchKernelGGL(k_fused_caf<1024>, grid, dim3(1024), 0, st, xb, hc, shifts, tw1, tw23, table_mode, nfreq,
+                           nhyp, hyp_per_wg, nblk, tiles_per_blk, vt);
 }
 
 void launch_transpose_norm_argmax(const float* vt, int32_t ntmpl, int32_t nfreq, const float* tscale,
