@@ -83,7 +83,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log2-block", type=int, default=0)
     ap.add_argument("--blocks-per-batch", type=int, default=0)
-    ap.add_argument("--engine", default="auto", choices=["auto", "fused", "rocfft"])
+    ap.add_argument("--engine", default="auto", choices=["auto", "persistent", "fused", "rocfft"])
     ap.add_argument("--no-surface", action="store_true", help="peak-only mode (no CAF surface written)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -188,7 +188,8 @@ def main():
         msamples = world * S / (elapsed / args.steps) / 1e6
         B, step_len, nb = plan.block, plan.step, plan.blocks_per_batch
         # algorithmic bytes per launch: one launch processes nb rx blocks
-        fused = plan.engine_used == "fused"
+        persistent = plan.engine_used == "persistent"   # both fused stages as ONE work-queue launch
+        fused = plan.engine_used in ("fused", "persistent")
         nblk_total = -(-S // step_len)
         blocks_per_launch = nblk_total / max(1, -(-nblk_total // nb))  # average (the last batch may be short)
         cells = blocks_per_launch * step_len * F_BINS
@@ -203,6 +204,8 @@ def main():
         else:
             mul_bytes = blocks_per_launch * 8.0 * B * (F_BINS + 2)      # write F rows, read X and H0 once
             mag_bytes = cells * (8.0 + (4.0 if surface_on else 0.0)) + blocks_per_launch * step_len * (4.0 + 8.0)
+        if persistent:
+            mul_bytes, mag_bytes = mul_bytes + mag_bytes, 0.0   # one kernel does both stages
         st = {}
         for name, alg in (("spectral_conj_multiply", mul_bytes), ("magsq_norm_argmax", mag_bytes)):
             ms, n = stages[name]
@@ -210,7 +213,9 @@ def main():
             st[name] = {"avg_ms": avg, "launches": n, "alg_bytes_per_launch": alg,
                         "achieved_GBs": alg / (avg * 1e-3) / 1e9 if avg > 0 else 0.0}
         if fused:
-            st["spectral_conj_multiply"]["kernel"] = "k_fused_caf (multiply + LDS inverse FFT + |.|^2)"
+            st["spectral_conj_multiply"]["kernel"] = (
+                "k_caf_persistent (multiply + LDS inverse FFT + |.|^2 on most CUs, transpose + QF^2 + argmax on the others)"
+                if persistent else "k_fused_caf (multiply + LDS inverse FFT + |.|^2)")
             st["spectral_conj_multiply"]["alg_flops_per_launch"] = flops_per_launch
             st["spectral_conj_multiply"]["achieved_TFLOPs"] = (
                 flops_per_launch / (st["spectral_conj_multiply"]["avg_ms"] * 1e-3) / 1e12
@@ -265,15 +270,19 @@ def main():
                     "note": "f32 FFT butterflies on the vector ALUs (no MFMA instruction is used); the figure is "
                             "the standard 5*B*log2(B) FFT count + X*H products + |.|^2 against the 157.3 TF f32 peak",
                 }
-                if fused and dom == "spectral_conj_multiply" else
+                if fused and not persistent and dom == "spectral_conj_multiply" else
                 {
                     "kernel": st[dom].get("kernel", dom), "bound": "hbm", "achieved": st[dom]["achieved_GBs"],
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": st[dom]["achieved_GBs"] / HBM_PEAK_GBS,
                     "traffic": traffic, "avg_launch_ms": st[dom]["avg_ms"],
                     "alg_bytes_per_launch": st[dom]["alg_bytes_per_launch"],
+                    **({"also_TFLOPs": st[dom]["achieved_TFLOPs"], "also_frac_f32_peak": st[dom]["achieved_TFLOPs"] / 157.3,
+                        "note": "one launch overlaps the ALU/LDS-bound FFT role (priced in also_TFLOPs against the "
+                                "157.3 TF f32 vector peak) with the HBM-bound transpose role on different CUs"}
+                       if persistent else {}),
                 }
             ),
-            "roofline_hbm_kernel": {
+            "roofline_hbm_kernel": None if persistent else {
                 "kernel": st["magsq_norm_argmax"].get("kernel", "k_magsq_norm_argmax"), "bound": "hbm",
                 "achieved": st["magsq_norm_argmax"]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": st["magsq_norm_argmax"]["achieved_GBs"] / HBM_PEAK_GBS,

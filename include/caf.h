@@ -108,10 +108,14 @@ typedef struct caf_plan_desc {
  *   FUSED : one hand-written kernel does multiply + 16384-point inverse FFT in LDS + |.|^2, a second
  *           one transposes/normalises/argmaxes; needs template_len <= 8192, (bins mode) grid | 16384,
  *           and cannot produce d_cqf.
+ *   PERSISTENT: the two FUSED stages as ONE work-queue launch (one resident workgroup per CU): the
+ *           HBM-bound transpose runs on some CUs while the others compute FFTs.  Same conditions and
+ *           results as FUSED.
  *   AUTO  : FUSED when its conditions hold and log2_block is 0 or 14, else ROCFFT. */
 #define CAF_ENGINE_AUTO 0
 #define CAF_ENGINE_ROCFFT 1
 #define CAF_ENGINE_FUSED 2
+#define CAF_ENGINE_PERSISTENT 3
 
 CAF_EXPORT int32_t caf_plan_create(caf_plan* plan, const caf_plan_desc* desc);
 CAF_EXPORT int32_t caf_plan_destroy(caf_plan plan);
@@ -120,7 +124,7 @@ CAF_EXPORT int32_t caf_plan_destroy(caf_plan plan);
 CAF_EXPORT int32_t caf_plan_info(caf_plan plan, int32_t* block, int32_t* step, int32_t* blocks_per_batch,
                                  int64_t* workspace_bytes);
 
-/* Engine actually selected by the plan: CAF_ENGINE_ROCFFT or CAF_ENGINE_FUSED. */
+/* Engine actually selected by the plan: CAF_ENGINE_ROCFFT, CAF_ENGINE_FUSED or CAF_ENGINE_PERSISTENT. */
 CAF_EXPORT int32_t caf_plan_engine(caf_plan plan, int32_t* engine);
 
 /* Outputs of one execute (any pointer may be NULL = not wanted). */

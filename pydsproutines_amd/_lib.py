@@ -30,6 +30,14 @@ CAF_FREQ_NORM = 1
 CAF_ENGINE_AUTO = 0
 CAF_ENGINE_ROCFFT = 1
 CAF_ENGINE_FUSED = 2
+CAF_ENGINE_PERSISTENT = 3
+ENGINE_IDS = {
+    "auto": CAF_ENGINE_AUTO,
+    "rocfft": CAF_ENGINE_ROCFFT,
+    "fused": CAF_ENGINE_FUSED,
+    "persistent": CAF_ENGINE_PERSISTENT,
+}
+ENGINE_NAMES = {v: k for k, v in ENGINE_IDS.items() if k != "auto"}
 CAF_NUM_STAGES = 7
 STAGE_NAMES = (
     "energy_prefix",

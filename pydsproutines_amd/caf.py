@@ -92,9 +92,9 @@ class CAFPlan:
         d.max_rx_len = int(max_rx_len)
         d.log2_block, d.blocks_per_batch = int(log2_block), int(blocks_per_batch)
         try:
-            d.engine = {"auto": _lib.CAF_ENGINE_AUTO, "rocfft": _lib.CAF_ENGINE_ROCFFT, "fused": _lib.CAF_ENGINE_FUSED}[engine]
+            d.engine = _lib.ENGINE_IDS[engine]
         except KeyError:
-            raise ValueError("engine must be 'auto', 'rocfft' or 'fused'")
+            raise ValueError("engine must be one of %s" % sorted(_lib.ENGINE_IDS))
         self.engine = engine
         h = ct.c_void_p()
         _lib.check(lib.caf_plan_create(ct.byref(h), ct.byref(d)), "caf_plan_create")
@@ -105,7 +105,7 @@ class CAFPlan:
         self.block, self.step, self.blocks_per_batch, self.workspace_bytes = blk.value, step.value, nb.value, ws.value
         eng = ct.c_int32()
         _lib.check(lib.caf_plan_engine(h, ct.byref(eng)))
-        self.engine_used = "fused" if eng.value == _lib.CAF_ENGINE_FUSED else "rocfft"
+        self.engine_used = _lib.ENGINE_NAMES[eng.value]
 
     def close(self):
         h, self._h = getattr(self, "_h", None), None

@@ -39,10 +39,33 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
 __device__ __forceinline__ float2 mulj(float2 a) { return make_float2(-a.y, a.x); }  // * (+j)
-// uniform base + 32-bit BYTE offset: lets the compiler pick the scalar-base (saddr) addressing form instead
-// of building a 64-bit address per access
+// Global-memory accessors: uniform base + 32-bit BYTE offset lets the compiler pick the scalar-base (saddr)
+// addressing form instead of building a 64-bit address per access.  The explicit address-space-1 casts keep
+// the accesses global_* (not flat_*) even where the base pointer was rebuilt from scalar halves
+// (uniform_ptr below), whose provenance the address-space inference cannot see.
+#define CAF_AS1 __attribute__((address_space(1)))
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+typedef float v4f_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float2 ld2(const float2* base, uint32_t elem) {
-    return *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(base) + (elem << 3));
+    const uint64_t u = *reinterpret_cast<const CAF_AS1 uint64_t*>((const CAF_AS1 char*)base + (elem << 3));
+    float2 r;
+    __builtin_memcpy(&r, &u, 8);
+    return r;
+}
+__device__ __forceinline__ float4 gld4(const float* base, uint32_t byteoff) {
+    const v4f_t v = *reinterpret_cast<const CAF_AS1 v4f_t*>((const CAF_AS1 char*)base + byteoff);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float gld1(const float* base, uint32_t byteoff) {
+    return *reinterpret_cast<const CAF_AS1 float*>((const CAF_AS1 char*)base + byteoff);
+}
+__device__ __forceinline__ void gst1(float* base, uint32_t byteoff, float v) {
+    *reinterpret_cast<CAF_AS1 float*>((CAF_AS1 char*)base + byteoff) = v;
+}
+// write-through store (sc1): visible device-wide once it has completed, without an L2 write-back fence
+__device__ __forceinline__ void gst1_wt(float* base, uint32_t byteoff, float v) {
+    __hip_atomic_store(reinterpret_cast<CAF_AS1 float*>((CAF_AS1 char*)base + byteoff), v, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // inverse 4-point DFT (kernel e^{+j 2 pi m n / 4}), in place
@@ -93,40 +116,28 @@ __device__ __forceinline__ void idft16(float2 (&v)[16]) {
 // |y|^2 tiles: vt[blk_local][s_tile][h][64]  (s_tile = delay/64 inside the block)
 // FT threads per workgroup (512: 2 waves/SIMD, 256-VGPR budget; 1024: 4 waves/SIMD, 128 VGPRs);
 // BPT = 1024 / FT radix-16 butterflies per thread and pass.
-template <int FT>
-__global__ __launch_bounds__(FT) void k_fused_caf(const float2* __restrict__ xb,       // [blocks][FB] spectra
-                                                  const float2* __restrict__ hc,       // [T][FB] or [T*F][FB]
-                                                  const int32_t* __restrict__ shifts,  // [F] (shift modes)
-                                                  const float2* __restrict__ tw1,      // [16][1024]
-                                                  const float2* __restrict__ tw23,     // [16][64] then [16][4]
-                                                  int32_t table_mode, int32_t nfreq, int32_t nhyp, int32_t hyp_per_wg,
-                                                  int32_t nblk, int32_t tiles_per_blk, float* __restrict__ vt) {
+//
+// fused_item: the whole hypothesis loop of one (rx block, hypothesis group [h0, h1)) work item, run by all FT
+// threads of a workgroup.  s_d / s_tw2 / s_tw3 are the caller's LDS arrays (the tables already loaded and
+// published by a barrier, or by the first barrier inside the loop).  Shared by the one-item-per-workgroup
+// kernel k_fused_caf and by the work-queue kernel k_caf_persistent.
+template <int FT, bool WT = false>
+__device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float2* __restrict__ s_tw2,
+                                           const float2* __restrict__ s_tw3,
+                                           const float2* __restrict__ xb,       // [blocks][FB] spectra
+                                           const float2* __restrict__ hc,       // [T][FB] or [T*F][FB]
+                                           const int32_t* __restrict__ shifts,  // [F] (shift modes)
+                                           const float2* __restrict__ tw1,      // [16][1024]
+                                           int32_t table_mode, int32_t nfreq, int32_t nhyp, int blk, int h0, int h1,
+                                           int32_t tiles_per_blk, float* __restrict__ vt) {
     constexpr int BPT = 1024 / FT;
-    __shared__ __attribute__((aligned(16))) float2 s_d[F_LDS_DATA];
-    __shared__ float2 s_tw2[16 * 64];
-    __shared__ float2 s_tw3[16 * 4];
     const int tid = threadIdx.x;
-    // XCD-aware mapping (speed only): workgroups are dealt round-robin over the 8 XCDs, so linear id L runs
-    // on XCD L % 8.  All hypothesis groups of one rx block are given to the SAME XCD (block b -> XCD b % 8,
-    // its groups on consecutive slots of that XCD), so the block spectrum X that every group re-reads per
-    // hypothesis is served by one 4 MiB L2 instead of being replicated (and thrashed) in several.
-    const int ngroups = (nhyp + hyp_per_wg - 1) / hyp_per_wg;
-    const int lin = blockIdx.x;
-    const int q = lin >> 3;
-    const int blk = (q / ngroups) * 8 + (lin & 7);
-    const int grp = q - (q / ngroups) * ngroups;
-    if (blk >= nblk) return;
-    const int h0 = grp * hyp_per_wg;
-    const int h1 = min(h0 + hyp_per_wg, nhyp);
-
-    for (int i = tid; i < 1024; i += FT) s_tw2[i] = tw23[i];
-    if (tid < 64) s_tw3[tid] = tw23[1024 + tid];
 
     // hypothesis-independent per-thread state: the pass-1 twiddle base e^{+j 2 pi m2 / 16384}
     float2 w[BPT];
     const float2* xp = xb + (int64_t)blk * FB;  // uniform base; per-thread offsets stay 32-bit (saddr loads)
 #pragma unroll
-    for (int j = 0; j < BPT; ++j) w[j] = tw1[1024 + tid + j * FT];
+    for (int j = 0; j < BPT; ++j) w[j] = ld2(tw1, (uint32_t)(1024 + tid + j * FT));
     float* vt_blk = vt + (int64_t)blk * tiles_per_blk * nhyp * 64;
 
     // row of the template-spectrum table used by hypothesis h (uniform) and its circular shift
@@ -138,7 +149,7 @@ __global__ __launch_bounds__(FT) void k_fused_caf(const float2* __restrict__ xb,
             sh_cur = 0;
         } else {
             const int t = h / nfreq;
-            sh_cur = shifts[h - t * nfreq];
+            sh_cur = *((const CAF_AS1 int32_t*)shifts + (h - t * nfreq));
             hrow_cur = hc + (int64_t)t * FB;
         }
     };
@@ -285,7 +296,10 @@ __global__ __launch_bounds__(FT) void k_fused_caf(const float2* __restrict__ xb,
                     float* pu = vt_blk + (int64_t)tile_u * nhyp * 64 + hoff;  // uniform (scalar) base
                     const uint32_t voff = ((uint32_t)tile_t * (uint32_t)nhyp * 64u + (uint32_t)(n1 + 16 * (n2 & 3))) << 2;
                     if (tile_u + tile_t < tiles_per_blk)
-                        *reinterpret_cast<float*>(reinterpret_cast<char*>(pu) + voff) = y[n4].x * y[n4].x + y[n4].y * y[n4].y;
+                        if (WT)
+                            gst1_wt(pu, voff, y[n4].x * y[n4].x + y[n4].y * y[n4].y);
+                        else
+                            gst1(pu, voff, y[n4].x * y[n4].x + y[n4].y * y[n4].y);
                 }
                 __builtin_amdgcn_sched_barrier(0);  // keep the four sub-steps from being co-scheduled (registers)
             }
@@ -294,6 +308,35 @@ __global__ __launch_bounds__(FT) void k_fused_caf(const float2* __restrict__ xb,
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+}
+
+// One workgroup per (rx block, group of hyp_per_wg hypotheses).
+template <int FT>
+__global__ __launch_bounds__(FT) void k_fused_caf(const float2* __restrict__ xb, const float2* __restrict__ hc,
+                                                  const int32_t* __restrict__ shifts, const float2* __restrict__ tw1,
+                                                  const float2* __restrict__ tw23,  // [16][64] then [16][4]
+                                                  int32_t table_mode, int32_t nfreq, int32_t nhyp, int32_t hyp_per_wg,
+                                                  int32_t nblk, int32_t tiles_per_blk, float* __restrict__ vt) {
+    __shared__ __attribute__((aligned(16))) float2 s_d[F_LDS_DATA];
+    __shared__ float2 s_tw2[16 * 64];
+    __shared__ float2 s_tw3[16 * 4];
+    const int tid = threadIdx.x;
+    // XCD-aware mapping (speed only): workgroups are dealt round-robin over the 8 XCDs, so linear id L runs
+    // on XCD L % 8.  All hypothesis groups of one rx block are given to the SAME XCD (block b -> XCD b % 8,
+    // its groups on consecutive slots of that XCD), so the block spectrum and the template-spectrum table
+    // they share are served by one 4 MiB L2 instead of being replicated in several.
+    const int ngroups = (nhyp + hyp_per_wg - 1) / hyp_per_wg;
+    const int lin = blockIdx.x;
+    const int q = lin >> 3;
+    const int blk = (q / ngroups) * 8 + (lin & 7);
+    const int grp = q - (q / ngroups) * ngroups;
+    if (blk >= nblk) return;
+    const int h0 = grp * hyp_per_wg;
+    const int h1 = min(h0 + hyp_per_wg, nhyp);
+
+    for (int i = tid; i < 1024; i += FT) s_tw2[i] = tw23[i];
+    if (tid < 64) s_tw3[tid] = tw23[1024 + tid];
+    fused_item<FT>(s_d, s_tw2, s_tw3, xb, hc, shifts, tw1, table_mode, nfreq, nhyp, blk, h0, h1, tiles_per_blk, vt);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -453,6 +496,451 @@ __global__ __launch_bounds__(256) void k_transpose_norm_argmax(
             }
         }
     }
+}
+
+template <typename Tp>
+__device__ __forceinline__ Tp* uniform_ptr(Tp* p) {
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return reinterpret_cast<Tp*>(((uint64_t)hi << 32) | lo);
+}
+
+// ----------------------------------------------------------------------------------------
+// Work-queue kernel: BOTH stages in one launch, overlapped across CUs.
+//
+// k_fused_caf is bound by the vector ALUs and the LDS (HBM ~1.6 TB/s), k_transpose_norm_argmax by HBM
+// (ALUs idle); run back to back they add up.  A k_fused_caf workgroup owns every VGPR and nearly all LDS
+// of its CU, so the two cannot share a CU as separate launches either.  Here one workgroup per CU stays
+// resident and pulls work items from two device-side queues:
+//   * FFT items  (rx block, hypothesis group)  -> fused_item();  each finished group is published with a
+//     release fence + done[block]++;
+//   * tile items (rx block, 16 delay tiles)    -> the LDS transpose of k_transpose_norm_argmax, four tiles at a
+//     time by four 256-thread sub-groups in lock-step; runs once done[block] == ngroups.
+// Workgroups in the last `tr_slots` of every 32 slots of an XCD look at the tile queue first, so about
+// tr_slots*8 CUs stream HBM while the others compute; a workgroup that finds the head of the tile queue not
+// ready takes an FFT item, and once the FFT queue is empty everybody drains the tile queue.
+// Both queues are claimed with one fetch-add (no compare-and-swap loops).
+// Termination: FFT items never wait.  A tile item waits for the FFT items of its block: those are either
+// running on resident workgroups (which finish) or still queued, and the queue is drained by the workgroups
+// that do not prefer tiles -- they take tiles only when no FFT item is left -- of which every resident prefix
+// of the grid has some (workgroups 0..7 are slot 0).  So every wait ends and every workgroup reaches the exit,
+// whatever number of workgroups is resident; a polling watchdog bounds the wait regardless.
+// The arguments live in device memory (PersistParams) and are read with scalar loads at the start of each
+// item, so that neither role's arguments take SGPRs away from the other (the hypothesis loop needs all 128
+// VGPRs and ~100 SGPRs; with 30 kernel arguments alive it spills).
+// ----------------------------------------------------------------------------------------
+constexpr int PQ_FFT_NEXT = 0, PQ_TR_NEXT = 1, PQ_DONE = 4;  // int32 slots of the queue block
+constexpr int PQ_QUADS = 4;  // a tile item = 4 quads = 16 delay tiles of one block (~2 MB of HBM traffic at F = 256)
+#define CAF_AS4 __attribute__((address_space(4)))
+
+__device__ __forceinline__ int32_t pq_load(const int32_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// the parameter block through the constant address space (scalar loads); the empty asm makes the pointer
+// opaque so that the loads are redone per item instead of being hoisted out of the work loop and kept alive
+__device__ __forceinline__ const CAF_AS4 PersistParams* params_of(const PersistParams* p) {
+    uint64_t v = reinterpret_cast<uint64_t>(p);
+    asm volatile("" : "+s"(v));
+    return reinterpret_cast<const CAF_AS4 PersistParams*>(v);
+}
+// raw buffer descriptor (gfx9 family: DATA_FORMAT = 32 in word 3) over [base, base + bytes)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_of(const void* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+// Cache policy of the |y|^2 tile reads: sc1 = device-scope coherent load.  The tiles were written during the SAME
+// launch by workgroups on other XCDs (each XCD has its own L2); the writers publish with a release fence (L2
+// write-back), the readers must not be served from a line their own L2 still holds from an earlier launch.
+constexpr int CAF_AUX_SC1 = 16;
+
+// Four 256-thread sub-groups transpose tiles 4*quad .. 4*quad+3 of local block z (all templates).  Same data
+// path as k_transpose_norm_argmax for full tiles (64 valid delays, nfreq a multiple of TR_F), written for
+// scalar addressing and few registers: wave-uniform ids come from v_readfirstlane, global accesses are buffer
+// instructions (descriptor + 32-bit lane offset + scalar offset), and the per-delay argmax is tracked where
+// the values are produced (4 delays per lane, hypotheses in increasing order) instead of in the row phase
+// (16 rows per lane).  Ragged tiles (the last tile of a block, a short final chunk) take a compact direct
+// path.  The barrier skeleton is common to both paths and every barrier is reached by all 1024 threads.
+template <int TR_F>
+__device__ __forceinline__ void transpose_quad(float* __restrict__ lds, const PersistParams* pp, int z, int quad) {
+    constexpr int TPITCH = TR_F + 1;
+    static_assert(TR_F >= 8, "the 512-float candidate area must fit the tile");
+    const CAF_AS4 PersistParams* P = params_of(pp);
+    const int32_t ntmpl = P->ntmpl, nfreq = P->nfreq, step = P->step, tiles_per_blk = P->tiles_per_blk;
+    const int64_t num_shifts = P->num_shifts, shift_start = P->shift_start;
+    // the thread id is made opaque here: otherwise every lane-derived constant of this role is hoisted out of the
+    // work loop of k_caf_persistent and stays alive (or is spilled and reloaded per hypothesis) in the FFT role
+    int tidx = threadIdx.x;
+    asm volatile("" : "+v"(tidx));
+    const int wave_id = __builtin_amdgcn_readfirstlane(tidx >> 6);
+    const int sub = wave_id >> 2, wv = wave_id & 3, lane = tidx & 63;
+    float* s_tile = lds + sub * (64 * TPITCH);
+    // per-wave argmax candidates [4 waves][64 delays], overlaid on the tile once its last chunk is consumed
+    float* s_pv = s_tile;
+    int32_t* s_pi = reinterpret_cast<int32_t*>(s_tile + 256);
+    const int tile = quad * 4 + sub;
+    const int blk = P->blk0 + z;
+    const int sl0 = tile * 64;
+    const int64_t rel0 = (int64_t)blk * step + sl0;
+    int64_t nv = num_shifts - (int64_t)blk * step;
+    if (nv > step) nv = step;
+    const bool in_range = tile < tiles_per_blk;
+    const bool valid = in_range && sl0 < nv;
+    const int nrows = valid ? (int)min((int64_t)64, nv - sl0) : 0;
+    const bool full = nrows == 64 && (nfreq % TR_F) == 0;
+    const int64_t pidx = (int64_t)blk * tiles_per_blk + tile;
+    const int s4 = 4 * (lane & 15), fq = lane >> 4;  // this lane's four delays / hypothesis within a group of 4
+    const uint32_t tile_bytes = (uint32_t)nfreq * 256u;  // one (tile, template): nfreq x 64 floats
+    for (int t = 0; t < ntmpl; ++t) {
+        // 64-bit products of uniform values are evaluated on the vector ALU (no scalar 64-bit multiply);
+        // v_readfirstlane brings the bases back into SGPRs
+        const float* vin = uniform_ptr(P->vt + (((int64_t)z * tiles_per_blk + tile) * ntmpl + t) * (int64_t)nfreq * 64);
+        float* surface = P->surface;
+        float* srow0 = uniform_ptr(surface ? surface + ((int64_t)t * num_shifts + rel0) * nfreq : nullptr);
+        const float* ie = uniform_ptr(P->inv_e + rel0);
+        const float ts = P->tscale[t];
+        const __amdgpu_buffer_rsrc_t rin = buf_of(vin, tile_bytes);
+        const __amdgpu_buffer_rsrc_t rout = buf_of(srow0, tile_bytes);  // 64 rows x nfreq floats
+        float g[4], bv[4];
+        int32_t bi[4];
+        v4f_t q[TR_F / 16];  // (whole-vector bit casts: __builtin_bit_cast of a single vector ELEMENT reads element 0)
+        // load mapping: float4 number (i*256 + lt) of the chunk -> hypothesis i*16 + 4*wv + fq, delays s4..s4+3
+        auto load_chunk = [&](int f0) {
+#pragma unroll
+            for (int i = 0; i < TR_F / 16; ++i)
+                q[i] = __builtin_bit_cast(v4f_t, __builtin_amdgcn_raw_buffer_load_b128(rin, (fq * 64 + s4) * 4,
+                                                                                       (f0 + 4 * wv + 16 * i) * 256,
+                                                                                       CAF_AUX_SC1));
+        };
+        if (full) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                g[k] = gld1(ie, (uint32_t)((s4 + k) << 2)) * ts;
+                bv[k] = -1.f;
+                bi[k] = 0;
+            }
+            load_chunk(0);
+        }
+        for (int f0 = 0; f0 < nfreq; f0 += TR_F) {
+            if (full) {
+#pragma unroll
+                for (int i = 0; i < TR_F / 16; ++i) {
+                    const int hyp = f0 + i * 16 + 4 * wv + fq;  // increasing with i and f0: first maximum wins
+                    const float x[4] = {q[i].x * g[0], q[i].y * g[1], q[i].z * g[2], q[i].w * g[3]};
+                    float* d = s_tile + s4 * TPITCH + (i * 16 + 4 * wv + fq);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (srow0) d[k * TPITCH] = x[k];
+                        if (x[k] > bv[k]) {
+                            bv[k] = x[k];
+                            bi[k] = hyp;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            if (full) {
+                if (f0 + TR_F < nfreq) load_chunk(f0 + TR_F);
+                if (srow0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = wv + 4 * r;  // uniform
+#pragma unroll
+                        for (int c = 0; c < TR_F / 64; ++c)
+                            __builtin_amdgcn_raw_buffer_store_b32(
+                                __builtin_bit_cast(int, s_tile[row * TPITCH + lane + 64 * c]), rout, lane * 4,
+                                (row * nfreq + f0 + 64 * c) * 4, 0);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        // candidates of this wave: plane wv of s_pv / s_pi
+        if (full) {
+            // lanes l, l^16, l^32, l^48 hold the same four delays: highest value, lowest hypothesis on ties
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                for (int o = 16; o <= 32; o <<= 1) {
+                    const float ov = __shfl_xor(bv[k], o, 64);
+                    const int32_t oi = __shfl_xor(bi[k], o, 64);
+                    if (ov > bv[k] || (ov == bv[k] && oi < bi[k])) {
+                        bv[k] = ov;
+                        bi[k] = oi;
+                    }
+                }
+            }
+            if (fq == 0) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    s_pv[wv * 64 + s4 + k] = bv[k];
+                    s_pi[wv * 64 + s4 + k] = bi[k];
+                }
+            }
+        } else {
+            // ragged tile: one wave per delay, straight from the |y|^2 tile (64-float stride), all hypotheses
+            s_pv[wv * 64 + lane] = -1.f;
+            s_pi[wv * 64 + lane] = 0;
+            for (int row = wv; row < nrows; row += 4) {
+                float b = -1.f;
+                int32_t bidx = 0;
+                const float gr = gld1(ie, (uint32_t)(row << 2)) * ts;
+                for (int f = lane; f < nfreq; f += 64) {
+                    const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, (f * 64 + row) << 2, 0, CAF_AUX_SC1)) * gr;
+                    if (srow0) gst1(srow0, (uint32_t)((row * nfreq + f) << 2), v);
+                    if (v > b) {
+                        b = v;
+                        bidx = f;
+                    }
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const float ov = __shfl_xor(b, o, 64);
+                    const int32_t oi = __shfl_xor(bidx, o, 64);
+                    if (ov > b || (ov == b && oi < bidx)) {
+                        b = ov;
+                        bidx = oi;
+                    }
+                }
+                if (lane == 0) {
+                    s_pv[wv * 64 + row] = b;
+                    s_pi[wv * 64 + row] = bidx;
+                }
+            }
+        }
+        __syncthreads();
+        if (wv == 0 && in_range) {
+            PeakRec* partial = P->partial;
+            const int64_t ppt = P->partial_per_tmpl;
+            if (!valid) {
+                if (lane == 0 && partial) {
+                    PeakRec r;
+                    r.v = -1.f;
+                    r.delay = 0x7fffffff;
+                    r.f = 0;
+                    partial[(int64_t)t * ppt + pidx] = r;
+                }
+            } else {
+                float* row_max = P->row_max;
+                int32_t* row_arg = P->row_arg;
+                // lane = delay: combine the four waves' candidates
+                float v = s_pv[lane];
+                int32_t vi = s_pi[lane];
+#pragma unroll
+                for (int w = 1; w < 4; ++w) {
+                    const float ov = s_pv[w * 64 + lane];
+                    const int32_t oi = s_pi[w * 64 + lane];
+                    if (ov > v || (ov == v && oi < vi)) {
+                        v = ov;
+                        vi = oi;
+                    }
+                }
+                if (lane < nrows) {
+                    const int64_t o = (int64_t)t * num_shifts + rel0 + lane;
+                    if (row_max) row_max[o] = v;
+                    if (row_arg) row_arg[o] = vi;
+                } else {
+                    v = -1.f;
+                }
+                if (partial) {
+                    float b = v;
+                    int32_t bidx = lane;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) {
+                        const float ov = __shfl_xor(b, o, 64);
+                        const int32_t oi = __shfl_xor(bidx, o, 64);
+                        if (ov > b || (ov == b && oi < bidx)) {
+                            b = ov;
+                            bidx = oi;
+                        }
+                    }
+                    const int32_t bf = __shfl(vi, bidx, 64);
+                    if (lane == 0) {
+                        PeakRec r;
+                        r.v = b;
+                        r.delay = (int32_t)(shift_start + rel0 + bidx);
+                        r.f = bf;
+                        partial[(int64_t)t * ppt + pidx] = r;
+                    }
+                }
+            }
+        }
+        __syncthreads();  // the candidate planes are overwritten by the next template's tile
+    }
+}
+
+__device__ __forceinline__ void pq_mark(const PersistParams* pp, int slot, int v) {
+    int32_t* d = params_of(pp)->dbg;
+    if (d) __hip_atomic_store(&d[blockIdx.x * 8 + slot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+template <int TR_F, bool STATS>
+__global__ __launch_bounds__(1024) void k_caf_persistent(const PersistParams* __restrict__ pp) {
+    static_assert(4 * 64 * (TR_F + 1) * 4 <= F_LDS_DATA * 8, "transposer tiles must fit the FFT image");
+    __shared__ __attribute__((aligned(16))) float2 s_d[F_LDS_DATA];
+    __shared__ float2 s_tw2[16 * 64];
+    __shared__ float2 s_tw3[16 * 4];
+    __shared__ int32_t s_cmd[2];
+    const int tid = threadIdx.x;
+    {
+        const CAF_AS4 PersistParams* P = params_of(pp);
+        const float2* tw23 = P->tw23;
+        s_tw2[tid] = tw23[tid];
+        if (tid < 64) s_tw3[tid] = tw23[1024 + tid];
+    }
+    __syncthreads();
+    // The claim runs on wave 0 as SCALAR control flow (uniform values, scalar branches); only the atomic
+    // read-modify-writes are predicated on lane 0.  A divergent `if (tid == 0)` around the claim loop lets the
+    // compiler restructure the work loop so that the other lanes of wave 0 run ahead to the barrier.
+    const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool lane0 = (tid & 63) == 0;
+    // per-workgroup role statistics for CAF_PERSIST_DEBUG (100 MHz wall clock; wave 0 only)
+    uint64_t tmark = STATS ? wall_clock64() : 0;
+    uint32_t t_claim = 0, t_fft = 0, t_tile = 0, c_fft = 0, c_tile = 0;
+    for (;;) {
+        if (wave_id == 0) {
+            const CAF_AS4 PersistParams* P = params_of(pp);
+            int32_t* pq = P->pq;
+            const int n_fft = P->n_fft, n_tr = P->n_tr, ipb = P->ipb, ngroups = P->ngroups;
+            // workgroups are dealt round-robin over the 8 XCDs: slot = index within the XCD.  The LAST tr_slots of
+            // every 32 slots prefer tiles, so any resident prefix of the grid contains workgroups that do not.
+            const bool prefer_tr = (int)((blockIdx.x >> 3) & 31) >= 32 - P->tr_slots;
+            int kind = 0, item = 0, spins = 0;
+            for (;;) {
+                const bool fft_left = __builtin_amdgcn_readfirstlane(pq_load(&pq[PQ_FFT_NEXT])) < n_fft;
+                if (prefer_tr || !fft_left) {
+                    const int t = __builtin_amdgcn_readfirstlane(pq_load(&pq[PQ_TR_NEXT]));
+                    if (t < n_tr) {
+                        // take a tile item when the head of the queue is ready -- or when there is nothing else
+                        // to do.  fetch-add, not compare-and-swap: with 256 claimers a CAS loop costs O(claimers)
+                        // failed atomics per item (measured: 8x slower end to end).  The item obtained may lie a few
+                        // blocks past the head; its block is waited for below.
+                        if (!fft_left || __builtin_amdgcn_readfirstlane(pq_load(&pq[PQ_DONE + t / ipb])) >= ngroups) {
+                            int my = 0;
+                            if (lane0) my = atomicAdd(&pq[PQ_TR_NEXT], 1);
+                            my = __builtin_amdgcn_readfirstlane(my);
+                            if (my < n_tr) {
+                                kind = 2;
+                                item = my;
+                                break;
+                            }
+                            continue;
+                        }
+                    } else if (!fft_left) {
+                        break;  // both queues fully claimed: exit
+                    }
+                }
+                if (fft_left) {
+                    int i = 0;
+                    if (lane0) i = atomicAdd(&pq[PQ_FFT_NEXT], 1);
+                    i = __builtin_amdgcn_readfirstlane(i);
+                    if (i < n_fft) {
+                        kind = 1;
+                        item = i;
+                        break;
+                    }
+                    continue;
+                }
+                __builtin_amdgcn_s_sleep(64);
+                if (++spins > (1 << 22)) break;  // cannot happen (see the wait below); kind 0 = leave
+            }
+            // a claimed tile item waits for its block.  The block's FFT items are either running on resident
+            // workgroups or still in the FFT queue, which the workgroups that do not prefer tiles keep draining
+            // (they never wait while FFT items are left, and workgroup 0 is always one of them).
+            // Watchdog (~10 s of polling): unreachable unless the protocol is broken; it makes the launch end with a
+            // mark in pq[2..3] (the tile is then transposed from unfinished data) instead of hanging the GPU.
+            if (kind == 2) {
+                spins = 0;
+                while (__builtin_amdgcn_readfirstlane(pq_load(&pq[PQ_DONE + item / ipb])) < ngroups) {
+                    __builtin_amdgcn_s_sleep(64);
+                    if (++spins > (1 << 22)) {
+                        if (lane0) {
+                            atomicExch(&pq[2], 1 + item);
+                            atomicExch(&pq[3], pq_load(&pq[PQ_FFT_NEXT]));
+                        }
+                        break;
+                    }
+                }
+            }
+            if (lane0) {
+                s_cmd[0] = kind;
+                s_cmd[1] = item;
+            }
+            if (STATS) {
+                const uint64_t now = wall_clock64();
+                t_claim += (uint32_t)(now - tmark);
+                tmark = now;
+            }
+        }
+        __syncthreads();
+        // uniform by construction; as scalars, everything derived from the item id stays in SGPRs
+        const int kind = __builtin_amdgcn_readfirstlane(s_cmd[0]), item = __builtin_amdgcn_readfirstlane(s_cmd[1]);
+        if (kind == 0) {
+            if (STATS && tid == 0) {
+                pq_mark(pp, 0, (int)t_claim);
+                pq_mark(pp, 1, (int)t_fft);
+                pq_mark(pp, 2, (int)t_tile);
+                pq_mark(pp, 3, (int)c_fft);
+                pq_mark(pp, 4, (int)c_tile);
+            }
+            break;
+        }
+        if (kind == 1) {
+            const CAF_AS4 PersistParams* P = params_of(pp);
+            const int ngroups = P->ngroups, hyp_per_wg = P->hyp_per_wg, nhyp = P->nhyp;
+            const int blk = item / ngroups;
+            const int grp = item - blk * ngroups;
+            const int h0 = grp * hyp_per_wg;
+            const int h1 = min(h0 + hyp_per_wg, nhyp);
+            // the |y|^2 tiles are stored write-through (sc1): device-visible once the store has completed
+            fused_item<1024, true>(s_d, s_tw2, s_tw3, P->xb, P->hc, P->shifts, P->tw1, P->table_mode, P->nfreq, nhyp, blk,
+                                   h0, h1, P->tiles_per_blk, P->vt);
+            // publish: every wave waits for its own stores (workgroup-scope release = s_waitcnt vmcnt(0); an
+            // agent-scope release would add an L2 write-back per item, which stalls the 32 CUs sharing that L2:
+            // measured +30 % on every FFT item), then one thread counts the group in
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __syncthreads();
+            if (tid == 0)
+                __hip_atomic_fetch_add(&params_of(pp)->pq[PQ_DONE + blk], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (STATS) {
+                const uint64_t now = wall_clock64();
+                t_fft += (uint32_t)(now - tmark);
+                tmark = now;
+                ++c_fft;
+            }
+        } else {
+            const int ipb = params_of(pp)->ipb;
+            const int z = item / ipb;
+            const int quad0 = (item - z * ipb) * PQ_QUADS;
+            const int nquads = (params_of(pp)->tiles_per_blk + 3) >> 2;
+            for (int qd = quad0; qd < min(quad0 + PQ_QUADS, nquads); ++qd)
+                transpose_quad<TR_F>(reinterpret_cast<float*>(s_d), pp, z, qd);
+            if (STATS) {
+                const uint64_t now = wall_clock64();
+                t_tile += (uint32_t)(now - tmark);
+                tmark = now;
+                ++c_tile;
+            }
+        }
+    }
+}
+
+// writes the parameter block (captured by value at launch time) and clears the queues
+__global__ void k_persist_setup(PersistParams h, PersistParams* d) {
+    int32_t* pq = h.pq;
+    const int n = PQ_DONE + h.nblk;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) pq[i] = 0;
+    if (threadIdx.x == 0) *d = h;
+}
+
+void launch_caf_persistent(const PersistParams* h, PersistParams* d_params, int32_t n_wgs, hipStream_t st) {
+    hipLaunchKernelGGL(k_persist_setup, dim3(1), dim3(256), 0, st, *h, d_params);
+    if (h->dbg)  // CAF_PERSIST_DEBUG: the variant that also keeps per-role clocks
+        hipLaunchKernelGGL((k_caf_persistent<128, true>), dim3((unsigned)n_wgs), dim3(1024), 0, st,
+                           (const PersistParams*)d_params);
+    else
+        hipLaunchKernelGGL((k_caf_persistent<128, false>), dim3((unsigned)n_wgs), dim3(1024), 0, st,
+                           (const PersistParams*)d_params);
 }
 
 void launch_fused_caf(const float2* xb, const float2* hc, const int32_t* shifts, const float2* tw1,

@@ -96,6 +96,35 @@ void launch_transpose_norm_argmax(const float* vt, int32_t ntmpl, int32_t nfreq,
                                   int32_t* row_arg, PeakRec* partial, int64_t partial_per_tmpl, hipStream_t st);
 void launch_colmax_abs(const float2* z, int32_t rows, int64_t n, float* maxv, int32_t* arg, hipStream_t st);
 
+// Arguments of the work-queue kernel k_caf_persistent, kept in device memory: each role reads the fields it
+// needs at the start of a work item (scalar loads), so the other role's arguments do not occupy SGPRs.
+struct PersistParams {
+    // FFT items (same meaning as launch_fused_caf)
+    const float2* xb;
+    const float2* hc;
+    const int32_t* shifts;
+    const float2* tw1;
+    const float2* tw23;
+    float* vt;
+    int32_t table_mode, nfreq, nhyp, hyp_per_wg, nblk, tiles_per_blk;
+    // tile items (same meaning as launch_transpose_norm_argmax)
+    int32_t ntmpl, step, blk0, pad0;
+    const float* tscale;
+    const float* inv_e;
+    int64_t num_shifts, shift_start;
+    float* surface;
+    float* row_max;
+    int32_t* row_arg;
+    PeakRec* partial;
+    int64_t partial_per_tmpl;
+    // queues: pq[0] next FFT item, pq[1] next tile item, pq[4 + b] finished hypothesis groups of block b
+    int32_t* pq;
+    int32_t tr_slots, ngroups, n_fft, ipb, n_tr, pad1;
+    int32_t* dbg;  // optional host-mapped progress marks (CAF_PERSIST_DEBUG), 4 ints per workgroup
+};
+// copies *h to d_params, clears the queue block and launches n_wgs resident workgroups
+void launch_caf_persistent(const PersistParams* h, PersistParams* d_params, int32_t n_wgs, hipStream_t st);
+
 // rocFFT wrapper shared by the plan and the ops (caf_fft.hip)
 struct FftPlan {
     void* plan = nullptr;  // rocfft_plan

@@ -7,6 +7,8 @@
 #include <mutex>
 #include <vector>
 
+#include <unistd.h>
+
 #include "caf_internal.h"
 
 namespace caf {
@@ -36,6 +38,10 @@ struct caf_plan_t {
     float2* d_pbuf = nullptr;
     PeakRec* d_partial = nullptr;
     bool fused = false;
+    bool persistent = false;  // fused stages as one work-queue launch (k_caf_persistent)
+    int n_cus = 0, tr_slots = 0;
+    PersistParams* d_params = nullptr;
+    int32_t* d_pq = nullptr;
     float* d_vt = nullptr;
     float2* d_tw1 = nullptr;
     float2* d_tw23 = nullptr;
@@ -101,8 +107,8 @@ struct caf_plan_t {
         pool.clear();
         fwd.destroy();
         inv.destroy();
-        void* ptrs[] = {d_hc,  d_shifts, d_tscale, d_gstart,  d_glen, d_tile_sums, d_prefix,
-                        d_inv_e, d_xb,   d_pbuf,   d_partial, d_vt,   d_tw1,       d_tw23};
+        void* ptrs[] = {d_hc,  d_shifts, d_tscale, d_gstart,  d_glen, d_tile_sums, d_prefix, d_inv_e,
+                        d_xb,  d_pbuf,   d_partial, d_vt,     d_tw1,  d_tw23,      d_params, d_pq};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
     }
@@ -222,12 +228,19 @@ static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
         CAF_REQUIRE(gs[g] >= 0 && gl[g] >= 1 && (int64_t)gs[g] + gl[g] <= N, "group outside the template span");
 
     // engine: the fused LDS-resident kernel works on 16384-point blocks
-    CAF_REQUIRE(d->engine >= CAF_ENGINE_AUTO && d->engine <= CAF_ENGINE_FUSED && d->reserved == 0, "bad engine field");
+    CAF_REQUIRE(d->engine >= CAF_ENGINE_AUTO && d->engine <= CAF_ENGINE_PERSISTENT && d->reserved == 0,
+                "bad engine field");
     const bool fused_ok = N <= 8192 && (d->freq_mode != CAF_FREQ_BINS || (d->grid >= 1 && 16384 % d->grid == 0)) &&
                           (d->log2_block == 0 || d->log2_block == 14);
-    CAF_REQUIRE(d->engine != CAF_ENGINE_FUSED || fused_ok,
-                "fused engine needs template_len <= 8192, grid | 16384 and log2_block 0 or 14");
-    p->fused = (d->engine == CAF_ENGINE_FUSED) || (d->engine == CAF_ENGINE_AUTO && fused_ok);
+    CAF_REQUIRE((d->engine != CAF_ENGINE_FUSED && d->engine != CAF_ENGINE_PERSISTENT) || fused_ok,
+                "fused engines need template_len <= 8192, grid | 16384 and log2_block 0 or 14");
+    p->fused = (d->engine == CAF_ENGINE_FUSED) || (d->engine == CAF_ENGINE_PERSISTENT) ||
+               (d->engine == CAF_ENGINE_AUTO && fused_ok);
+    // one launch for both stages: full tiles need a whole number of 128-hypothesis chunks per template
+    // (other F are correct through the ragged path, but slow: AUTO keeps the two-kernel form for them)
+    p->persistent = d->engine == CAF_ENGINE_PERSISTENT || (d->engine == CAF_ENGINE_AUTO && fused_ok && F % 128 == 0);
+    if (const char* e = getenv("CAF_PERSISTENT"))  // A/B switch for AUTO plans
+        if (d->engine == CAF_ENGINE_AUTO && fused_ok) p->persistent = atoi(e) != 0;
 
     // block size: B = 2^k, B >= 2N (>= 50 % valid outputs); default 16 N clipped to [2^12, 2^18]
     int lb = p->fused ? 14 : d->log2_block;
@@ -319,6 +332,17 @@ static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
             for (int dd = 0; dd < 4; ++dd) tw23[1024 + n3 * 4 + dd] = cis((double)n3 * dd, 64.0);
         CAF_HIP_TRY(hipMemcpy(p->d_tw1, tw1.data(), tw1.size() * 8, hipMemcpyHostToDevice));
         CAF_HIP_TRY(hipMemcpy(p->d_tw23, tw23.data(), tw23.size() * 8, hipMemcpyHostToDevice));
+        if (p->persistent) {
+            hipDeviceProp_t prop;
+            CAF_HIP_TRY(hipGetDeviceProperties(&prop, p->device));
+            p->n_cus = prop.multiProcessorCount;  // one resident 1024-thread workgroup per CU
+            p->tr_slots = 7;                      // ~56 CUs look at the tile queue first (measured optimum on C2)
+            if (const char* e = getenv("CAF_PERSIST_WGS")) p->n_cus = std::max(1, atoi(e));
+            if (const char* e = getenv("CAF_PERSIST_TR_SLOTS")) p->tr_slots = std::max(0, atoi(e));
+            p->tr_slots = std::min(p->tr_slots, 31);  // slot 0 of every XCD never prefers tiles (termination argument)
+            if ((rc = p->alloc(&p->d_params, 1))) return rc;
+            if ((rc = p->alloc(&p->d_pq, 4 + nb))) return rc;
+        }
     } else {
         if ((rc = p->alloc(&p->d_pbuf, (int64_t)nb * T * F * p->pitch))) return rc;
     }
@@ -416,7 +440,7 @@ int32_t caf_plan_info(caf_plan plan, int32_t* block, int32_t* step, int32_t* blo
 
 int32_t caf_plan_engine(caf_plan plan, int32_t* engine) {
     CAF_REQUIRE(plan && engine, "NULL argument");
-    *engine = plan->fused ? CAF_ENGINE_FUSED : CAF_ENGINE_ROCFFT;
+    *engine = plan->persistent ? CAF_ENGINE_PERSISTENT : plan->fused ? CAF_ENGINE_FUSED : CAF_ENGINE_ROCFFT;
     return CAF_OK;
 }
 
@@ -473,7 +497,88 @@ int32_t caf_plan_execute(caf_plan p, const float* d_rx, int64_t rx_len, int64_t 
     }
     if (p->fused) {
         CAF_REQUIRE(!out->d_cqf, "the fused engine has no complex-QF output (create the plan with CAF_ENGINE_ROCFFT)");
-        for (int64_t b0 = 0; b0 < nblk; b0 += p->nb) {
+        for (int64_t b0 = 0; p->persistent && b0 < nblk; b0 += p->nb) {
+            const int32_t nbk = (int32_t)std::min<int64_t>(p->nb, nblk - b0);
+            PersistParams h;
+            std::memset(&h, 0, sizeof(h));
+            h.xb = p->d_xb + b0 * (int64_t)p->B;
+            h.hc = p->d_hc;
+            h.shifts = p->d_shifts;
+            h.tw1 = p->d_tw1;
+            h.tw23 = p->d_tw23;
+            h.vt = p->d_vt;
+            h.table_mode = p->mul_mode == 2 ? 1 : 0;
+            h.nfreq = F;
+            h.nhyp = T * F;
+            h.hyp_per_wg = p->hyp_per_wg;
+            h.nblk = nbk;
+            h.tiles_per_blk = p->tiles_per_blk;
+            h.ntmpl = T;
+            h.step = p->step;
+            h.blk0 = (int32_t)b0;
+            h.tscale = p->d_tscale;
+            h.inv_e = p->d_inv_e;
+            h.num_shifts = num_shifts;
+            h.shift_start = shift_start;
+            h.surface = out->d_surface;
+            h.row_max = out->d_row_max;
+            h.row_arg = out->d_row_arg;
+            h.partial = want_peak ? p->d_partial : nullptr;
+            h.partial_per_tmpl = p->partial_per_tmpl;
+            h.pq = p->d_pq;
+            h.tr_slots = p->tr_slots;
+            h.ngroups = (T * F + p->hyp_per_wg - 1) / p->hyp_per_wg;
+            h.n_fft = nbk * h.ngroups;
+            h.ipb = (p->tiles_per_blk + 15) / 16;  // 16 tiles per item (PQ_QUADS quads, caf_fused.hip)
+            h.n_tr = nbk * h.ipb;
+            // both stages are one kernel: its time is booked on the multiply/FFT stage
+            int32_t* h_dbg = nullptr;
+            if (getenv("CAF_PERSIST_DEBUG")) {  // host-mapped role statistics, 8 ints per workgroup
+                (void)hipHostMalloc((void**)&h_dbg, sizeof(int32_t) * 8 * (size_t)p->n_cus, hipHostMallocMapped);
+                std::memset(h_dbg, 0, sizeof(int32_t) * 8 * (size_t)p->n_cus);
+                (void)hipHostGetDevicePointer((void**)&h.dbg, h_dbg, 0);
+            }
+            p->stage_begin(3, st);
+            launch_caf_persistent(&h, p->d_params, p->n_cus, st);
+            p->stage_end(st);
+            if (h_dbg) {
+                // wait (bounded) and report what the workgroups did: time per role in us (100 MHz device clock)
+                hipEvent_t ev;
+                (void)hipEventCreate(&ev);
+                (void)hipEventRecord(ev, st);
+                bool done = false;
+                for (int i = 0; i < 80 && !done; ++i) {
+                    done = hipEventQuery(ev) == hipSuccess;
+                    if (!done) usleep(100000);
+                }
+                if (!done) {
+                    fprintf(stderr, "[caf persistent] kernel still running after 8 s: aborting the process\n");
+                    _exit(3);
+                }
+                std::vector<int32_t> q(4 + nbk);
+                (void)hipMemcpy(q.data(), p->d_pq, q.size() * 4, hipMemcpyDeviceToHost);
+                double sum[2][5] = {{0}};
+                int cnt[2] = {0, 0};
+                for (int w = 0; w < p->n_cus; ++w) {
+                    const int pref = ((w >> 3) & 31) >= 32 - p->tr_slots;
+                    ++cnt[pref];
+                    for (int k = 0; k < 5; ++k) sum[pref][k] += h_dbg[8 * w + k];
+                }
+                fprintf(stderr, "[caf persistent] n_fft=%d n_tr=%d | fft_next=%d tr_next=%d watchdog=%d,%d\n", h.n_fft, h.n_tr,
+                        q[0], q[1], q[2], q[3]);
+                for (int r = 0; r < 2; ++r)
+                    if (cnt[r])
+                        fprintf(stderr,
+                                "  %s workgroups (%d): claim+wait %.0f us, fft %.0f us in %.1f items (%.1f us each), tiles %.0f us "
+                                "in %.1f items (%.1f us each)\n",
+                                r ? "tile-first" : "fft-first", cnt[r], sum[r][0] / cnt[r] / 100.0, sum[r][1] / cnt[r] / 100.0,
+                                sum[r][3] / cnt[r], sum[r][3] > 0 ? sum[r][1] / sum[r][3] / 100.0 : 0.0,
+                                sum[r][2] / cnt[r] / 100.0, sum[r][4] / cnt[r],
+                                sum[r][4] > 0 ? sum[r][2] / sum[r][4] / 100.0 : 0.0);
+                (void)hipHostFree(h_dbg);
+            }
+        }
+        for (int64_t b0 = 0; !p->persistent && b0 < nblk; b0 += p->nb) {
             const int32_t nbk = (int32_t)std::min<int64_t>(p->nb, nblk - b0);
             p->stage_begin(3, st);
             launch_fused_caf(p->d_xb + b0 * (int64_t)p->B, p->d_hc, p->d_shifts, p->d_tw1, p->d_tw23,

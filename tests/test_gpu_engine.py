@@ -180,16 +180,18 @@ def test_argument_validation():
         plan.run(np.ones(500, np.complex64))  # host array where a device array is required
 
 
-@pytest.mark.parametrize("engine", ["fused", "rocfft"])
+@pytest.mark.parametrize("engine", ["fused", "persistent", "rocfft"])
 def test_engines_agree_with_oracle(engine, golden):
-    """Both inverse-transform engines (hand-written LDS FFT kernel / rocFFT) against the oracle:
-    on-grid shift mode, explicit-frequency table mode with groups, multi-template, ragged tail."""
+    """All inverse-transform engines (hand-written LDS FFT kernel as two launches / as one work-queue
+    launch / rocFFT) against the oracle: on-grid shift mode, explicit-frequency table mode with groups,
+    multi-template, ragged tail."""
     from pydsproutines_amd import CAFPlan, asarray
 
     g = golden("c2_mini")
     t, rx, bins, sh = g["template"], g["rx"], g["bins"], g["shifts"]
     plan = CAFPlan(t, max_rx_len=rx.size, bins=bins, grid=t.size, engine=engine)
-    assert plan.block == (16384 if engine == "fused" else plan.block)
+    assert plan.engine_used == engine
+    assert plan.block == (16384 if engine != "rocfft" else plan.block)
     res = plan.run(asarray(rx), surface=True)
     surf = res.surface.get()[0]
     tol = _surface_check(surf[sh], g["caf"])
@@ -230,8 +232,33 @@ def test_engines_agree_with_oracle(engine, golden):
     ref3 = O.GroupXcorr(y, starts, lengths, freqs, fs).caf(rxg, shg)
     _surface_check(r3.surface.get()[0], ref3)
     assert int(r3.peak_delay.get()[0]) == 777 and freqs[int(r3.peak_freq.get()[0])] == 6.0
-    if engine == "fused":
+    if engine != "rocfft":
         with pytest.raises(ValueError):
             plan3.run(asarray(rxg), cqf=True)  # complex QF is a rocFFT-engine output
         with pytest.raises(ValueError):
-            CAFPlan(np.ones(9000, np.complex64), max_rx_len=40000, bins=[0], grid=16384, engine="fused")
+            CAFPlan(np.ones(9000, np.complex64), max_rx_len=40000, bins=[0], grid=16384, engine=engine)
+
+    # 2 templates x 128 bins (whole 128-hypothesis chunks: the full-tile path of the transposers), 3 blocks,
+    # run twice on different data through the same plan: the second result must not see the first one's tiles
+    F4 = 128
+    b4 = np.arange(-F4 // 2, F4 // 2)
+    tm4 = np.stack([qpsk(rng, n) for _ in range(2)])
+    plan4 = CAFPlan(tm4, max_rx_len=m, bins=b4, grid=n, engine=engine)
+    for trial, spots4 in enumerate([[(2000, -60), (30000, 63)], [(25000, 5), (123, -1)]]):
+        rx4 = cn(rng, m)
+        for i, (d0, k0) in enumerate(spots4):
+            rx4[d0 : d0 + n] += (2 * tm4[i] * np.exp(2j * np.pi * k0 * np.arange(n) / n)).astype(np.complex64)
+        r4 = plan4.run(asarray(rx4), surface=True)
+        rows4 = np.concatenate((np.arange(0, 300), np.arange(15700, 16200), np.arange(24900, 25100), np.arange(m - n + 1 - 200, m - n + 1)))
+        for i, (d0, k0) in enumerate(spots4):
+            ref = O.caf_bins(tm4[i], rx4, b4, rows4)
+            s_i = r4.surface.get()[i]
+            tol = _surface_check(s_i[rows4], ref)
+            _argmax_check(r4.row_arg.get()[i][rows4], r4.row_max.get()[i][rows4], ref, tol)
+            np.testing.assert_array_equal(r4.row_max.get()[i], s_i.max(axis=1))
+            np.testing.assert_array_equal(r4.row_arg.get()[i], np.argmax(s_i, axis=1))
+            assert (int(r4.peak_delay.get()[i]), int(b4[r4.peak_freq.get()[i]])) == (d0, k0)
+        # peak-only call (no surface, no rows) gives the same peaks
+        r5 = plan4.run(asarray(rx4), surface=False, rows=False, peak=True)
+        np.testing.assert_array_equal(r5.peak_delay.get(), r4.peak_delay.get())
+        np.testing.assert_array_equal(r5.peak_val.get(), r4.peak_val.get())
