@@ -295,11 +295,12 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
                     const int tile_t = (n2 >> 2) + 4 * q;                     // per-thread part
                     float* pu = vt_blk + (int64_t)tile_u * nhyp * 64 + hoff;  // uniform (scalar) base
                     const uint32_t voff = ((uint32_t)tile_t * (uint32_t)nhyp * 64u + (uint32_t)(n1 + 16 * (n2 & 3))) << 2;
-                    if (tile_u + tile_t < tiles_per_blk)
+                    if (tile_u + tile_t < tiles_per_blk) {
                         if (WT)
                             gst1_wt(pu, voff, y[n4].x * y[n4].x + y[n4].y * y[n4].y);
                         else
                             gst1(pu, voff, y[n4].x * y[n4].x + y[n4].y * y[n4].y);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);  // keep the four sub-steps from being co-scheduled (registers)
             }
@@ -554,218 +555,239 @@ typedef int v4i_t __attribute__((ext_vector_type(4)));
 // write-back), the readers must not be served from a line their own L2 still holds from an earlier launch.
 constexpr int CAF_AUX_SC1 = 16;
 
-// Four 256-thread sub-groups transpose tiles 4*quad .. 4*quad+3 of local block z (all templates).  Same data
-// path as k_transpose_norm_argmax for full tiles (64 valid delays, nfreq a multiple of TR_F), written for
-// scalar addressing and few registers: wave-uniform ids come from v_readfirstlane, global accesses are buffer
-// instructions (descriptor + 32-bit lane offset + scalar offset), and the per-delay argmax is tracked where
-// the values are produced (4 delays per lane, hypotheses in increasing order) instead of in the row phase
-// (16 rows per lane).  Ragged tiles (the last tile of a block, a short final chunk) take a compact direct
-// path.  The barrier skeleton is common to both paths and every barrier is reached by all 1024 threads.
-template <int TR_F>
-__device__ __forceinline__ void transpose_quad(float* __restrict__ lds, const PersistParams* pp, int z, int quad) {
-    constexpr int TPITCH = TR_F + 1;
-    static_assert(TR_F >= 8, "the 512-float candidate area must fit the tile");
+// Barrier-free tile role: every WAVE transposes its own (delay tile, template): 64 delays x nfreq hypotheses
+// in steps of 32 hypotheses through a private 64 x 33 float LDS patch.  No workgroup barrier, no cross-wave
+// traffic: the 16 waves of the workgroup run out of phase, so loads, LDS transposes and stores of different
+// waves overlap.  Two steps of loads are kept in flight per wave (16 KB).  Surface rows leave as 128-byte
+// segments, two rows per store instruction.  The per-delay argmax is tracked where the values are produced
+// (4 delays per lane, hypotheses in increasing order) and finished with wave shuffles.
+// Bounds: the tile, surface-row and energy buffers are raw buffer descriptors sized to the valid extent, so
+// out-of-range loads return 0 and out-of-range row stores are dropped by the hardware; ragged tiles (fewer
+// than 64 delays, nfreq not a multiple of 32) need no separate path.
+constexpr int TW_H = 32;              // hypotheses per step
+constexpr int TW_PITCH = TW_H + 1;    // LDS row pitch (floats): conflict-free transposed writes
+constexpr int TW_LDS = 64 * TW_PITCH;  // floats per wave
+
+template <bool SURF>
+__device__ __forceinline__ void transpose_wave(float* __restrict__ lds, const PersistParams* pp, int z, int tile0) {
     const CAF_AS4 PersistParams* P = params_of(pp);
     const int32_t ntmpl = P->ntmpl, nfreq = P->nfreq, step = P->step, tiles_per_blk = P->tiles_per_blk;
     const int64_t num_shifts = P->num_shifts, shift_start = P->shift_start;
-    // the thread id is made opaque here: otherwise every lane-derived constant of this role is hoisted out of the
-    // work loop of k_caf_persistent and stays alive (or is spilled and reloaded per hypothesis) in the FFT role
-    int tidx = threadIdx.x;
-    asm volatile("" : "+v"(tidx));
-    const int wave_id = __builtin_amdgcn_readfirstlane(tidx >> 6);
-    const int sub = wave_id >> 2, wv = wave_id & 3, lane = tidx & 63;
-    float* s_tile = lds + sub * (64 * TPITCH);
-    // per-wave argmax candidates [4 waves][64 delays], overlaid on the tile once its last chunk is consumed
-    float* s_pv = s_tile;
-    int32_t* s_pi = reinterpret_cast<int32_t*>(s_tile + 256);
-    const int tile = quad * 4 + sub;
+    const int wave_id = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    float* s_w = lds + wave_id * TW_LDS;
+    const int tile = tile0 + wave_id;
+    if (tile >= tiles_per_blk) return;  // (wave-uniform; no barriers in this role)
     const int blk = P->blk0 + z;
     const int sl0 = tile * 64;
     const int64_t rel0 = (int64_t)blk * step + sl0;
     int64_t nv = num_shifts - (int64_t)blk * step;
     if (nv > step) nv = step;
-    const bool in_range = tile < tiles_per_blk;
-    const bool valid = in_range && sl0 < nv;
-    const int nrows = valid ? (int)min((int64_t)64, nv - sl0) : 0;
-    const bool full = nrows == 64 && (nfreq % TR_F) == 0;
+    const int nrows = sl0 < nv ? (int)min((int64_t)64, nv - sl0) : 0;
     const int64_t pidx = (int64_t)blk * tiles_per_blk + tile;
+    PeakRec* partial = P->partial;
+    const int64_t ppt = P->partial_per_tmpl;
     const int s4 = 4 * (lane & 15), fq = lane >> 4;  // this lane's four delays / hypothesis within a group of 4
-    const uint32_t tile_bytes = (uint32_t)nfreq * 256u;  // one (tile, template): nfreq x 64 floats
+    const int nsteps = (nfreq + TW_H - 1) / TW_H;
+    // Waves of a workgroup that run identical code stay in phase (all wait for loads, then all compute, then all
+    // store).  Odd waves start half a step late, so that one half streams while the other half computes.
+    if (wave_id & 1)
+        for (int i = P->stagger; i > 0; --i) __builtin_amdgcn_s_sleep(16);
     for (int t = 0; t < ntmpl; ++t) {
+        if (nrows == 0) {
+            if (lane == 0 && partial) {
+                PeakRec r;
+                r.v = -1.f;
+                r.delay = 0x7fffffff;
+                r.f = 0;
+                partial[(int64_t)t * ppt + pidx] = r;
+            }
+            continue;
+        }
         // 64-bit products of uniform values are evaluated on the vector ALU (no scalar 64-bit multiply);
         // v_readfirstlane brings the bases back into SGPRs
         const float* vin = uniform_ptr(P->vt + (((int64_t)z * tiles_per_blk + tile) * ntmpl + t) * (int64_t)nfreq * 64);
-        float* surface = P->surface;
-        float* srow0 = uniform_ptr(surface ? surface + ((int64_t)t * num_shifts + rel0) * nfreq : nullptr);
-        const float* ie = uniform_ptr(P->inv_e + rel0);
+        float* srow0 = SURF ? uniform_ptr(P->surface + ((int64_t)t * num_shifts + rel0) * nfreq) : nullptr;
         const float ts = P->tscale[t];
-        const __amdgpu_buffer_rsrc_t rin = buf_of(vin, tile_bytes);
-        const __amdgpu_buffer_rsrc_t rout = buf_of(srow0, tile_bytes);  // 64 rows x nfreq floats
+        const __amdgpu_buffer_rsrc_t rin = buf_of(vin, (uint32_t)nfreq * 256u);
+        const __amdgpu_buffer_rsrc_t rout = buf_of(srow0, (uint32_t)(nrows * nfreq) * 4u);  // rows >= nrows: dropped
+        const __amdgpu_buffer_rsrc_t rie = buf_of(uniform_ptr(P->inv_e + rel0), (uint32_t)nrows * 4u);
         float g[4], bv[4];
         int32_t bi[4];
-        v4f_t q[TR_F / 16];  // (whole-vector bit casts: __builtin_bit_cast of a single vector ELEMENT reads element 0)
-        // load mapping: float4 number (i*256 + lt) of the chunk -> hypothesis i*16 + 4*wv + fq, delays s4..s4+3
-        auto load_chunk = [&](int f0) {
 #pragma unroll
-            for (int i = 0; i < TR_F / 16; ++i)
+        for (int k = 0; k < 4; ++k) {
+            g[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rie, (s4 + k) * 4, 0, 0)) * ts;
+            bv[k] = -1.f;
+            bi[k] = 0;
+        }
+        // load mapping of a step: float4 number (i*64 + lane) -> hypothesis 4*i + fq, delays s4 .. s4+3.
+        // Steps past the end are loaded too (the descriptor bounds make them zeros without memory traffic), so
+        // that the loop body is straight-line code and the outstanding-load bookkeeping stays exact.
+        v4f_t qa[TW_H / 4], qb[TW_H / 4];
+        auto load_step = [&](v4f_t(&q)[TW_H / 4], int s) {
+#pragma unroll
+            for (int i = 0; i < TW_H / 4; ++i)
                 q[i] = __builtin_bit_cast(v4f_t, __builtin_amdgcn_raw_buffer_load_b128(rin, (fq * 64 + s4) * 4,
-                                                                                       (f0 + 4 * wv + 16 * i) * 256,
-                                                                                       CAF_AUX_SC1));
+                                                                                       (s * TW_H + 4 * i) * 256, CAF_AUX_SC1));
         };
-        if (full) {
+        // lanes 0..31 -> row r, lanes 32..63 -> row r+1: one per-lane offset, the row in the scalar offset
+        const int half = lane >> 5, col = lane & 31;
+        const float* srd = s_w + half * TW_PITCH + col;
+        float* swr = s_w + s4 * TW_PITCH + fq;
+        const int voff = (half * nfreq + col) * 4;
+        auto do_step = [&](v4f_t(&q)[TW_H / 4], int s) {
+            const int f0 = s * TW_H;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                g[k] = gld1(ie, (uint32_t)((s4 + k) << 2)) * ts;
-                bv[k] = -1.f;
-                bi[k] = 0;
-            }
-            load_chunk(0);
-        }
-        for (int f0 = 0; f0 < nfreq; f0 += TR_F) {
-            if (full) {
-#pragma unroll
-                for (int i = 0; i < TR_F / 16; ++i) {
-                    const int hyp = f0 + i * 16 + 4 * wv + fq;  // increasing with i and f0: first maximum wins
-                    const float x[4] = {q[i].x * g[0], q[i].y * g[1], q[i].z * g[2], q[i].w * g[3]};
-                    float* d = s_tile + s4 * TPITCH + (i * 16 + 4 * wv + fq);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        if (srow0) d[k * TPITCH] = x[k];
-                        if (x[k] > bv[k]) {
-                            bv[k] = x[k];
-                            bi[k] = hyp;
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-            if (full) {
-                if (f0 + TR_F < nfreq) load_chunk(f0 + TR_F);
-                if (srow0) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = wv + 4 * r;  // uniform
-#pragma unroll
-                        for (int c = 0; c < TR_F / 64; ++c)
-                            __builtin_amdgcn_raw_buffer_store_b32(
-                                __builtin_bit_cast(int, s_tile[row * TPITCH + lane + 64 * c]), rout, lane * 4,
-                                (row * nfreq + f0 + 64 * c) * 4, 0);
-                    }
-                }
-            }
-            __syncthreads();
-        }
-        // candidates of this wave: plane wv of s_pv / s_pi
-        if (full) {
-            // lanes l, l^16, l^32, l^48 hold the same four delays: highest value, lowest hypothesis on ties
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-#pragma unroll
-                for (int o = 16; o <= 32; o <<= 1) {
-                    const float ov = __shfl_xor(bv[k], o, 64);
-                    const int32_t oi = __shfl_xor(bi[k], o, 64);
-                    if (ov > bv[k] || (ov == bv[k] && oi < bi[k])) {
-                        bv[k] = ov;
-                        bi[k] = oi;
-                    }
-                }
-            }
-            if (fq == 0) {
+            for (int i = 0; i < TW_H / 4; ++i) {
+                const int hyp = f0 + 4 * i + fq;  // increasing with i and s: first maximum wins
+                const bool hv = hyp < nfreq;
+                const float x[4] = {q[i].x * g[0], q[i].y * g[1], q[i].z * g[2], q[i].w * g[3]};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    s_pv[wv * 64 + s4 + k] = bv[k];
-                    s_pi[wv * 64 + s4 + k] = bi[k];
+                    if (SURF) swr[k * TW_PITCH + 4 * i] = x[k];
+                    const bool up = hv & (x[k] > bv[k]);  // selects, not branches: the step stays one basic block
+                    bv[k] = up ? x[k] : bv[k];
+                    bi[k] = up ? hyp : bi[k];
                 }
             }
-        } else {
-            // ragged tile: one wave per delay, straight from the |y|^2 tile (64-float stride), all hypotheses
-            s_pv[wv * 64 + lane] = -1.f;
-            s_pi[wv * 64 + lane] = 0;
-            for (int row = wv; row < nrows; row += 4) {
-                float b = -1.f;
-                int32_t bidx = 0;
-                const float gr = gld1(ie, (uint32_t)(row << 2)) * ts;
-                for (int f = lane; f < nfreq; f += 64) {
-                    const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, (f * 64 + row) << 2, 0, CAF_AUX_SC1)) * gr;
-                    if (srow0) gst1(srow0, (uint32_t)((row * nfreq + f) << 2), v);
-                    if (v > b) {
-                        b = v;
-                        bidx = f;
-                    }
-                }
+            load_step(q, s + 2);  // refill this register set: two steps stay in flight
+            if (SURF) {
+                __builtin_amdgcn_wave_barrier();  // LDS operations of a wave execute in order
+                // columns past nfreq (ragged last step): an offset beyond the descriptor, dropped by the bounds check
+                const int vo = (f0 + col < nfreq) ? voff : 0x7ffffff0;
 #pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    const float ov = __shfl_xor(b, o, 64);
-                    const int32_t oi = __shfl_xor(bidx, o, 64);
-                    if (ov > b || (ov == b && oi < bidx)) {
-                        b = ov;
-                        bidx = oi;
-                    }
-                }
-                if (lane == 0) {
-                    s_pv[wv * 64 + row] = b;
-                    s_pi[wv * 64 + row] = bidx;
+                for (int r = 0; r < 64; r += 2)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, srd[r * TW_PITCH]), rout, vo,
+                                                          (r * nfreq + f0) * 4, 0);
+                __builtin_amdgcn_wave_barrier();
+            }
+        };
+        load_step(qa, 0);
+        load_step(qb, 1);
+        for (int s = 0; s < nsteps; s += 2) {
+            do_step(qa, s);
+            do_step(qb, s + 1);
+        }
+        // lanes l, l^16, l^32, l^48 hold the same four delays: highest value, lowest hypothesis on ties
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int o = 16; o <= 32; o <<= 1) {
+                const float ov = __shfl_xor(bv[k], o, 64);
+                const int32_t oi = __shfl_xor(bi[k], o, 64);
+                if (ov > bv[k] || (ov == bv[k] && oi < bi[k])) {
+                    bv[k] = ov;
+                    bi[k] = oi;
                 }
             }
         }
-        __syncthreads();
-        if (wv == 0 && in_range) {
-            PeakRec* partial = P->partial;
-            const int64_t ppt = P->partial_per_tmpl;
-            if (!valid) {
-                if (lane == 0 && partial) {
-                    PeakRec r;
-                    r.v = -1.f;
-                    r.delay = 0x7fffffff;
-                    r.f = 0;
-                    partial[(int64_t)t * ppt + pidx] = r;
-                }
-            } else {
-                float* row_max = P->row_max;
-                int32_t* row_arg = P->row_arg;
-                // lane = delay: combine the four waves' candidates
-                float v = s_pv[lane];
-                int32_t vi = s_pi[lane];
+        // lanes 0..15 (fq == 0) now hold delays 4*lane .. 4*lane+3
+        float* row_max = P->row_max;
+        int32_t* row_arg = P->row_arg;
+        float best = -1.f;
+        int32_t bdel = 0x7fffffff, bfrq = 0;
+        if (fq == 0) {
+            const int64_t o = (int64_t)t * num_shifts + rel0 + s4;
 #pragma unroll
-                for (int w = 1; w < 4; ++w) {
-                    const float ov = s_pv[w * 64 + lane];
-                    const int32_t oi = s_pi[w * 64 + lane];
-                    if (ov > v || (ov == v && oi < vi)) {
-                        v = ov;
-                        vi = oi;
-                    }
-                }
-                if (lane < nrows) {
-                    const int64_t o = (int64_t)t * num_shifts + rel0 + lane;
-                    if (row_max) row_max[o] = v;
-                    if (row_arg) row_arg[o] = vi;
-                } else {
-                    v = -1.f;
-                }
-                if (partial) {
-                    float b = v;
-                    int32_t bidx = lane;
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) {
-                        const float ov = __shfl_xor(b, o, 64);
-                        const int32_t oi = __shfl_xor(bidx, o, 64);
-                        if (ov > b || (ov == b && oi < bidx)) {
-                            b = ov;
-                            bidx = oi;
-                        }
-                    }
-                    const int32_t bf = __shfl(vi, bidx, 64);
-                    if (lane == 0) {
-                        PeakRec r;
-                        r.v = b;
-                        r.delay = (int32_t)(shift_start + rel0 + bidx);
-                        r.f = bf;
-                        partial[(int64_t)t * ppt + pidx] = r;
+            for (int k = 0; k < 4; ++k) {
+                if (s4 + k < nrows) {
+                    if (row_max) row_max[o + k] = bv[k];
+                    if (row_arg) row_arg[o + k] = bi[k];
+                    if (bv[k] > best) {  // increasing delay: first maximum wins
+                        best = bv[k];
+                        bdel = s4 + k;
+                        bfrq = bi[k];
                     }
                 }
             }
         }
-        __syncthreads();  // the candidate planes are overwritten by the next template's tile
+        if (partial) {
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(best, o, 64);
+                const int32_t od = __shfl_xor(bdel, o, 64);
+                const int32_t of = __shfl_xor(bfrq, o, 64);
+                if (ov > best || (ov == best && od < bdel)) {
+                    best = ov;
+                    bdel = od;
+                    bfrq = of;
+                }
+            }
+            if (lane == 0) {
+                PeakRec r;
+                r.v = best;
+                r.delay = (int32_t)(shift_start + rel0 + bdel);
+                r.f = bfrq;
+                partial[(int64_t)t * ppt + pidx] = r;
+            }
+        }
+    }
+}
+
+// waits (bounded) until every hypothesis group of the block of tile item `item` is published
+__device__ __forceinline__ void pq_wait_block(int32_t* pq, int item, int ipb, int ngroups, bool lane0) {
+    // The block's FFT items are either running on resident workgroups or still in the FFT queue, which the
+    // workgroups that do not prefer tiles keep draining (they never wait while FFT items are left, and workgroup
+    // 0 is always one of them).  Watchdog (~10 s of polling): unreachable unless the protocol is broken; it makes
+    // the launch end with a mark in pq[2..3] (the tile is then transposed from unfinished data) instead of hanging.
+    int spins = 0;
+    while (__builtin_amdgcn_readfirstlane(pq_load(&pq[PQ_DONE + item / ipb])) < ngroups) {
+        __builtin_amdgcn_s_sleep(64);
+        if (++spins > (1 << 22)) {
+            if (lane0) {
+                atomicExch(&pq[2], 1 + item);
+                atomicExch(&pq[3], pq_load(&pq[PQ_FFT_NEXT]));
+            }
+            break;
+        }
+    }
+}
+
+// The tile role of k_caf_persistent, out of line for the same reason as the FFT role (its two register sets of
+// loads in flight need an allocation of their own).  Processes tile item `item_in`, then keeps taking tile items
+// as long as the head of the tile queue is ready (or no FFT item is left), so that the call overhead is paid per
+// run of items; returns when the workgroup should look at the FFT queue again.
+typedef __attribute__((address_space(3))) float lds_float;
+typedef __attribute__((address_space(3))) int32_t lds_int;
+__device__ __attribute__((noinline)) void persistent_tile_run(lds_float* lds_in, lds_int* s_next_in,
+                                                              const PersistParams* pp_in, int item_in) {
+    const PersistParams* pp = uniform_ptr(pp_in);
+    int item = __builtin_amdgcn_readfirstlane(item_in);
+    float* lds = (float*)lds_in;
+    int32_t* s_next = (int32_t*)s_next_in;
+    const int wave_id = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const bool lane0 = (threadIdx.x & 63) == 0;
+    for (;;) {
+        const CAF_AS4 PersistParams* P = params_of(pp);
+        const int ipb = P->ipb;
+        const int z = item / ipb;
+        if (P->surface)
+            transpose_wave<true>(lds, pp, z, (item - z * ipb) * 16);
+        else
+            transpose_wave<false>(lds, pp, z, (item - z * ipb) * 16);
+        if (wave_id == 0) {
+            int32_t* pq = P->pq;
+            const int n_fft = P->n_fft, n_tr = P->n_tr, ngroups = P->ngroups;
+            int next = -1;
+            const int t = __builtin_amdgcn_readfirstlane(pq_load(&pq[PQ_TR_NEXT]));
+            if (t < n_tr) {
+                const bool fft_left = __builtin_amdgcn_readfirstlane(pq_load(&pq[PQ_FFT_NEXT])) < n_fft;
+                if (!fft_left || __builtin_amdgcn_readfirstlane(pq_load(&pq[PQ_DONE + t / ipb])) >= ngroups) {
+                    int my = 0;
+                    if (lane0) my = atomicAdd(&pq[PQ_TR_NEXT], 1);
+                    my = __builtin_amdgcn_readfirstlane(my);
+                    if (my < n_tr) {
+                        pq_wait_block(pq, my, ipb, ngroups, lane0);
+                        next = my;
+                    }
+                }
+            }
+            if (lane0) *s_next = next;
+        }
+        __syncthreads();  // every wave has finished its tile; the next item id is published
+        item = __builtin_amdgcn_readfirstlane(*s_next);
+        __syncthreads();  // (s_next may be rewritten only after everybody has read it)
+        if (item < 0) return;
     }
 }
 
@@ -774,9 +796,37 @@ __device__ __forceinline__ void pq_mark(const PersistParams* pp, int slot, int v
     if (d) __hip_atomic_store(&d[blockIdx.x * 8 + slot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-template <int TR_F, bool STATS>
+// The FFT role of k_caf_persistent, called out of line so that the hypothesis loop keeps a register allocation
+// of its own (it needs all 128 VGPRs; allocated together with the queue logic and the tile role it reloads
+// spilled values every hypothesis).  Called ~21 times per workgroup: the call and the callee-saved register
+// traffic are negligible.  Arguments arrive in VGPRs; v_readfirstlane makes them scalar again.
+typedef __attribute__((address_space(3))) float2 lds_float2;
+__device__ __attribute__((noinline)) void persistent_fft_item(lds_float2* s_d, const lds_float2* s_tw2,
+                                                              const lds_float2* s_tw3, const PersistParams* pp_in,
+                                                              int item_in) {
+    const PersistParams* pp = uniform_ptr(pp_in);
+    const int item = __builtin_amdgcn_readfirstlane(item_in);
+    const CAF_AS4 PersistParams* P = params_of(pp);
+    const int ngroups = P->ngroups, hyp_per_wg = P->hyp_per_wg, nhyp = P->nhyp;
+    const int blk = item / ngroups;
+    const int grp = item - blk * ngroups;
+    const int h0 = grp * hyp_per_wg;
+    const int h1 = min(h0 + hyp_per_wg, nhyp);
+    // the |y|^2 tiles are stored write-through (sc1): device-visible once the store has completed
+    fused_item<1024, true>((float2*)s_d, (const float2*)s_tw2, (const float2*)s_tw3, P->xb, P->hc, P->shifts, P->tw1,
+                           P->table_mode, P->nfreq, nhyp, blk, h0, h1, P->tiles_per_blk, P->vt);
+    // publish: every wave waits for its own stores (workgroup-scope release = s_waitcnt vmcnt(0); an
+    // agent-scope release would add an L2 write-back per item, which stalls the 32 CUs sharing that L2:
+    // measured +30 % on every FFT item), then one thread counts the group in
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (threadIdx.x == 0)
+        __hip_atomic_fetch_add(&params_of(pp)->pq[PQ_DONE + blk], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <bool STATS>
 __global__ __launch_bounds__(1024) void k_caf_persistent(const PersistParams* __restrict__ pp) {
-    static_assert(4 * 64 * (TR_F + 1) * 4 <= F_LDS_DATA * 8, "transposer tiles must fit the FFT image");
+    static_assert(16 * TW_LDS * 4 <= F_LDS_DATA * 8, "transposer patches must fit the FFT image");
     __shared__ __attribute__((aligned(16))) float2 s_d[F_LDS_DATA];
     __shared__ float2 s_tw2[16 * 64];
     __shared__ float2 s_tw3[16 * 4];
@@ -844,24 +894,7 @@ __global__ __launch_bounds__(1024) void k_caf_persistent(const PersistParams* __
                 __builtin_amdgcn_s_sleep(64);
                 if (++spins > (1 << 22)) break;  // cannot happen (see the wait below); kind 0 = leave
             }
-            // a claimed tile item waits for its block.  The block's FFT items are either running on resident
-            // workgroups or still in the FFT queue, which the workgroups that do not prefer tiles keep draining
-            // (they never wait while FFT items are left, and workgroup 0 is always one of them).
-            // Watchdog (~10 s of polling): unreachable unless the protocol is broken; it makes the launch end with a
-            // mark in pq[2..3] (the tile is then transposed from unfinished data) instead of hanging the GPU.
-            if (kind == 2) {
-                spins = 0;
-                while (__builtin_amdgcn_readfirstlane(pq_load(&pq[PQ_DONE + item / ipb])) < ngroups) {
-                    __builtin_amdgcn_s_sleep(64);
-                    if (++spins > (1 << 22)) {
-                        if (lane0) {
-                            atomicExch(&pq[2], 1 + item);
-                            atomicExch(&pq[3], pq_load(&pq[PQ_FFT_NEXT]));
-                        }
-                        break;
-                    }
-                }
-            }
+            if (kind == 2) pq_wait_block(pq, item, ipb, ngroups, lane0);  // a claimed tile item waits for its block
             if (lane0) {
                 s_cmd[0] = kind;
                 s_cmd[1] = item;
@@ -886,22 +919,7 @@ __global__ __launch_bounds__(1024) void k_caf_persistent(const PersistParams* __
             break;
         }
         if (kind == 1) {
-            const CAF_AS4 PersistParams* P = params_of(pp);
-            const int ngroups = P->ngroups, hyp_per_wg = P->hyp_per_wg, nhyp = P->nhyp;
-            const int blk = item / ngroups;
-            const int grp = item - blk * ngroups;
-            const int h0 = grp * hyp_per_wg;
-            const int h1 = min(h0 + hyp_per_wg, nhyp);
-            // the |y|^2 tiles are stored write-through (sc1): device-visible once the store has completed
-            fused_item<1024, true>(s_d, s_tw2, s_tw3, P->xb, P->hc, P->shifts, P->tw1, P->table_mode, P->nfreq, nhyp, blk,
-                                   h0, h1, P->tiles_per_blk, P->vt);
-            // publish: every wave waits for its own stores (workgroup-scope release = s_waitcnt vmcnt(0); an
-            // agent-scope release would add an L2 write-back per item, which stalls the 32 CUs sharing that L2:
-            // measured +30 % on every FFT item), then one thread counts the group in
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __syncthreads();
-            if (tid == 0)
-                __hip_atomic_fetch_add(&params_of(pp)->pq[PQ_DONE + blk], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            persistent_fft_item((lds_float2*)s_d, (const lds_float2*)s_tw2, (const lds_float2*)s_tw3, pp, item);
             if (STATS) {
                 const uint64_t now = wall_clock64();
                 t_fft += (uint32_t)(now - tmark);
@@ -909,12 +927,7 @@ __global__ __launch_bounds__(1024) void k_caf_persistent(const PersistParams* __
                 ++c_fft;
             }
         } else {
-            const int ipb = params_of(pp)->ipb;
-            const int z = item / ipb;
-            const int quad0 = (item - z * ipb) * PQ_QUADS;
-            const int nquads = (params_of(pp)->tiles_per_blk + 3) >> 2;
-            for (int qd = quad0; qd < min(quad0 + PQ_QUADS, nquads); ++qd)
-                transpose_quad<TR_F>(reinterpret_cast<float*>(s_d), pp, z, qd);
+            persistent_tile_run((lds_float*)s_d, (lds_int*)&s_cmd[1], pp, item);
             if (STATS) {
                 const uint64_t now = wall_clock64();
                 t_tile += (uint32_t)(now - tmark);
@@ -935,12 +948,12 @@ __global__ void k_persist_setup(PersistParams h, PersistParams* d) {
 
 void launch_caf_persistent(const PersistParams* h, PersistParams* d_params, int32_t n_wgs, hipStream_t st) {
     hipLaunchKernelGGL(k_persist_setup, dim3(1), dim3(256), 0, st, *h, d_params);
+    const dim3 grid((unsigned)n_wgs), block(1024);
+    const PersistParams* dp = d_params;
     if (h->dbg)  // CAF_PERSIST_DEBUG: the variant that also keeps per-role clocks
-        hipLaunchKernelGGL((k_caf_persistent<128, true>), dim3((unsigned)n_wgs), dim3(1024), 0, st,
-                           (const PersistParams*)d_params);
+        hipLaunchKernelGGL((k_caf_persistent<true>), grid, block, 0, st, dp);
     else
-        hipLaunchKernelGGL((k_caf_persistent<128, false>), dim3((unsigned)n_wgs), dim3(1024), 0, st,
-                           (const PersistParams*)d_params);
+        hipLaunchKernelGGL((k_caf_persistent<false>), grid, block, 0, st, dp);
 }
 
 void launch_fused_caf(const float2* xb, const float2* hc, const int32_t* shifts, const float2* tw1,

@@ -336,7 +336,7 @@ static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
             hipDeviceProp_t prop;
             CAF_HIP_TRY(hipGetDeviceProperties(&prop, p->device));
             p->n_cus = prop.multiProcessorCount;  // one resident 1024-thread workgroup per CU
-            p->tr_slots = 7;                      // ~56 CUs look at the tile queue first (measured optimum on C2)
+            p->tr_slots = 12;                     // 96 CUs look at the tile queue first (measured optimum on C2: 10..14)
             if (const char* e = getenv("CAF_PERSIST_WGS")) p->n_cus = std::max(1, atoi(e));
             if (const char* e = getenv("CAF_PERSIST_TR_SLOTS")) p->tr_slots = std::max(0, atoi(e));
             p->tr_slots = std::min(p->tr_slots, 31);  // slot 0 of every XCD never prefers tiles (termination argument)
@@ -531,6 +531,8 @@ int32_t caf_plan_execute(caf_plan p, const float* d_rx, int64_t rx_len, int64_t 
             h.n_fft = nbk * h.ngroups;
             h.ipb = (p->tiles_per_blk + 15) / 16;  // 16 tiles per item (PQ_QUADS quads, caf_fused.hip)
             h.n_tr = nbk * h.ipb;
+            h.stagger = 0;
+            if (const char* e = getenv("CAF_PERSIST_STAGGER")) h.stagger = atoi(e);
             // both stages are one kernel: its time is booked on the multiply/FFT stage
             int32_t* h_dbg = nullptr;
             if (getenv("CAF_PERSIST_DEBUG")) {  // host-mapped role statistics, 8 ints per workgroup
