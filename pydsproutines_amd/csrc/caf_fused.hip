@@ -20,8 +20,10 @@
 // Passes 2 and 3 read and write the same LDS addresses per butterfly (in place), so only one
 // barrier per pass is needed.  LDS image: element (n1, row, col) at n1*1090 + row*68 + col
 // (complex64); the 68/1090 pitches keep the strided reads of passes 3 and 4 off the same banks.
-// Default: 1024 threads (4 waves per SIMD, 102 VGPRs), one butterfly per thread and pass; the
+// Default: 1024 threads (4 waves per SIMD, all 128 VGPRs, no spills), one butterfly per thread and pass; the
 // 512-thread / two-butterfly variant is kept as an A/B switch (measured 20 % slower).
+// The same hypothesis loop (fused_item) also runs inside k_caf_persistent (end of this file), which
+// overlaps it with the transpose stage on other CUs in a single work-queue launch.
 #include <cstdlib>
 
 #include "caf_internal.h"
@@ -514,25 +516,25 @@ __device__ __forceinline__ Tp* uniform_ptr(Tp* p) {
 // (ALUs idle); run back to back they add up.  A k_fused_caf workgroup owns every VGPR and nearly all LDS
 // of its CU, so the two cannot share a CU as separate launches either.  Here one workgroup per CU stays
 // resident and pulls work items from two device-side queues:
-//   * FFT items  (rx block, hypothesis group)  -> fused_item();  each finished group is published with a
-//     release fence + done[block]++;
-//   * tile items (rx block, 16 delay tiles)    -> the LDS transpose of k_transpose_norm_argmax, four tiles at a
-//     time by four 256-thread sub-groups in lock-step; runs once done[block] == ngroups.
+//   * FFT items  (rx block, hypothesis group)  -> fused_item() with write-through |y|^2 stores; each finished
+//     group is published with done[block]++;
+//   * tile items (rx block, 16 delay tiles)    -> one tile per wave through a wave-private LDS patch, no
+//     barrier (transpose_wave); runs once done[block] == ngroups.
 // Workgroups in the last `tr_slots` of every 32 slots of an XCD look at the tile queue first, so about
 // tr_slots*8 CUs stream HBM while the others compute; a workgroup that finds the head of the tile queue not
 // ready takes an FFT item, and once the FFT queue is empty everybody drains the tile queue.
-// Both queues are claimed with one fetch-add (no compare-and-swap loops).
+// Both queues are claimed with one fetch-add (no compare-and-swap loops), by wave 0 as scalar control flow.
 // Termination: FFT items never wait.  A tile item waits for the FFT items of its block: those are either
 // running on resident workgroups (which finish) or still queued, and the queue is drained by the workgroups
 // that do not prefer tiles -- they take tiles only when no FFT item is left -- of which every resident prefix
 // of the grid has some (workgroups 0..7 are slot 0).  So every wait ends and every workgroup reaches the exit,
 // whatever number of workgroups is resident; a polling watchdog bounds the wait regardless.
-// The arguments live in device memory (PersistParams) and are read with scalar loads at the start of each
-// item, so that neither role's arguments take SGPRs away from the other (the hypothesis loop needs all 128
-// VGPRs and ~100 SGPRs; with 30 kernel arguments alive it spills).
+// Registers: each role is a noinline function with a register allocation of its own (the hypothesis loop needs
+// all 128 VGPRs; allocated together with the other role it reloads spilled values every hypothesis), and the
+// arguments live in device memory (PersistParams), read with scalar loads at the start of each item.
 // ----------------------------------------------------------------------------------------
 constexpr int PQ_FFT_NEXT = 0, PQ_TR_NEXT = 1, PQ_DONE = 4;  // int32 slots of the queue block
-constexpr int PQ_QUADS = 4;  // a tile item = 4 quads = 16 delay tiles of one block (~2 MB of HBM traffic at F = 256)
+constexpr int PQ_TILES = 16;  // a tile item = 16 delay tiles of one block, one per wave (~2 MB of HBM traffic at F = 256)
 #define CAF_AS4 __attribute__((address_space(4)))
 
 __device__ __forceinline__ int32_t pq_load(const int32_t* p) {
@@ -549,17 +551,15 @@ __device__ __forceinline__ const CAF_AS4 PersistParams* params_of(const PersistP
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_of(const void* base, uint32_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
-typedef int v4i_t __attribute__((ext_vector_type(4)));
 // Cache policy of the |y|^2 tile reads: sc1 = device-scope coherent load.  The tiles were written during the SAME
-// launch by workgroups on other XCDs (each XCD has its own L2); the writers publish with a release fence (L2
-// write-back), the readers must not be served from a line their own L2 still holds from an earlier launch.
+// launch by workgroups on other XCDs (each XCD has its own L2) with write-through stores; the readers must not be
+// served from a line their own L2 may still hold.  (Measured: no cost against plain loads.)
 constexpr int CAF_AUX_SC1 = 16;
 
 // Barrier-free tile role: every WAVE transposes its own (delay tile, template): 64 delays x nfreq hypotheses
 // in steps of 32 hypotheses through a private 64 x 33 float LDS patch.  No workgroup barrier, no cross-wave
-// traffic: the 16 waves of the workgroup run out of phase, so loads, LDS transposes and stores of different
-// waves overlap.  Two steps of loads are kept in flight per wave (16 KB).  Surface rows leave as 128-byte
-// segments, two rows per store instruction.  The per-delay argmax is tracked where the values are produced
+// traffic.  Two register sets of loads (2 x 8 KB per wave) alternate; surface rows leave as 128-byte segments,
+// two rows per store instruction.  The per-delay argmax is tracked where the values are produced
 // (4 delays per lane, hypotheses in increasing order) and finished with wave shuffles.
 // Bounds: the tile, surface-row and energy buffers are raw buffer descriptors sized to the valid extent, so
 // out-of-range loads return 0 and out-of-range row stores are dropped by the hardware; ragged tiles (fewer
@@ -589,10 +589,6 @@ __device__ __forceinline__ void transpose_wave(float* __restrict__ lds, const Pe
     const int64_t ppt = P->partial_per_tmpl;
     const int s4 = 4 * (lane & 15), fq = lane >> 4;  // this lane's four delays / hypothesis within a group of 4
     const int nsteps = (nfreq + TW_H - 1) / TW_H;
-    // Waves of a workgroup that run identical code stay in phase (all wait for loads, then all compute, then all
-    // store).  Odd waves start half a step late, so that one half streams while the other half computes.
-    if (wave_id & 1)
-        for (int i = P->stagger; i > 0; --i) __builtin_amdgcn_s_sleep(16);
     for (int t = 0; t < ntmpl; ++t) {
         if (nrows == 0) {
             if (lane == 0 && partial) {
@@ -762,9 +758,9 @@ __device__ __attribute__((noinline)) void persistent_tile_run(lds_float* lds_in,
         const int ipb = P->ipb;
         const int z = item / ipb;
         if (P->surface)
-            transpose_wave<true>(lds, pp, z, (item - z * ipb) * 16);
+            transpose_wave<true>(lds, pp, z, (item - z * ipb) * PQ_TILES);
         else
-            transpose_wave<false>(lds, pp, z, (item - z * ipb) * 16);
+            transpose_wave<false>(lds, pp, z, (item - z * ipb) * PQ_TILES);
         if (wave_id == 0) {
             int32_t* pq = P->pq;
             const int n_fft = P->n_fft, n_tr = P->n_tr, ngroups = P->ngroups;

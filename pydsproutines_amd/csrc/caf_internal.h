@@ -119,8 +119,7 @@ struct PersistParams {
     int64_t partial_per_tmpl;
     // queues: pq[0] next FFT item, pq[1] next tile item, pq[4 + b] finished hypothesis groups of block b
     int32_t* pq;
-    int32_t tr_slots, ngroups, n_fft, ipb, n_tr;
-    int32_t stagger;  // start delay of the odd waves of the tile role, in units of 16 x 64 clocks
+    int32_t tr_slots, ngroups, n_fft, ipb, n_tr, pad1;
     int32_t* dbg;  // optional host-mapped progress marks (CAF_PERSIST_DEBUG), 4 ints per workgroup
 };
 // copies *h to d_params, clears the queue block and launches n_wgs resident workgroups

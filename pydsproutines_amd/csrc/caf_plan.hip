@@ -529,10 +529,8 @@ int32_t caf_plan_execute(caf_plan p, const float* d_rx, int64_t rx_len, int64_t 
             h.tr_slots = p->tr_slots;
             h.ngroups = (T * F + p->hyp_per_wg - 1) / p->hyp_per_wg;
             h.n_fft = nbk * h.ngroups;
-            h.ipb = (p->tiles_per_blk + 15) / 16;  // 16 tiles per item (PQ_QUADS quads, caf_fused.hip)
+            h.ipb = (p->tiles_per_blk + 15) / 16;  // 16 tiles per item (PQ_TILES, caf_fused.hip)
             h.n_tr = nbk * h.ipb;
-            h.stagger = 0;
-            if (const char* e = getenv("CAF_PERSIST_STAGGER")) h.stagger = atoi(e);
             // both stages are one kernel: its time is booked on the multiply/FFT stage
             int32_t* h_dbg = nullptr;
             if (getenv("CAF_PERSIST_DEBUG")) {  // host-mapped role statistics, 8 ints per workgroup
