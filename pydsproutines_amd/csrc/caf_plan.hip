@@ -575,6 +575,32 @@ int32_t caf_plan_execute(caf_plan p, const float* d_rx, int64_t rx_len, int64_t 
                                 sum[r][3] / cnt[r], sum[r][3] > 0 ? sum[r][1] / sum[r][3] / 100.0 : 0.0,
                                 sum[r][2] / cnt[r] / 100.0, sum[r][4] / cnt[r],
                                 sum[r][4] > 0 ? sum[r][2] / sum[r][4] / 100.0 : 0.0);
+                // CAF_PERSIST_TILE_ONLY="16,64,256": re-run only the tile role on k workgroups over the tiles just
+                // produced (per-CU streaming rate of the role at different levels of HBM concurrency)
+                if (const char* lst = getenv("CAF_PERSIST_TILE_ONLY")) {
+                    PersistParams h2 = h;
+                    h2.n_fft = 0;
+                    h2.ngroups = 0;  // every block counts as published
+                    h2.dbg = nullptr;
+                    hipEvent_t e0, e1;
+                    (void)hipEventCreate(&e0);
+                    (void)hipEventCreate(&e1);
+                    for (const char* c = lst; *c;) {
+                        const int k = atoi(c);
+                        while (*c && *c != ',') ++c;
+                        if (*c == ',') ++c;
+                        if (k < 1) continue;
+                        (void)hipEventRecord(e0, st);
+                        launch_caf_persistent(&h2, p->d_params, k, st);
+                        (void)hipEventRecord(e1, st);
+                        (void)hipEventSynchronize(e1);
+                        float ms = 0.f;
+                        (void)hipEventElapsedTime(&ms, e0, e1);
+                        const double bytes = (double)h2.n_tr * 16.0 * 64.0 * F * 4.0 * (out->d_surface ? 2.0 : 1.0);
+                        fprintf(stderr, "  tile role alone on %3d workgroups: %.2f ms, %.1f us per item, %.1f GB/s per CU, %.2f TB/s\n",
+                                k, ms, ms * 1e3 * k / h2.n_tr, bytes / (ms * 1e-3) / k / 1e9, bytes / (ms * 1e-3) / 1e12);
+                    }
+                }
                 (void)hipHostFree(h_dbg);
             }
         }
