@@ -242,6 +242,12 @@ CAF_EXPORT int32_t caf_iq16_to_c64(const int16_t* d_iq, int64_t num_samples, flo
 /* per column of a complex64 (rows, n) matrix: max_r |z| and the first row attaining it
  * (TemplateCrossCorrelator.correlate(returnMax=True), xcorrRoutines.py:361-371) */
 CAF_EXPORT int32_t caf_colmax_abs(const float* d_z, int32_t rows, int64_t n, float* d_max, int32_t* d_arg, void* stream);
+/* GroupXcorrCZT_Permutations.getCAF / getCAF_GPU (xcorrRoutines.py:1454-1484, 1549-1585): sum the selected
+ * per-template complex64 planes d_planes[num_planes][rows][cols] (h_sel: host array of num_sel <= 64 plane
+ * numbers), then d_out[rows][cols] (float64) = |sum|^2 / d_row_norm[row] (float64) / ynormsq */
+CAF_EXPORT int32_t caf_sum_planes_qf2(const float* d_planes, int32_t num_planes, int64_t rows, int32_t cols,
+                                      const int32_t* h_sel, int32_t num_sel, const double* d_row_norm, double ynormsq,
+                                      double* d_out, void* stream);
 
 #ifdef __cplusplus
 }

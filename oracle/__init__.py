@@ -26,6 +26,8 @@ from .xcorr import (  # noqa: F401
     GroupXcorr,
     GroupXcorrFFT,
     GroupXcorrCZT,
+    GroupXcorrCZT_Permutations,
+    GroupXcorrGPU,
     TemplateCrossCorrelator,
     IppXcorrFFT,
     IppGroupXcorrFFT,

@@ -307,6 +307,77 @@ class GroupXcorrCZT:
         return xc, cztFreq
 
 
+class GroupXcorrGPU(GroupXcorr):
+    """ref: xcorrRoutines.py:1897-2058 (defined under `import cupy` upstream: restated from the source
+    text).  ``xcorr`` is the parent's; ``xcorrKernel`` returns (QF^2 float32[S], frequency index int32[S])."""
+
+    def __init__(self, y, starts, lengths, freqs, fs):
+        super().__init__(y, starts, lengths, freqs, fs)
+
+    def xcorrKernel(self, rx, shifts, numShiftsPerBlk=2, verbTiming=False):
+        shifts = np.asarray(shifts)
+        assert shifts.size % numShiftsPerBlk == 0
+        caf = self.caf(rx, shifts)
+        idx = np.argmax(caf, axis=1)
+        return caf[np.arange(shifts.size), idx].astype(np.float32), idx.astype(np.int32)
+
+
+class GroupXcorrCZT_Permutations:
+    """ref: xcorrRoutines.py:1264-1690 (defined under `import cupy` upstream: restated from the source
+    text of the CPU methods ``xcorr`` :1486-1547 / ``_xcorrThread`` :1635-1690 / ``getCAF`` :1549-1633).
+    Pinned by the identity getCAF(selection) == GroupXcorrCZT(composite of the selected templates).xcorr,
+    checked against the importable reference class in tests/golden/make_golden.py."""
+
+    def __init__(self, ygroups, ygroupIdxs, groupStarts, f1, f2, binWidth, fs, autoConj=True):
+        ygroups = np.asarray(ygroups)
+        ygroupIdxs = np.asarray(ygroupIdxs)
+        groupStarts = np.asarray(groupStarts)
+        assert ygroups.shape[0] == ygroupIdxs.size
+        assert np.unique(ygroupIdxs).size == groupStarts.size
+        self.numTemplates = ygroupIdxs.size
+        self.numGroups = groupStarts.size
+        assert np.all(np.sort(np.unique(ygroupIdxs)) == np.arange(self.numGroups))
+        self.groupStarts, self.ygroupIdxs, self.fs = groupStarts, ygroupIdxs, fs
+        self.length = ygroups.shape[1]
+        self.f1, self.f2, self.binWidth = f1, f2, binWidth
+        self.ygroups = ygroups.conj() if autoConj else ygroups
+        self.ygroupsEnergy = np.linalg.norm(self.ygroups, axis=1) ** 2
+
+    def xcorr(self, rx, shifts=None, numThreads=1):
+        rx = np.asarray(rx)
+        if shifts is None:
+            shifts = np.arange(len(rx) - (self.groupStarts[-1] + self.length) + 1)
+        else:
+            shifts = np.asarray(shifts)
+            assert shifts[-1] + self.groupStarts[-1] + self.length < rx.size
+        k = int((self.f2 - self.f1) / self.binWidth + 1)
+        self.xcTemplates = np.zeros((self.numTemplates, shifts.size, k), dtype=np.complex128)
+        self.rxgroupNormSq = np.zeros((self.numGroups, shifts.size))
+        cztFreq = np.arange(self.f1, self.f2 + self.binWidth / 2, self.binWidth)
+        groupPhases = np.exp(-1j * 2 * np.pi * cztFreq * self.groupStarts.reshape((-1, 1)) / self.fs)
+        cztc = CZTCached(self.length, self.f1, self.f2, self.binWidth, self.fs)
+        for i, shift in enumerate(shifts):
+            for t in range(self.numTemplates):
+                g = self.ygroupIdxs[t]
+                rxgroup = rx[shift + self.groupStarts[g] : shift + self.groupStarts[g] + self.length]
+                self.rxgroupNormSq[g, i] = _energy(rxgroup)
+                self.xcTemplates[t, i, :] = cztc.run(self.ygroups[t, :] * rxgroup) * groupPhases[g, :]
+        return cztFreq
+
+    def getCAF(self, templateIdx, numThreads=4):
+        templateIdx = np.asarray(templateIdx)
+        assert templateIdx.size == self.numGroups
+        cafcplx = np.zeros(self.xcTemplates.shape[1:], dtype=np.complex128)
+        rxnormsq = np.zeros(self.rxgroupNormSq.shape[1])
+        ynormsq = 0.0
+        for g in range(templateIdx.size):
+            t = np.argwhere(self.ygroupIdxs == g)[templateIdx[g]][0]
+            cafcplx += self.xcTemplates[t]
+            rxnormsq += self.rxgroupNormSq[g, :]
+            ynormsq += self.ygroupsEnergy[t]
+        return np.abs(cafcplx) ** 2 / rxnormsq.reshape(-1, 1) / ynormsq
+
+
 class GroupXcorrFFT:
     """Equal-length groups on the makeFreq(fftlen, fs) grid.
 

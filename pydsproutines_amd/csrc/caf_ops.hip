@@ -357,4 +357,18 @@ int32_t caf_colmax_abs(const float* d_z, int32_t rows, int64_t n, float* d_max, 
     return CAF_OK;
 }
 
+int32_t caf_sum_planes_qf2(const float* d_planes, int32_t num_planes, int64_t rows, int32_t cols, const int32_t* h_sel,
+                           int32_t num_sel, const double* d_row_norm, double ynormsq, double* d_out, void* stream) {
+    CAF_REQUIRE(d_planes && h_sel && d_row_norm && d_out && num_planes >= 1 && rows >= 1 && cols >= 1,
+                "caf_sum_planes_qf2: bad arguments");
+    CAF_REQUIRE(num_sel >= 1 && num_sel <= 64, "caf_sum_planes_qf2: between 1 and 64 planes can be summed");
+    for (int j = 0; j < num_sel; ++j)
+        CAF_REQUIRE(h_sel[j] >= 0 && h_sel[j] < num_planes, "caf_sum_planes_qf2: plane number out of range");
+    CAF_REQUIRE(ynormsq > 0.0, "caf_sum_planes_qf2: ynormsq must be positive");
+    launch_sum_planes_qf2((const float2*)d_planes, rows * cols, cols, h_sel, num_sel, d_row_norm, ynormsq, d_out,
+                          (hipStream_t)stream);
+    CAF_HIP_TRY(hipGetLastError());
+    return CAF_OK;
+}
+
 }  // extern "C"

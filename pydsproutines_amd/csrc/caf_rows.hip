@@ -606,6 +606,38 @@ void launch_magnsq(const void* x, int64_t n, int in_c128, void* out, int out_f64
         hipLaunchKernelGGL((k_magnsq<double2, double>), dim3(g), dim3(256), 0, st, (const double2*)x, n, (double*)out);
 }
 
+// Combination step of GroupXcorrCZT_Permutations.getCAF (xcorrRoutines.py:1454-1484, 1549-1585):
+// out[i][k] = | sum_j planes[idx[j]][i][k] |^2 / (row_norm[i] * ynormsq), complex64 planes of rows x cols
+constexpr int SUMPL_MAX = 64;
+struct SumPlanesIdx {
+    int32_t v[SUMPL_MAX];
+};
+__global__ __launch_bounds__(256) void k_sum_planes_qf2(const float2* __restrict__ planes, int64_t plane_elems,
+                                                        int32_t cols, SumPlanesIdx idx, int32_t nsel,
+                                                        const double* __restrict__ row_norm, double ynormsq,
+                                                        double* __restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < plane_elems; e += stride) {
+        float2 acc = make_float2(0.f, 0.f);
+        for (int j = 0; j < nsel; ++j) {
+            const float2 v = planes[(int64_t)idx.v[j] * plane_elems + e];
+            acc.x += v.x;
+            acc.y += v.y;
+        }
+        const float m = acc.x * acc.x + acc.y * acc.y;  // cp.abs(complex64)**2 is float32 upstream
+        out[e] = (double)m / row_norm[e / cols] / ynormsq;
+    }
+}
+
+void launch_sum_planes_qf2(const float2* planes, int64_t plane_elems, int32_t cols, const int32_t* h_idx, int32_t nsel,
+                           const double* row_norm, double ynormsq, double* out, hipStream_t st) {
+    SumPlanesIdx idx;
+    for (int j = 0; j < SUMPL_MAX; ++j) idx.v[j] = j < nsel ? h_idx[j] : 0;
+    const unsigned g = std::min<unsigned>(cdiv(plane_elems, 256), 256 * 16);
+    hipLaunchKernelGGL(k_sum_planes_qf2, dim3(g), dim3(256), 0, st, planes, plane_elems, cols, idx, nsel, row_norm, ynormsq,
+                       out);
+}
+
 int64_t moving_num_tiles(int64_t n) { return (n + 1 + MA_TILE - 1) / MA_TILE; }
 
 void scan_tiles(double* tile_sums, int64_t ntiles, hipStream_t st);  // caf_kernels.hip

@@ -27,6 +27,7 @@ from .cupyExtensions import (  # noqa: F401  (re-exported like `from cupyExtensi
     cupyCopyGroups32fc,
     cupyCopyIncrementalEqualSlicesToMatrix_32fc,
     fftRows,
+    multiplySlicesOptimistically,
     multiplySlidesNormalised,
     multiTemplateSlidingDotProduct,
 )
@@ -569,6 +570,128 @@ class pbIppGroupXcorrCZT(_GroupEngine):
 # ------------------------------------------------------------------------------------------
 # small helpers of the reference API
 # ------------------------------------------------------------------------------------------
+class GroupXcorrGPU(GroupXcorr):
+    """ref: xcorrRoutines.py:1897-2058.  ``GroupXcorr`` without the autoConj / autoZeroStarts options;
+    ``xcorr`` as the parent, ``xcorrKernel`` returns (QF^2 float32[S], frequency INDEX int32[S])."""
+
+    def __init__(self, y, starts, lengths, freqs, fs):
+        super().__init__(y, starts, lengths, freqs, fs)
+
+    def xcorrKernel(self, rx, shifts, numShiftsPerBlk=2, verbTiming=False):
+        rx = np.asarray(rx)
+        shifts = np.asarray(shifts)
+        assert shifts.size % numShiftsPerBlk == 0
+        res, rel = self._run(rx, shifts + self._first, rows=True, peak=False)
+        return res.row_max.get()[0][rel].astype(np.float32), res.row_arg.get()[0][rel].astype(np.int32)
+
+
+class GroupXcorrCZT_Permutations:
+    """ref: xcorrRoutines.py:1264-1690.  Every template (one of several candidates per group, all of one
+    length) is correlated ONCE into a complex (shifts, k) CZT plane; ``getCAF`` then combines one plane per
+    group into the CAF of that permutation, so P1 x P2 x ... permutations cost P1 + P2 + ... correlations.
+
+    Device flow per template: product rows x[shift + start : +L] * template (``caf_multiply_slices_indexed_rows``)
+    -> Bluestein CZT rows (``caf_czt_run_many``, the group's start phase folded into the output chirp);
+    rx group energies from one moving sum of |rx|^2; ``getCAF`` = ``caf_sum_planes_qf2``.
+    The planes stay on the device (``d_xcTemplates`` complex64 (T, S, k)); ``xcTemplates`` / ``rxgroupNormSq``
+    are host copies for callers that read the reference's attributes."""
+
+    def __init__(self, ygroups, ygroupIdxs, groupStarts, f1, f2, binWidth, fs, autoConj=True):
+        ygroups = np.asarray(ygroups)
+        ygroupIdxs = np.asarray(ygroupIdxs)
+        groupStarts = np.asarray(groupStarts)
+        assert ygroups.shape[0] == ygroupIdxs.size
+        assert np.unique(ygroupIdxs).size == groupStarts.size
+        self.numTemplates = ygroupIdxs.size
+        self.numGroups = groupStarts.size
+        assert np.all(np.sort(np.unique(ygroupIdxs)) == np.arange(self.numGroups))
+        self.groupStarts = groupStarts
+        self.ygroupIdxs = ygroupIdxs
+        self.fs = fs
+        self.length = ygroups.shape[1]
+        self.f1, self.f2, self.binWidth = f1, f2, binWidth
+        self.ygroups = ygroups.conj() if autoConj else ygroups
+        self.ygroupsEnergy = np.linalg.norm(self.ygroups, axis=1) ** 2
+        self._d_ygroups = asarray(_c64(self.ygroups))
+        self.d_xcTemplates = None
+        self.d_rxgroupNormSq = None
+
+    # -- shared device path ------------------------------------------------------------------
+    def _correlate(self, d_rx, shifts):
+        shifts = np.asarray(shifts)
+        L, T, G = self.length, self.numTemplates, self.numGroups
+        S = shifts.size
+        cztFreq = np.arange(self.f1, self.f2 + self.binWidth / 2, self.binWidth)
+        czts = []
+        for g in range(G):  # one CZT object per group: output chirp * exp(-j 2 pi f start_g / fs)
+            c = CZTCachedGPU(L, self.f1, self.f2, self.binWidth, self.fs)
+            ph = np.exp(-2j * np.pi * c.getFreq() * float(self.groupStarts[g]) / self.fs)
+            c._d_wws = asarray((c._ww64[c.m - 1 : c.m + c.k - 1] * ph).astype(np.complex64))
+            czts.append(c)
+        k = czts[0].k
+        # sliding energy of rx once: E[d] = sum |rx[d : d+L]|^2 (causal moving sum, so E[d] = msum[d + L - 1])
+        msum = cupyMovingAverage(cupyComplexMagnSq(d_rx, np.float32), L, sumInstead=True).get().astype(np.float64)
+        self._rxgroupNormSq = np.stack([msum[shifts + int(self.groupStarts[g]) + L - 1] for g in range(G)])
+        self.d_rxgroupNormSq = asarray(self._rxgroupNormSq.astype(np.float32))
+        self.d_xcTemplates = empty((T, S, k), np.complex64)
+        d_len = asarray(np.full(S, L, np.int32))
+        for t in range(T):
+            g = int(self.ygroupIdxs[t])
+            d_starts = asarray((shifts + int(self.groupStarts[g])).astype(np.int32))
+            d_rowidx = asarray(np.full(S, t, np.int32))
+            d_mul = multiplySlicesOptimistically(d_rx, self._d_ygroups, d_starts, d_len, d_rowidx)
+            czts[g].runMany(d_mul, out=self.d_xcTemplates[t])
+        self._shape = (S, k)
+        return cztFreq
+
+    def _check_shifts(self, n, shifts):
+        if shifts is None:
+            return np.arange(n - (self.groupStarts[-1] + self.length) + 1)
+        shifts = np.asarray(shifts)
+        assert shifts[-1] + self.groupStarts[-1] + self.length < n
+        return shifts
+
+    # -- reference entry points --------------------------------------------------------------
+    def xcorrGPU(self, rx, shifts, batchSz=32):
+        requireDeviceArray(rx)
+        requireDtype(np.complex64, rx)
+        return self._correlate(rx, self._check_shifts(rx.size, shifts))
+
+    def xcorr(self, rx, shifts=None, numThreads=1):
+        rx = np.asarray(rx)
+        return self._correlate(asarray(_c64(rx)), self._check_shifts(rx.size, shifts))
+
+    @property
+    def xcTemplates(self):
+        return self.d_xcTemplates.get().astype(np.complex128)
+
+    @property
+    def rxgroupNormSq(self):
+        return self._rxgroupNormSq
+
+    def _select(self, templateIdx):
+        templateIdx = np.asarray(templateIdx)
+        assert templateIdx.size == self.numGroups
+        sel = np.array([np.argwhere(self.ygroupIdxs == g)[templateIdx[g]][0] for g in range(self.numGroups)], np.int32)
+        return sel, self._rxgroupNormSq.sum(axis=0), float(np.sum(self.ygroupsEnergy[sel]))
+
+    def getCAF_GPU(self, templateIdx):
+        sel, rxnormsq, ynormsq = self._select(templateIdx)
+        S, k = self._shape
+        out = empty((S, k), np.float64)
+        d_norm = asarray(np.ascontiguousarray(rxnormsq, dtype=np.float64))
+        _lib.check(
+            _lib.load().caf_sum_planes_qf2(ct.c_void_p(self.d_xcTemplates.ptr), self.numTemplates, S, k,
+                                           sel.ctypes.data_as(ct.c_void_p), sel.size, ct.c_void_p(d_norm.ptr), ynormsq,
+                                           ct.c_void_p(out.ptr), None),
+            "caf_sum_planes_qf2",
+        )
+        return out
+
+    def getCAF(self, templateIdx, numThreads=4):
+        return self.getCAF_GPU(templateIdx).get()
+
+
 def argmax2d(m):
     """ref: xcorrRoutines.py:815-830."""
     return np.unravel_index(np.argmax(m), m.shape)

@@ -272,7 +272,56 @@ def gen_kat4():
     save("kat4_tcc", x=x, t1=t1, t2=t2, qf_single=chk, abs1=a1, abs2=a2)
 
 
+def gen_perm():
+    """GroupXcorrCZT_Permutations / GroupXcorrGPU are defined under `import cupy` upstream and cannot be
+    imported here.  They are pinned through identities with importable reference classes:
+      getCAF(selection) == GroupXcorrCZT(composite of the selected templates, same CZT grid).xcorr
+      GroupXcorrGPU.xcorr / xcorrKernel == GroupXcorr.xcorr (value, frequency) on the same inputs."""
+    rng = np.random.default_rng(606)
+    fs = 4096.0
+    L, m = 96, 1400
+    groupStarts = np.array([0, 150])
+    ygroupIdxs = np.array([0, 0, 1, 1, 1])
+    ygroups = np.stack([qpsk(rng, L) for _ in range(5)])
+    rx = (0.4 * cn(rng, m)).astype(np.complex64)
+    d0, f0 = 500, 22.0
+    tone = np.exp(2j * np.pi * f0 * np.arange(groupStarts[-1] + L) / fs)
+    for g, t in ((0, 1), (1, 4)):  # the planted permutation: second template of group 0, third of group 1
+        s = groupStarts[g]
+        rx[d0 + s : d0 + s + L] += (ygroups[t] * tone[s : s + L]).astype(np.complex64)
+    f1, f2, bw = -40.0, 40.0, 2.0
+    sh = np.arange(440, 560)
+    op = O.GroupXcorrCZT_Permutations(ygroups, ygroupIdxs, groupStarts, f1, f2, bw, fs)
+    cztf = op.xcorr(rx, sh)
+    sels = np.array([[0, 0], [1, 2], [1, 0]])
+    cafs = []
+    print("GroupXcorrCZT_Permutations (via reference GroupXcorrCZT on the composite)")
+    for sel in sels:
+        tsel = [np.argwhere(ygroupIdxs == g)[sel[g]][0] for g in range(2)]
+        comp = np.zeros(groupStarts[-1] + L, np.complex64)
+        for g, t in enumerate(tsel):
+            comp[groupStarts[g] : groupStarts[g] + L] = ygroups[t]
+        r = R.GroupXcorrCZT(comp, groupStarts, np.array([L, L]), f1, f2, bw, fs)
+        caf, f = r.xcorr(rx, sh)
+        cafs.append(caf)
+        report("  getCAF %s" % (sel,), caf, op.getCAF(sel))
+    # GroupXcorrGPU == GroupXcorr
+    freqs = np.arange(-32.0, 32.0, 2.0)
+    comp = np.zeros(groupStarts[-1] + L, np.complex64)
+    comp[:L], comp[groupStarts[1] : groupStarts[1] + L] = ygroups[1], ygroups[4]
+    rg = R.GroupXcorr(comp, groupStarts, np.array([L, L]), freqs, fs)
+    xc, fpk = rg.xcorr(rx, sh)
+    og = O.GroupXcorrGPU(comp, groupStarts, np.array([L, L]), freqs, fs)
+    kxc, kfi = og.xcorrKernel(rx, sh)
+    report("  GroupXcorrGPU.xcorrKernel value", xc, kxc)
+    report("  GroupXcorrGPU.xcorrKernel freq", fpk, freqs[kfi])
+    save("perm_small", ygroups=ygroups, ygroupIdxs=ygroupIdxs, groupStarts=groupStarts, rx=rx, shifts=sh,
+         fs=np.array([fs]), f1f2bw=np.array([f1, f2, bw]), sels=sels, cafs=np.stack(cafs), cztFreq=cztf,
+         gfreqs=freqs, gcomp=comp, gxc=xc, gfpk=fpk, d0f0=np.array([d0, f0]))
+
+
 if __name__ == "__main__":
+    gen_perm()
     gen_fastxcorr()
     gen_kat2()
     gen_kat1_kat3()

@@ -207,6 +207,58 @@ def test_kat1_groupxcorrczt_and_pybind_twin(golden):
         pbIppGroupXcorrCZT(12, -0.1, 0.1, 0.1, 100.0, 0)
 
 
+def test_permutations_and_groupxcorrgpu(golden):
+    """GroupXcorrCZT_Permutations (CPU-flavour ``xcorr``/``getCAF`` and GPU-flavour ``xcorrGPU``/``getCAF_GPU``)
+    and GroupXcorrGPU against the golden vectors made with the reference's GroupXcorrCZT / GroupXcorr."""
+    from pydsproutines_amd import asarray
+    from pydsproutines_amd.devarray import DeviceArray
+    from pydsproutines_amd.xcorrRoutines import GroupXcorrCZT_Permutations, GroupXcorrGPU
+
+    g = golden("perm_small")
+    f1, f2, bw = g["f1f2bw"]
+    fs = float(g["fs"][0])
+    sh = g["shifts"]
+    p = GroupXcorrCZT_Permutations(g["ygroups"], g["ygroupIdxs"], g["groupStarts"], f1, f2, bw, fs)
+    f = p.xcorr(g["rx"], sh)
+    np.testing.assert_allclose(f, g["cztFreq"])
+    assert p.xcTemplates.shape == (5, sh.size, f.size) and p.xcTemplates.dtype == np.complex128
+    op = O.GroupXcorrCZT_Permutations(g["ygroups"], g["ygroupIdxs"], g["groupStarts"], f1, f2, bw, fs)
+    op.xcorr(g["rx"], sh)
+    scale = np.abs(op.xcTemplates).max()
+    assert np.max(np.abs(p.xcTemplates - op.xcTemplates)) <= 2e-5 * scale  # complex planes incl. the group phase
+    np.testing.assert_allclose(p.rxgroupNormSq, op.rxgroupNormSq, rtol=1e-5)
+    for sel, caf in zip(g["sels"], g["cafs"]):
+        got = p.getCAF(sel)
+        assert got.dtype == np.float64 and got.shape == caf.shape
+        np.testing.assert_allclose(got, caf, atol=TOL)
+    d0, f0 = g["d0f0"]
+    best = p.getCAF(g["sels"][1])
+    i, j = np.unravel_index(np.argmax(best), best.shape)
+    assert sh[i] == d0 and f[j] == f0
+    # GPU flavour: device rx, device CAF
+    p2 = GroupXcorrCZT_Permutations(g["ygroups"], g["ygroupIdxs"], g["groupStarts"], f1, f2, bw, fs)
+    f_b = p2.xcorrGPU(asarray(g["rx"]), sh)
+    np.testing.assert_allclose(f_b, f)
+    d_caf = p2.getCAF_GPU(g["sels"][2])
+    assert isinstance(d_caf, DeviceArray) and d_caf.dtype == np.float64
+    np.testing.assert_allclose(d_caf.get(), g["cafs"][2], atol=TOL)
+    with pytest.raises(AssertionError):
+        p2.getCAF(np.array([0]))
+    with pytest.raises(TypeError):
+        p2.xcorrGPU(g["rx"], sh)  # host array where a device array is required
+    # GroupXcorrGPU
+    gg = GroupXcorrGPU(g["gcomp"], g["groupStarts"], np.array([96, 96]), g["gfreqs"], fs)
+    xc, fpk = gg.xcorr(g["rx"], sh)
+    np.testing.assert_allclose(xc, g["gxc"], atol=TOL)
+    np.testing.assert_array_equal(fpk, g["gfpk"])
+    kxc, kfi = gg.xcorrKernel(g["rx"], sh)
+    assert kxc.dtype == np.float32 and kfi.dtype == np.int32
+    np.testing.assert_allclose(kxc, g["gxc"], atol=TOL)
+    np.testing.assert_array_equal(g["gfreqs"][kfi], g["gfpk"])
+    with pytest.raises(AssertionError):
+        gg.xcorrKernel(g["rx"], sh[:-1])
+
+
 # ---- TemplateCrossCorrelator (the reference's own unit test) --------------------------------
 def test_kat4_template_cross_correlator(golden):
     from pydsproutines_amd import asarray

@@ -173,6 +173,37 @@ def test_kat4_tcc(golden):
         both.correlate(x[:50])
 
 
+def test_permutations_and_groupxcorrgpu(golden):
+    """GroupXcorrCZT_Permutations / GroupXcorrGPU (cupy-only upstream): pinned through the reference's
+    GroupXcorrCZT on the composite of the selected templates and GroupXcorr on the same inputs."""
+    g = golden("perm_small")
+    f1, f2, bw = g["f1f2bw"]
+    fs = float(g["fs"][0])
+    op = O.GroupXcorrCZT_Permutations(g["ygroups"], g["ygroupIdxs"], g["groupStarts"], f1, f2, bw, fs)
+    f = op.xcorr(g["rx"], g["shifts"])
+    np.testing.assert_allclose(f, g["cztFreq"])
+    assert op.xcTemplates.shape == (5, g["shifts"].size, f.size) and op.rxgroupNormSq.shape == (2, g["shifts"].size)
+    for sel, caf in zip(g["sels"], g["cafs"]):
+        np.testing.assert_allclose(op.getCAF(sel), caf, atol=5e-7)
+    d0, f0 = g["d0f0"]
+    i, j = np.unravel_index(np.argmax(g["cafs"][1]), g["cafs"][1].shape)  # the planted permutation [1, 2]
+    assert g["shifts"][i] == d0 and f[j] == f0 and g["cafs"][1].max() > 3 * g["cafs"][0].max()
+    with pytest.raises(AssertionError):
+        op.getCAF(np.array([0]))
+    with pytest.raises(AssertionError):
+        O.GroupXcorrCZT_Permutations(g["ygroups"], np.array([0, 0, 2, 2, 2]), g["groupStarts"], f1, f2, bw, fs)
+    og = O.GroupXcorrGPU(g["gcomp"], g["groupStarts"], np.array([96, 96]), g["gfreqs"], fs)
+    xc, fpk = og.xcorr(g["rx"], g["shifts"])
+    np.testing.assert_allclose(xc, g["gxc"], atol=5e-7)
+    np.testing.assert_array_equal(fpk, g["gfpk"])
+    kxc, kfi = og.xcorrKernel(g["rx"], g["shifts"])
+    assert kxc.dtype == np.float32 and kfi.dtype == np.int32
+    np.testing.assert_allclose(kxc, g["gxc"], atol=5e-7)
+    np.testing.assert_array_equal(g["gfreqs"][kfi], g["gfpk"])
+    with pytest.raises(AssertionError):
+        og.xcorrKernel(g["rx"], g["shifts"][:-1])  # 119 shifts, 2 per block
+
+
 def test_kernel_semantics_against_scipy():
     """The reference pins its kernels to scipy (filterRoutines.py:1256,1319,1358;
     benchmark_upfirdnkernels.py:58-67, benchmark_filterkernels.py:72-74)."""
