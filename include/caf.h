@@ -242,6 +242,13 @@ CAF_EXPORT int32_t caf_iq16_to_c64(const int16_t* d_iq, int64_t num_samples, flo
 /* per column of a complex64 (rows, n) matrix: max_r |z| and the first row attaining it
  * (TemplateCrossCorrelator.correlate(returnMax=True), xcorrRoutines.py:361-371) */
 CAF_EXPORT int32_t caf_colmax_abs(const float* d_z, int32_t rows, int64_t n, float* d_max, int32_t* d_arg, void* stream);
+/* Sub-sample refinement after the peak (fineFreqTimeSearch / GenXcorr.xcorr, xcorrRoutines.py:583-719):
+ * d_out[i] = d_a[i] * conj(d_b[i]) (complex64; `x_fft * y_fft.conj()` :648, `y_aligned.conj() * x_aligned` :622) */
+CAF_EXPORT int32_t caf_mul_conj(const float* d_a, const float* d_b, int64_t n, float* d_out, void* stream);
+/* d_out[r] (complex128) = scale * sum_k d_vec[k] (complex64) * conj(d_steer[r][k]) (complex128 [rows][n]):
+ * `np.dot(rx_vec, steeringvec.conj().T) / norms` :661-665, `np.vdot(precomputed, fineshifts[j])` :630 */
+CAF_EXPORT int32_t caf_steer_dot(const float* d_vec, const double* d_steer, int64_t rows, int64_t n, double scale,
+                                 double* d_out, void* stream);
 /* GroupXcorrCZT_Permutations.getCAF / getCAF_GPU (xcorrRoutines.py:1454-1484, 1549-1585): sum the selected
  * per-template complex64 planes d_planes[num_planes][rows][cols] (h_sel: host array of num_sel <= 64 plane
  * numbers), then d_out[rows][cols] (float64) = |sum|^2 / d_row_norm[row] (float64) / ynormsq */

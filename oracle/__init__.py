@@ -28,6 +28,9 @@ from .xcorr import (  # noqa: F401
     GroupXcorrCZT,
     GroupXcorrCZT_Permutations,
     GroupXcorrGPU,
+    GenXcorr,
+    fineFreqTimeSearch,
+    makeTimeScanSteervec,
     TemplateCrossCorrelator,
     IppXcorrFFT,
     IppGroupXcorrFFT,

@@ -307,6 +307,64 @@ class GroupXcorrCZT:
         return xc, cztFreq
 
 
+def makeTimeScanSteervec(td_scan_range, fs, siglen):
+    """ref: xcorrRoutines.py:670-676."""
+    return np.exp(1j * 2 * np.pi * makeFreq(siglen, fs) * np.asarray(td_scan_range).reshape((-1, 1)))
+
+
+def _time_scan(x, y, steeringvec, sigFreq, bounds):
+    """ref: xcorrRoutines.py:644-667 / 696-719 (shared by fineFreqTimeSearch and GenXcorr.xcorr)."""
+    x_fft = np.fft.fft(x)
+    y_fft = np.fft.fft(y)
+    rx_vec = x_fft * y_fft.conj()
+    if bounds is not None:
+        rx_vec[np.logical_or(sigFreq < bounds[0], sigFreq >= bounds[1])] = 0
+    return np.dot(rx_vec, steeringvec.conj().T) / np.linalg.norm(x_fft) / np.linalg.norm(y_fft)
+
+
+def fineFreqTimeSearch(x_aligned, y_aligned, fineRes, freqfound, freqRes, fs, td_scan_range, steeringvec=None,
+                       td_scan_freqBounds=None):
+    """ref: xcorrRoutines.py:583-667.  Returns (finefreqfound | None, timediff, cost_vec)."""
+    x_aligned = np.asarray(x_aligned)
+    y_aligned = np.asarray(y_aligned)
+    n = len(x_aligned)
+    if len(fineRes) > 0:
+        precomputed = y_aligned.conj() * x_aligned
+        for i in range(len(fineRes)):
+            fineFreq = np.arange(freqfound - freqRes, freqfound + freqRes, fineRes[i])
+            fineshifts = np.exp(1j * 2 * np.pi * -fineFreq.reshape((-1, 1)) * np.arange(n) / fs)
+            pp = np.array([np.vdot(precomputed, fineshifts[j]) for j in range(len(fineFreq))])
+            ind = int(np.argmax(np.abs(pp)))
+            freqfound = fineFreq[ind]
+        finefreqfound = freqfound
+        x_aligned = x_aligned * fineshifts[ind]
+    else:
+        finefreqfound = None
+    td_scan_range = np.asarray(td_scan_range)
+    if steeringvec is None:
+        steeringvec = makeTimeScanSteervec(td_scan_range, fs, n)
+    cost_vec = _time_scan(x_aligned, y_aligned, steeringvec, makeFreq(n, fs), td_scan_freqBounds)
+    return finefreqfound, td_scan_range[int(np.argmax(np.abs(cost_vec)))], cost_vec
+
+
+class GenXcorr:
+    """ref: xcorrRoutines.py:679-719."""
+
+    def __init__(self, td_scan_range, fs, siglen):
+        self.td_scan_range = np.asarray(td_scan_range)
+        self.fs = fs
+        self.sigFreq = makeFreq(siglen, fs)
+        self.steeringvec = np.exp(1j * 2 * np.pi * self.sigFreq * self.td_scan_range.reshape((-1, 1)))
+        self.td_scan_freqBounds = None
+
+    def setTDscan_freqBounds(self, td_scan_freqBounds):
+        self.td_scan_freqBounds = td_scan_freqBounds
+
+    def xcorr(self, x, y):
+        cost_vec = _time_scan(np.asarray(x), np.asarray(y), self.steeringvec, self.sigFreq, self.td_scan_freqBounds)
+        return self.td_scan_range[int(np.argmax(np.abs(cost_vec)))], cost_vec
+
+
 class GroupXcorrGPU(GroupXcorr):
     """ref: xcorrRoutines.py:1897-2058 (defined under `import cupy` upstream: restated from the source
     text).  ``xcorr`` is the parent's; ``xcorrKernel`` returns (QF^2 float32[S], frequency index int32[S])."""

@@ -357,6 +357,22 @@ int32_t caf_colmax_abs(const float* d_z, int32_t rows, int64_t n, float* d_max, 
     return CAF_OK;
 }
 
+int32_t caf_mul_conj(const float* d_a, const float* d_b, int64_t n, float* d_out, void* stream) {
+    CAF_REQUIRE(d_a && d_b && d_out && n >= 0, "caf_mul_conj: bad arguments");
+    if (n) launch_mul_conj((const float2*)d_a, (const float2*)d_b, n, (float2*)d_out, (hipStream_t)stream);
+    CAF_HIP_TRY(hipGetLastError());
+    return CAF_OK;
+}
+
+int32_t caf_steer_dot(const float* d_vec, const double* d_steer, int64_t rows, int64_t n, double scale, double* d_out,
+                      void* stream) {
+    CAF_REQUIRE(d_vec && d_steer && d_out && rows >= 1 && n >= 1, "caf_steer_dot: bad arguments");
+    CAF_REQUIRE(rows < ((int64_t)1 << 31), "caf_steer_dot: too many rows");
+    launch_steer_dot((const float2*)d_vec, (const double2*)d_steer, rows, n, scale, (double2*)d_out, (hipStream_t)stream);
+    CAF_HIP_TRY(hipGetLastError());
+    return CAF_OK;
+}
+
 int32_t caf_sum_planes_qf2(const float* d_planes, int32_t num_planes, int64_t rows, int32_t cols, const int32_t* h_sel,
                            int32_t num_sel, const double* d_row_norm, double ynormsq, double* d_out, void* stream) {
     CAF_REQUIRE(d_planes && h_sel && d_row_norm && d_out && num_planes >= 1 && rows >= 1 && cols >= 1,

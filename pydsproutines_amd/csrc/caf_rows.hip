@@ -638,6 +638,56 @@ void launch_sum_planes_qf2(const float2* planes, int64_t plane_elems, int32_t co
                        out);
 }
 
+// Sub-sample refinement after the peak (fineFreqTimeSearch / GenXcorr, xcorrRoutines.py:583-719):
+//   k_mul_conj : out[i] = a[i] * conj(b[i])                       (x_fft * y_fft.conj(), y.conj() * x, masks)
+//   k_steer_dot: out[r] = scale * sum_k vec[k] * conj(steer[r][k]) (np.dot(rx_vec, steeringvec.conj().T), np.vdot)
+// The steering matrix is complex128 as upstream (phases 2 pi f tau need the precision); products and the sum
+// are float64, the vector is the complex64 the device FFT produced.
+__global__ __launch_bounds__(256) void k_mul_conj(const float2* __restrict__ a, const float2* __restrict__ b, int64_t n,
+                                                  float2* __restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const float2 x = a[i], y = b[i];
+        out[i] = make_float2(x.x * y.x + x.y * y.y, x.y * y.x - x.x * y.y);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_steer_dot(const float2* __restrict__ vec, const double2* __restrict__ steer,
+                                                   int64_t n, double scale, double2* __restrict__ out) {
+    __shared__ double s_re[4], s_im[4];
+    const double2* row = steer + (int64_t)blockIdx.x * n;
+    double re = 0.0, im = 0.0;
+    for (int64_t k = threadIdx.x; k < n; k += 256) {
+        const float2 v = vec[k];
+        const double2 s = row[k];
+        re += (double)v.x * s.x + (double)v.y * s.y;  // v * conj(s)
+        im += (double)v.y * s.x - (double)v.x * s.y;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        re += __shfl_xor(re, o, 64);
+        im += __shfl_xor(im, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_re[threadIdx.x >> 6] = re;
+        s_im[threadIdx.x >> 6] = im;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        out[blockIdx.x] = make_double2(scale * (s_re[0] + s_re[1] + s_re[2] + s_re[3]),
+                                       scale * (s_im[0] + s_im[1] + s_im[2] + s_im[3]));
+}
+
+void launch_mul_conj(const float2* a, const float2* b, int64_t n, float2* out, hipStream_t st) {
+    const unsigned g = std::min<unsigned>(cdiv(n, 256), 256 * 16);
+    hipLaunchKernelGGL(k_mul_conj, dim3(g), dim3(256), 0, st, a, b, n, out);
+}
+
+void launch_steer_dot(const float2* vec, const double2* steer, int64_t rows, int64_t n, double scale, double2* out,
+                      hipStream_t st) {
+    hipLaunchKernelGGL(k_steer_dot, dim3((unsigned)rows), dim3(256), 0, st, vec, steer, n, scale, out);
+}
+
 int64_t moving_num_tiles(int64_t n) { return (n + 1 + MA_TILE - 1) / MA_TILE; }
 
 void scan_tiles(double* tile_sums, int64_t ntiles, hipStream_t st);  // caf_kernels.hip

@@ -570,6 +570,108 @@ class pbIppGroupXcorrCZT(_GroupEngine):
 # ------------------------------------------------------------------------------------------
 # small helpers of the reference API
 # ------------------------------------------------------------------------------------------
+# ------------------------------------------------------------------------------------------
+# sub-sample refinement after the peak
+# ------------------------------------------------------------------------------------------
+def makeTimeScanSteervec(td_scan_range, fs, siglen):
+    """ref: xcorrRoutines.py:670-676 (complex128 (len(td_scan_range), siglen) host matrix)."""
+    sigFreq = makeFreq(siglen, fs)
+    return np.exp(1j * 2 * np.pi * sigFreq * np.asarray(td_scan_range).reshape((-1, 1)))
+
+
+def _p(a):
+    return ct.c_void_p(a.ptr)
+
+
+def _mul_conj(d_a, d_b):
+    out = empty(d_a.shape, np.complex64)
+    _lib.check(_lib.load().caf_mul_conj(_p(d_a), _p(d_b), d_a.size, _p(out), None), "caf_mul_conj")
+    return out
+
+
+def _steer_dot(d_vec, d_steer, scale=1.0):
+    """scale * sum_k vec[k] * conj(steer[r, k]) for every row r, float64 accumulation; complex128 host result."""
+    rows, n = d_steer.shape
+    out = empty((rows,), np.complex128)
+    _lib.check(_lib.load().caf_steer_dot(_p(d_vec), _p(d_steer), rows, n, float(scale), _p(out), None), "caf_steer_dot")
+    return out.get()
+
+
+def _dev_norm(d_x):
+    """||x|| of a complex64 device vector (|x|^2 -> moving sum over the whole length, float64 accumulation)."""
+    s = cupyMovingAverage(cupyComplexMagnSq(d_x, np.float32), d_x.size, sumInstead=True)
+    return float(np.sqrt(np.float64(s[d_x.size - 1 : d_x.size].get()[0])))
+
+
+def _time_scan(d_x, d_y, d_steer, freq_mask):
+    x_fft, y_fft = fftRows(d_x), fftRows(d_y)
+    rx_vec = _mul_conj(x_fft, y_fft)
+    if freq_mask is not None:
+        rx_vec = _mul_conj(rx_vec, asarray(freq_mask.astype(np.complex64)))
+    return _steer_dot(rx_vec, d_steer, 1.0 / (_dev_norm(x_fft) * _dev_norm(y_fft)))
+
+
+def fineFreqTimeSearch(x_aligned, y_aligned, fineRes, freqfound, freqRes, fs, td_scan_range, steeringvec=None,
+                       td_scan_freqBounds=None):
+    """ref: xcorrRoutines.py:583-667.  Fine frequency (successive grids ``fineRes`` around ``freqfound``) and
+    then sub-sample time alignment by a steering-vector scan of the cross spectrum.  Returns
+    (finefreqfound or None, timediff, cost_vec complex128).  Device flow: y * conj(x) -> steering dot products
+    (``caf_steer_dot``) for the frequency grids; FFT rows -> x_fft * conj(y_fft) (``caf_mul_conj``) -> steering
+    dot products for the time scan."""
+    x = _c64(np.asarray(x_aligned))
+    y = _c64(np.asarray(y_aligned))
+    n = x.size
+    d_x, d_y = asarray(x), asarray(y)
+    if len(fineRes) > 0:
+        d_yx = _mul_conj(d_y, d_x)  # conj(precomputed), precomputed = y.conj() * x (:622)
+        for i in range(len(fineRes)):
+            fineFreq = np.arange(freqfound - freqRes, freqfound + freqRes, fineRes[i])
+            fineshifts = np.exp(1j * 2 * np.pi * -fineFreq.reshape((-1, 1)) * np.arange(n) / fs)
+            pp = _steer_dot(d_yx, asarray(np.conj(fineshifts)))  # = np.vdot(precomputed, fineshifts[j])
+            fineFreq_ind = int(np.argmax(np.abs(pp)))
+            freqfound = fineFreq[fineFreq_ind]
+        finefreqfound = freqfound
+        d_x = _mul_conj(d_x, asarray(_c64(np.conj(fineshifts[fineFreq_ind]))))  # x * fineshifts[ind]
+    else:
+        finefreqfound = None
+    td_scan_range = np.asarray(td_scan_range)
+    if steeringvec is None:
+        steeringvec = makeTimeScanSteervec(td_scan_range, fs, n)
+    mask = None
+    if td_scan_freqBounds is not None:
+        freqvec = makeFreq(n, fs)
+        mask = ~np.logical_or(freqvec < td_scan_freqBounds[0], freqvec >= td_scan_freqBounds[1])
+    cost_vec = _time_scan(d_x, d_y, asarray(np.ascontiguousarray(steeringvec, dtype=np.complex128)), mask)
+    idx_td = int(np.argmax(np.abs(cost_vec)))
+    return finefreqfound, td_scan_range[idx_td], cost_vec
+
+
+class GenXcorr:
+    """ref: xcorrRoutines.py:679-719.  The time-scan half of ``fineFreqTimeSearch`` with the steering matrix
+    built (and here: uploaded) once."""
+
+    def __init__(self, td_scan_range, fs, siglen):
+        self.td_scan_range = np.asarray(td_scan_range)
+        self.fs = fs
+        self.sigFreq = makeFreq(siglen, fs)
+        self.steeringvec = self._makeTimeScanSteervec()
+        self._d_steer = asarray(np.ascontiguousarray(self.steeringvec, dtype=np.complex128))
+        self.td_scan_freqBounds = None
+
+    def _makeTimeScanSteervec(self):
+        return np.exp(1j * 2 * np.pi * self.sigFreq * self.td_scan_range.reshape((-1, 1)))
+
+    def setTDscan_freqBounds(self, td_scan_freqBounds):
+        self.td_scan_freqBounds = td_scan_freqBounds
+
+    def xcorr(self, x, y):
+        mask = None
+        if self.td_scan_freqBounds is not None:
+            mask = ~np.logical_or(self.sigFreq < self.td_scan_freqBounds[0], self.sigFreq >= self.td_scan_freqBounds[1])
+        cost_vec = _time_scan(asarray(_c64(np.asarray(x))), asarray(_c64(np.asarray(y))), self._d_steer, mask)
+        return self.td_scan_range[int(np.argmax(np.abs(cost_vec)))], cost_vec
+
+
 class GroupXcorrGPU(GroupXcorr):
     """ref: xcorrRoutines.py:1897-2058.  ``GroupXcorr`` without the autoConj / autoZeroStarts options;
     ``xcorr`` as the parent, ``xcorrKernel`` returns (QF^2 float32[S], frequency INDEX int32[S])."""

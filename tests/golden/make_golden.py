@@ -320,7 +320,42 @@ def gen_perm():
          gfreqs=freqs, gcomp=comp, gxc=xc, gfpk=fpk, d0f0=np.array([d0, f0]))
 
 
+def gen_finesearch():
+    """fineFreqTimeSearch / GenXcorr (xcorrRoutines.py:583-719): a band-limited signal delayed by a fraction
+    of a sample and offset in frequency; two levels of fine frequency grids, a 201-point time scan."""
+    rng = np.random.default_rng(707)
+    fs, n = 1.0e4, 2048
+    spec = np.zeros(n, np.complex128)
+    band = np.abs(RC.makeFreq(n, fs)) < 0.3 * fs
+    spec[band] = (rng.standard_normal(band.sum()) + 1j * rng.standard_normal(band.sum()))
+    x = np.fft.ifft(spec)
+    tau, df = 0.37 / fs, 1.7  # y(t) = x(t - tau) e^{j 2 pi df t}
+    y = np.fft.ifft(spec * np.exp(-2j * np.pi * RC.makeFreq(n, fs) * tau)) * np.exp(2j * np.pi * df * np.arange(n) / fs)
+    x = (x / np.abs(x).max() + 0.01 * cn(rng, n, np.complex128)).astype(np.complex64)
+    y = (y / np.abs(y).max() + 0.01 * cn(rng, n, np.complex128)).astype(np.complex64)
+    td = np.arange(-1.0, 1.0 + 1e-9, 0.01) / fs
+    ff, tdiff, cost = quiet(R.fineFreqTimeSearch, x, y, [0.5, 0.05], 0.0, 4.0, fs, td)
+    off, otd, ocost = O.fineFreqTimeSearch(x, y, [0.5, 0.05], 0.0, 4.0, fs, td)
+    print("fineFreqTimeSearch: finefreq %r timediff %r (samples %.3f)" % (ff, tdiff, tdiff * fs))
+    report("  finefreq", np.array([ff]), np.array([off]))
+    report("  timediff", np.array([tdiff]), np.array([otd]))
+    report("  cost_vec", cost, ocost)
+    ff0, tdiff0, cost0 = quiet(R.fineFreqTimeSearch, x, y, [], 0.0, 4.0, fs, td, None, np.array([-2000.0, 2000.0]))
+    _, otd0, ocost0 = O.fineFreqTimeSearch(x, y, [], 0.0, 4.0, fs, td, None, np.array([-2000.0, 2000.0]))
+    report("  (no fine freq, bounded) cost_vec", cost0, ocost0)
+    gx = R.GenXcorr(td, fs, n)
+    gtd, gcost = gx.xcorr(x, y)
+    ogx = O.GenXcorr(td, fs, n)
+    ogtd, ogcost = ogx.xcorr(x, y)
+    report("  GenXcorr cost_vec", gcost, ogcost)
+    assert ff0 is None and otd0 == tdiff0 and ogtd == gtd and otd == tdiff and off == ff
+    save("finesearch", x=x, y=y, td=td, fs=np.array([fs]), fineRes=np.array([0.5, 0.05]), freqRes=np.array([4.0]),
+         finefreq=np.array([ff]), timediff=np.array([tdiff]), cost=cost, timediff0=np.array([tdiff0]), cost0=cost0,
+         bounds=np.array([-2000.0, 2000.0]), gen_timediff=np.array([gtd]), gen_cost=gcost)
+
+
 if __name__ == "__main__":
+    gen_finesearch()
     gen_perm()
     gen_fastxcorr()
     gen_kat2()

@@ -259,6 +259,36 @@ def test_permutations_and_groupxcorrgpu(golden):
         gg.xcorrKernel(g["rx"], sh[:-1])
 
 
+def test_finefreqtimesearch_and_genxcorr(golden):
+    """Sub-sample refinement after the peak (xcorrRoutines.py:583-719) against the reference's outputs:
+    same fine frequency and time-difference grid points, cost vector within 2e-5 (complex64 FFT on the
+    device, float64 steering sums)."""
+    from pydsproutines_amd.xcorrRoutines import GenXcorr, fineFreqTimeSearch, makeTimeScanSteervec
+
+    g = golden("finesearch")
+    fs = float(g["fs"][0])
+    ff, td, cost = fineFreqTimeSearch(g["x"], g["y"], list(g["fineRes"]), 0.0, float(g["freqRes"][0]), fs, g["td"])
+    assert ff == g["finefreq"][0] and td == g["timediff"][0]
+    assert cost.dtype == np.complex128 and cost.shape == g["cost"].shape
+    np.testing.assert_allclose(cost, g["cost"], atol=TOL)
+    ff0, td0, cost0 = fineFreqTimeSearch(g["x"], g["y"], [], 0.0, 4.0, fs, g["td"], None, g["bounds"])
+    assert ff0 is None and td0 == g["timediff0"][0]
+    np.testing.assert_allclose(cost0, g["cost0"], atol=TOL)
+    gx = GenXcorr(g["td"], fs, g["x"].size)
+    gtd, gcost = gx.xcorr(g["x"], g["y"])
+    assert gtd == g["gen_timediff"][0]
+    np.testing.assert_allclose(gcost, g["gen_cost"], atol=TOL)
+    gx.setTDscan_freqBounds(g["bounds"])
+    btd, bcost = gx.xcorr(g["x"], g["y"])
+    assert btd == g["timediff0"][0]
+    np.testing.assert_allclose(bcost, g["cost0"], atol=TOL)
+    sv = makeTimeScanSteervec(g["td"], fs, g["x"].size)
+    np.testing.assert_array_equal(sv, O.makeTimeScanSteervec(g["td"], fs, g["x"].size))
+    _, td1, cost1 = fineFreqTimeSearch(g["x"], g["y"], [], 0.0, 4.0, fs, g["td"], sv)
+    assert td1 == gtd
+    np.testing.assert_allclose(cost1, g["gen_cost"], atol=TOL)
+
+
 # ---- TemplateCrossCorrelator (the reference's own unit test) --------------------------------
 def test_kat4_template_cross_correlator(golden):
     from pydsproutines_amd import asarray

@@ -204,6 +204,26 @@ def test_permutations_and_groupxcorrgpu(golden):
         og.xcorrKernel(g["rx"], g["shifts"][:-1])  # 119 shifts, 2 per block
 
 
+def test_finefreqtimesearch_and_genxcorr(golden):
+    g = golden("finesearch")
+    fs = float(g["fs"][0])
+    ff, td, cost = O.fineFreqTimeSearch(g["x"], g["y"], list(g["fineRes"]), 0.0, float(g["freqRes"][0]), fs, g["td"])
+    assert ff == g["finefreq"][0] and td == g["timediff"][0]
+    np.testing.assert_allclose(cost, g["cost"], atol=1e-12)
+    ff0, td0, cost0 = O.fineFreqTimeSearch(g["x"], g["y"], [], 0.0, 4.0, fs, g["td"], None, g["bounds"])
+    assert ff0 is None and td0 == g["timediff0"][0]
+    np.testing.assert_allclose(cost0, g["cost0"], atol=1e-12)
+    gx = O.GenXcorr(g["td"], fs, g["x"].size)
+    gtd, gcost = gx.xcorr(g["x"], g["y"])
+    assert gtd == g["gen_timediff"][0]
+    np.testing.assert_allclose(gcost, g["gen_cost"], atol=1e-12)
+    # an explicit steering matrix is the same as the default one
+    sv = O.makeTimeScanSteervec(g["td"], fs, g["x"].size)
+    _, td1, cost1 = O.fineFreqTimeSearch(g["x"], g["y"], [], 0.0, 4.0, fs, g["td"], sv)
+    np.testing.assert_allclose(cost1, gcost, atol=1e-12)
+    assert td1 == gtd
+
+
 def test_kernel_semantics_against_scipy():
     """The reference pins its kernels to scipy (filterRoutines.py:1256,1319,1358;
     benchmark_upfirdnkernels.py:58-67, benchmark_filterkernels.py:72-74)."""
