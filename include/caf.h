@@ -111,7 +111,7 @@ typedef struct caf_plan_desc {
  *   PERSISTENT: the two FUSED stages as ONE work-queue launch (one resident workgroup per CU): the
  *           HBM-bound transpose runs on some CUs while the others compute FFTs.  Same conditions and
  *           results as FUSED.
- *   AUTO  : FUSED when its conditions hold and log2_block is 0 or 14, else ROCFFT. */
+ *   AUTO  : PERSISTENT when the FUSED conditions hold and log2_block is 0 or 14, else ROCFFT. */
 #define CAF_ENGINE_AUTO 0
 #define CAF_ENGINE_ROCFFT 1
 #define CAF_ENGINE_FUSED 2

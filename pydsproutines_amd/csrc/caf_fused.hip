@@ -555,6 +555,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_of(const void* base, uint3
 // launch by workgroups on other XCDs (each XCD has its own L2) with write-through stores; the readers must not be
 // served from a line their own L2 may still hold.  (Measured: no cost against plain loads.)
 constexpr int CAF_AUX_SC1 = 16;
+// 16-byte vector stores to addresses that are only 4-byte aligned (delay offsets are arbitrary)
+typedef float v4f_u_t __attribute__((ext_vector_type(4), aligned(4)));
+typedef int v4i_u_t __attribute__((ext_vector_type(4), aligned(4)));
 
 // Barrier-free tile role: every WAVE transposes its own (delay tile, template): 64 delays x nfreq hypotheses
 // in steps of 32 hypotheses through a private 64 x 33 float LDS patch.  No workgroup barrier, no cross-wave
@@ -720,6 +723,106 @@ __device__ __forceinline__ void transpose_wave(float* __restrict__ lds, const Pe
     }
 }
 
+// Tile role without a frequency scan (nfreq == 1: config C3, TemplateCrossCorrelator-style banks, fastXcorr
+// branch A through the engine).  The hypothesis axis of a tile IS the template axis and every value is its own
+// per-delay result, so nothing is transposed: a wave streams 32 templates x 64 delays per step and writes each
+// template's 64 results as 16-byte pieces straight to row_max (and the (T, S, 1) surface), row_arg = 0, and a
+// (delay, value) record per (tile, template).  One step replaces 32 passes of the general path.
+// (out of line: keeps the general path's register allocation unchanged)
+__device__ __attribute__((noinline)) void transpose_wave_f1(const PersistParams* pp_in, int z_in, int tile0_in) {
+    const PersistParams* pp = uniform_ptr(pp_in);
+    const int z = __builtin_amdgcn_readfirstlane(z_in), tile0 = __builtin_amdgcn_readfirstlane(tile0_in);
+    const CAF_AS4 PersistParams* P = params_of(pp);
+    const int32_t nhyp = P->ntmpl, step = P->step, tiles_per_blk = P->tiles_per_blk;
+    const int64_t num_shifts = P->num_shifts, shift_start = P->shift_start;
+    const int wave_id = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const int tile = tile0 + wave_id;
+    if (tile >= tiles_per_blk) return;
+    const int blk = P->blk0 + z;
+    const int sl0 = tile * 64;
+    const int64_t rel0 = (int64_t)blk * step + sl0;
+    int64_t nv = num_shifts - (int64_t)blk * step;
+    if (nv > step) nv = step;
+    const int nrows = sl0 < nv ? (int)min((int64_t)64, nv - sl0) : 0;
+    const int64_t pidx = (int64_t)blk * tiles_per_blk + tile;
+    PeakRec* partial = P->partial;
+    const int64_t ppt = P->partial_per_tmpl;
+    float* row_max = P->row_max;
+    int32_t* row_arg = P->row_arg;
+    float* surface = P->surface;
+    const int s4 = 4 * (lane & 15), fq = lane >> 4;
+    const float* vin = uniform_ptr(P->vt + ((int64_t)z * tiles_per_blk + tile) * (int64_t)nhyp * 64);
+    const __amdgpu_buffer_rsrc_t rin = buf_of(vin, (uint32_t)nhyp * 256u);
+    const __amdgpu_buffer_rsrc_t rts = buf_of(P->tscale, (uint32_t)nhyp * 4u);
+    const __amdgpu_buffer_rsrc_t rie = buf_of(uniform_ptr(P->inv_e + rel0), (uint32_t)nrows * 4u);
+    float g[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) g[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rie, (s4 + k) * 4, 0, 0));
+    const bool all4 = s4 + 3 < nrows;
+    for (int h0 = 0; h0 < nhyp; h0 += TW_H) {
+        v4f_t q[TW_H / 4];
+        float ts[TW_H / 4];
+#pragma unroll
+        for (int i = 0; i < TW_H / 4; ++i) {
+            q[i] = __builtin_bit_cast(v4f_t, __builtin_amdgcn_raw_buffer_load_b128(rin, (fq * 64 + s4) * 4, (h0 + 4 * i) * 256,
+                                                                                   CAF_AUX_SC1));
+            ts[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rts, fq * 4, (h0 + 4 * i) * 4, 0));
+        }
+#pragma unroll
+        for (int i = 0; i < TW_H / 4; ++i) {
+            const int h = h0 + 4 * i + fq;
+            const bool hv = h < nhyp;
+            const float x[4] = {q[i].x * g[0] * ts[i], q[i].y * g[1] * ts[i], q[i].z * g[2] * ts[i], q[i].w * g[3] * ts[i]};
+            if (hv && nrows > 0) {
+                const int64_t o = (int64_t)h * num_shifts + rel0 + s4;
+                if (all4) {
+                    const v4f_u_t xv = {x[0], x[1], x[2], x[3]};
+                    const v4i_u_t zv = {0, 0, 0, 0};
+                    if (row_max) *reinterpret_cast<v4f_u_t*>(row_max + o) = xv;
+                    if (surface) *reinterpret_cast<v4f_u_t*>(surface + o) = xv;
+                    if (row_arg) *reinterpret_cast<v4i_u_t*>(row_arg + o) = zv;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (s4 + k < nrows) {
+                            if (row_max) row_max[o + k] = x[k];
+                            if (surface) surface[o + k] = x[k];
+                            if (row_arg) row_arg[o + k] = 0;
+                        }
+                }
+            }
+            if (partial) {
+                // the template's maximum over the tile's delays: first maximum wins, NaN never does
+                float best = -1.f;
+                int32_t bdel = 0x7fffffff;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (s4 + k < nrows && x[k] > best) {
+                        best = x[k];
+                        bdel = s4 + k;
+                    }
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) {
+                    const float ov = __shfl_xor(best, o, 64);
+                    const int32_t od = __shfl_xor(bdel, o, 64);
+                    if (ov > best || (ov == best && od < bdel)) {
+                        best = ov;
+                        bdel = od;
+                    }
+                }
+                if (hv && (lane & 15) == 0) {
+                    PeakRec r;
+                    r.v = best;
+                    r.delay = nrows > 0 && bdel != 0x7fffffff ? (int32_t)(shift_start + rel0 + bdel) : 0x7fffffff;
+                    r.f = 0;
+                    partial[(int64_t)h * ppt + pidx] = r;
+                }
+            }
+        }
+    }
+}
+
 // waits (bounded) until every hypothesis group of the block of tile item `item` is published
 __device__ __forceinline__ void pq_wait_block(int32_t* pq, int item, int ipb, int ngroups, bool lane0) {
     // The block's FFT items are either running on resident workgroups or still in the FFT queue, which the
@@ -757,7 +860,9 @@ __device__ __attribute__((noinline)) void persistent_tile_run(lds_float* lds_in,
         const CAF_AS4 PersistParams* P = params_of(pp);
         const int ipb = P->ipb;
         const int z = item / ipb;
-        if (P->surface)
+        if (P->nfreq == 1)
+            transpose_wave_f1(pp, z, (item - z * ipb) * PQ_TILES);
+        else if (P->surface)
             transpose_wave<true>(lds, pp, z, (item - z * ipb) * PQ_TILES);
         else
             transpose_wave<false>(lds, pp, z, (item - z * ipb) * PQ_TILES);

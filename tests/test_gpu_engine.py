@@ -262,3 +262,25 @@ def test_engines_agree_with_oracle(engine, golden):
         r5 = plan4.run(asarray(rx4), surface=False, rows=False, peak=True)
         np.testing.assert_array_equal(r5.peak_delay.get(), r4.peak_delay.get())
         np.testing.assert_array_equal(r5.peak_val.get(), r4.peak_val.get())
+
+    # no frequency scan (one bin), 37 templates (more than one 32-template step, ragged): the C3 / template-bank
+    # shape, which the persistent engine streams without a transpose
+    T6 = 37
+    tm6 = np.stack([qpsk(rng, n) for _ in range(T6)])
+    rx6 = cn(rng, m)
+    d6 = 500 + 1000 * np.arange(T6) + rng.integers(0, 64, T6)
+    for i in range(T6):
+        rx6[d6[i] : d6[i] + n] += 2 * tm6[i]
+    plan6 = CAFPlan(tm6, max_rx_len=m, bins=[0], grid=n, engine=engine)
+    r6 = plan6.run(asarray(rx6), surface=True)
+    np.testing.assert_array_equal(r6.peak_delay.get(), d6)
+    assert np.all(r6.row_arg.get() == 0) and np.all(r6.peak_freq.get() == 0)
+    np.testing.assert_array_equal(r6.surface.get()[:, :, 0], r6.row_max.get())
+    rm6 = r6.row_max.get()
+    for i in (0, 17, 36):
+        ref = O.fastXcorr(tm6[i], rx6)
+        assert np.max(np.abs(rm6[i] - ref)) <= 1e-4 * ref.max()
+        assert float(r6.peak_val.get()[i]) == rm6[i].max()
+    r7 = plan6.run(asarray(rx6), shift_start=700, num_shifts=20001, surface=False, rows=True, peak=True)
+    np.testing.assert_allclose(r7.row_max.get(), rm6[:, 700:20701], atol=2e-6)
+    assert np.all(r7.peak_delay.get()[1:20] == d6[1:20])
