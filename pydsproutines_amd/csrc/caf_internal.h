@@ -45,8 +45,9 @@ void launch_magsq(const float2* pbuf, int32_t pitch, int32_t ntmpl, int32_t nfre
                   const float* inv_e, int64_t num_shifts, int64_t shift_start, int32_t step, int32_t blk0,
                   int32_t nblk, int32_t tiles_per_blk, float* surface, float* row_max, int32_t* row_arg,
                   PeakRec* partial, int64_t partial_per_tmpl, hipStream_t st);
-void launch_peak_reduce(const PeakRec* partial, int64_t count, int64_t stride, int32_t ntmpl, float* pv, int32_t* pd,
-                        int32_t* pf, hipStream_t st);
+constexpr int PEAK_PARTS = 64;  // first-stage slices per template of the two-stage peak reduction
+void launch_peak_reduce(const PeakRec* partial, int64_t count, int64_t stride, int32_t ntmpl, PeakRec* scratch,
+                        float* pv, int32_t* pd, int32_t* pf, hipStream_t st);
 void scan_tiles(double* tile_sums, int64_t ntiles, hipStream_t st);
 
 // caf_rows.hip

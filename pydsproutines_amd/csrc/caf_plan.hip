@@ -347,7 +347,8 @@ static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
     } else {
         if ((rc = p->alloc(&p->d_pbuf, (int64_t)nb * T * F * p->pitch))) return rc;
     }
-    if ((rc = p->alloc(&p->d_partial, (int64_t)T * p->partial_per_tmpl))) return rc;
+    // tile records + PEAK_PARTS records per template for the two-stage reduction
+    if ((rc = p->alloc(&p->d_partial, (int64_t)T * p->partial_per_tmpl + (int64_t)T * PEAK_PARTS))) return rc;
 
     // template spectra: u = auto_conj ? tmpl : conj(tmpl);  u_f[n] = u[n] exp(+j 2 pi nu_f n);
     // Hc = conj(FFT_B(u_f)) / B  (rocFFT's inverse is unnormalised, 1/B is folded in here)
@@ -645,7 +646,7 @@ int32_t caf_plan_execute(caf_plan p, const float* d_rx, int64_t rx_len, int64_t 
         p->stage_begin(6, st);
         // only the records of the blocks touched by this call are valid
         launch_peak_reduce(p->d_partial, (p->fused ? nblk : nblk_pad) * p->tiles_per_blk, p->partial_per_tmpl, T,
-                           out->d_peak_val,
+                           p->d_partial + (int64_t)T * p->partial_per_tmpl, out->d_peak_val,
                            out->d_peak_delay, out->d_peak_freq, st);
         p->stage_end(st);
     }
