@@ -827,8 +827,9 @@ __device__ __attribute__((noinline)) void transpose_wave_f1(const PersistParams*
 __device__ __forceinline__ void pq_wait_block(int32_t* pq, int item, int ipb, int ngroups, bool lane0) {
     // The block's FFT items are either running on resident workgroups or still in the FFT queue, which the
     // workgroups that do not prefer tiles keep draining (they never wait while FFT items are left, and workgroup
-    // 0 is always one of them).  Watchdog (~10 s of polling): unreachable unless the protocol is broken; it makes
-    // the launch end with a mark in pq[2..3] (the tile is then transposed from unfinished data) instead of hanging.
+    // 0 is always one of them).  Watchdog (~10 s of polling): unreachable unless the protocol is broken; it leaves
+    // a mark in pq[2..3] and TRAPS, so that the launch fails loudly (the next synchronisation reports an error)
+    // instead of hanging the GPU or transposing unfinished data.
     int spins = 0;
     while (__builtin_amdgcn_readfirstlane(pq_load(&pq[PQ_DONE + item / ipb])) < ngroups) {
         __builtin_amdgcn_s_sleep(64);
@@ -837,7 +838,7 @@ __device__ __forceinline__ void pq_wait_block(int32_t* pq, int item, int ipb, in
                 atomicExch(&pq[2], 1 + item);
                 atomicExch(&pq[3], pq_load(&pq[PQ_FFT_NEXT]));
             }
-            break;
+            __builtin_trap();
         }
     }
 }
