@@ -300,6 +300,14 @@ static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
     p->max_blocks = (total_blocks + nb - 1) / nb * nb;
     p->partial_per_tmpl = p->max_blocks * p->tiles_per_blk;
     p->hyp_per_wg = (int)std::min<int64_t>(p->fused ? 64 : 16, (int64_t)T * F);
+    if (p->fused) {
+        // small jobs: fewer hypotheses per FFT work item, so that there are about two items per CU when the job
+        // allows it (one block x 32 hypotheses as ONE item kept 255 CUs idle for 0.25 ms)
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p->device);
+        const int64_t want = ((int64_t)T * F * total_blocks + 2 * cus - 1) / (2 * cus);
+        p->hyp_per_wg = (int)std::min<int64_t>(p->hyp_per_wg, std::max<int64_t>(4, want));
+    }
 
     // device buffers
     int rc;
