@@ -242,6 +242,12 @@ CAF_EXPORT int32_t caf_iq16_to_c64(const int16_t* d_iq, int64_t num_samples, flo
 /* per column of a complex64 (rows, n) matrix: max_r |z| and the first row attaining it
  * (TemplateCrossCorrelator.correlate(returnMax=True), xcorrRoutines.py:361-371) */
 CAF_EXPORT int32_t caf_colmax_abs(const float* d_z, int32_t rows, int64_t n, float* d_max, int32_t* d_arg, void* stream);
+/* Tone-dot zoom, dotTonesScaling_32f (genTones.cu:165-283, cupyDotTonesScaling spectralRoutines.py:580-630):
+ * d_out[b][k] (complex64, ceil(len/64) x num_freqs) = sum over the 64-sample block b of
+ * d_src[i] * exp(j 2 pi (f0 + k fstep) i), f0 / fstep normalised (cycles per sample); summing over b gives the
+ * CZT of d_src at the normalised frequencies -(f0 + k fstep) */
+CAF_EXPORT int32_t caf_dot_tones(const float* d_src, int64_t len, double f0, double fstep, int32_t num_freqs,
+                                 float* d_out, void* stream);
 /* Sub-sample refinement after the peak (fineFreqTimeSearch / GenXcorr.xcorr, xcorrRoutines.py:583-719):
  * d_out[i] = d_a[i] * conj(d_b[i]) (complex64; `x_fft * y_fft.conj()` :648, `y_aligned.conj() * x_aligned` :622) */
 CAF_EXPORT int32_t caf_mul_conj(const float* d_a, const float* d_b, int64_t n, float* d_out, void* stream);

@@ -182,6 +182,24 @@ def copyIncrementalEqualSlicesToMatrix(x, start, increment, length, rows):
     return copySlicesToMatrix(x, start + increment * np.arange(rows), length)
 
 
+def dotTonesScaling(f0, fstep, numFreqs, src):
+    """ref: genTones.cu:165-283 / spectralRoutines.py:580-630 (cupy-only upstream: restated from the kernel text,
+    in float64 -- the kernel's own float recurrence over the frequencies is its error, not its definition).
+    out[b, k] = sum over the 64-sample block b of src[i] * exp(j 2 pi (f0 + k fstep) i); complex128 (B, numFreqs).
+    Pinned by the upstream docstring's identity sum(axis=0) == czt(src) at -(f0 + k fstep), checked against the
+    importable reference `czt` in tests/golden/make_golden.py."""
+    src = np.asarray(src).astype(np.complex128)
+    n = src.size
+    nb = (n + 63) // 64
+    i = np.arange(nb * 64, dtype=np.float64)
+    padded = np.zeros(nb * 64, np.complex128)
+    padded[:n] = src
+    out = np.empty((nb, numFreqs), np.complex128)
+    for k in range(numFreqs):
+        out[:, k] = (padded * np.exp(2j * np.pi * ((f0 + k * fstep) * i % 1.0))).reshape(nb, 64).sum(axis=1)
+    return out
+
+
 def copyGroups(x, y, xStarts, yStarts, lengths):
     """y[yStarts[b] + i] = x[xStarts[b] + i] for i < lengths[b]; returns y."""
     for xs, ys, l in zip(xStarts, yStarts, lengths):

@@ -357,6 +357,15 @@ int32_t caf_colmax_abs(const float* d_z, int32_t rows, int64_t n, float* d_max, 
     return CAF_OK;
 }
 
+int32_t caf_dot_tones(const float* d_src, int64_t len, double f0, double fstep, int32_t num_freqs, float* d_out,
+                      void* stream) {
+    CAF_REQUIRE(d_src && d_out && len >= 1 && num_freqs >= 1, "caf_dot_tones: bad arguments");
+    CAF_REQUIRE((len + 63) / 64 < ((int64_t)1 << 31), "caf_dot_tones: source too long");
+    launch_dot_tones(f0, fstep, num_freqs, len, (const float2*)d_src, (float2*)d_out, (hipStream_t)stream);
+    CAF_HIP_TRY(hipGetLastError());
+    return CAF_OK;
+}
+
 int32_t caf_mul_conj(const float* d_a, const float* d_b, int64_t n, float* d_out, void* stream) {
     CAF_REQUIRE(d_a && d_b && d_out && n >= 0, "caf_mul_conj: bad arguments");
     if (n) launch_mul_conj((const float2*)d_a, (const float2*)d_b, n, (float2*)d_out, (hipStream_t)stream);

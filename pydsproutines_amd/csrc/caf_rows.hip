@@ -688,6 +688,55 @@ void launch_steer_dot(const float2* vec, const double2* steer, int64_t rows, int
     hipLaunchKernelGGL(k_steer_dot, dim3((unsigned)rows), dim3(256), 0, st, vec, steer, n, scale, out);
 }
 
+// Tone-dot zoom (dotTonesScaling_32f, genTones.cu:165-283; cupyDotTonesScaling, spectralRoutines.py:580-630):
+//   out[b][k] = sum_{i in 64-sample block b} src[i] * exp(j 2 pi (f0 + k fstep) i),  k < num_freqs
+// One wave per block.  Every lane carries src[i] * tone and steps it by exp(j 2 pi fstep i) (complex64, as
+// upstream), re-anchored with a float64 sincospi at every batch of 64 frequencies (upstream lets the float
+// recurrence run over all frequencies); a 64 x 65 LDS patch turns 64 frequencies x 64 samples into row sums.
+__global__ __launch_bounds__(64) void k_dot_tones(double f0, double fstep, int32_t num_freqs, int64_t len,
+                                                  const float2* __restrict__ src, float2* __restrict__ out) {
+    __shared__ float2 s_ws[64 * 65];
+    const int lane = threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+    const float2 v = i < len ? src[i] : make_float2(0.f, 0.f);
+    double sr, cr;
+    {
+        double t = fstep * (double)i;
+        t -= floor(t);  // whole cycles do not matter; keeps the argument of sincospi small
+        sincospi(2.0 * t, &sr, &cr);
+    }
+    const float2 alpha = make_float2((float)cr, (float)sr);
+    for (int k0 = 0; k0 < num_freqs; k0 += 64) {
+        double t = (f0 + (double)k0 * fstep) * (double)i;
+        t -= floor(t);
+        sincospi(2.0 * t, &sr, &cr);
+        float2 cur = make_float2(v.x * (float)cr - v.y * (float)sr, v.x * (float)sr + v.y * (float)cr);
+        const int nk = min(64, num_freqs - k0);
+        for (int r = 0; r < nk; ++r) {
+            s_ws[r * 65 + lane] = cur;
+            cur = make_float2(cur.x * alpha.x - cur.y * alpha.y, cur.x * alpha.y + cur.y * alpha.x);
+        }
+        __builtin_amdgcn_wave_barrier();  // one wave: LDS operations execute in order
+        if (lane < nk) {
+            float2 acc = make_float2(0.f, 0.f);
+#pragma unroll 8
+            for (int c = 0; c < 64; ++c) {
+                const float2 w = s_ws[lane * 65 + c];
+                acc.x += w.x;
+                acc.y += w.y;
+            }
+            out[(int64_t)blockIdx.x * num_freqs + k0 + lane] = acc;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+void launch_dot_tones(double f0, double fstep, int32_t num_freqs, int64_t len, const float2* src, float2* out,
+                      hipStream_t st) {
+    hipLaunchKernelGGL(k_dot_tones, dim3((unsigned)((len + 63) / 64)), dim3(64), 0, st, f0, fstep, num_freqs, len, src,
+                       out);
+}
+
 int64_t moving_num_tiles(int64_t n) { return (n + 1 + MA_TILE - 1) / MA_TILE; }
 
 void scan_tiles(double* tile_sums, int64_t ntiles, hipStream_t st);  // caf_kernels.hip

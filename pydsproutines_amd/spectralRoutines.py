@@ -151,4 +151,20 @@ def czt(x, f1, f2, binWidth, fs):
     return CZTCached(len(x), f1, f2, binWidth, fs, convertTo32fc=True).run(x)
 
 
-__all__ = ["next_fast_len", "prev_fast_len", "CZTCachedGPU", "CZTCached", "pbIppCZT32fc", "czt", "DeviceArray"]
+def cupyDotTonesScaling(f0, fstep, numFreqs, src):
+    """ref: spectralRoutines.py:580-630, genTones.cu:165-283 (`dotTonesScaling_32f`).  Dot products of the
+    tones exp(j 2 pi (f0 + k fstep) i) with ``src`` in blocks of 64 samples; returns the
+    (ceil(len / 64), numFreqs) complex64 interim array -- ``sum(axis=0)`` of it is the CZT of ``src`` at the
+    normalised frequencies -(f0 + k fstep) (the upstream docstring's comparison)."""
+    requireDeviceArray(src)
+    requireDtype(np.complex64, src)
+    length = src.size
+    nblocks = (length + 63) // 64
+    out = empty((nblocks, int(numFreqs)), np.complex64)
+    _lib.check(_lib.load().caf_dot_tones(ct.c_void_p(src.ptr), length, float(f0), float(fstep), int(numFreqs),
+                                         ct.c_void_p(out.ptr), None), "caf_dot_tones")
+    return out
+
+
+__all__ = ["next_fast_len", "prev_fast_len", "CZTCachedGPU", "CZTCached", "pbIppCZT32fc", "czt", "cupyDotTonesScaling",
+           "DeviceArray"]

@@ -354,7 +354,23 @@ def gen_finesearch():
          bounds=np.array([-2000.0, 2000.0]), gen_timediff=np.array([gtd]), gen_cost=gcost)
 
 
+def gen_dottones():
+    """dotTonesScaling_32f (cupy-only upstream): pinned by the identity of its own docstring,
+    sum over blocks == czt(src, f1, f2, fstep, fs) with f0 = -f1/fs, step = -fstep/fs."""
+    rng = np.random.default_rng(808)
+    fs, n = 1000.0, 1000  # 15 full blocks + one of 40 samples
+    src = cn(rng, n)
+    f1, f2, fstep = -20.0, 19.5, 0.5
+    ref = quiet(RS.czt, src.astype(np.complex128), f1, f2, fstep, fs)
+    k = ref.size
+    mine = O.kernels.dotTonesScaling(-f1 / fs, -fstep / fs, k, src).sum(axis=0)
+    print("dotTonesScaling (block sums vs reference czt), k=%d" % k)
+    report("  sum over blocks", ref, mine)
+    save("dottones", src=src, fs=np.array([fs]), f1f2step=np.array([f1, f2, fstep]), czt=ref)
+
+
 if __name__ == "__main__":
+    gen_dottones()
     gen_finesearch()
     gen_perm()
     gen_fastxcorr()

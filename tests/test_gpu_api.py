@@ -289,6 +289,33 @@ def test_finefreqtimesearch_and_genxcorr(golden):
     np.testing.assert_allclose(cost1, g["gen_cost"], atol=TOL)
 
 
+def test_dottones_scaling(golden):
+    """cupyDotTonesScaling (genTones.cu:165-283): block dot products against the oracle, their sum against the
+    reference's czt (the upstream docstring's check); a long frequency run shows the per-batch re-anchoring."""
+    from pydsproutines_amd import asarray
+    from pydsproutines_amd.spectralRoutines import cupyDotTonesScaling
+
+    g = golden("dottones")
+    f1, f2, step = g["f1f2step"]
+    fs = float(g["fs"][0])
+    k = g["czt"].size
+    d_out = cupyDotTonesScaling(-f1 / fs, -step / fs, k, asarray(g["src"]))
+    out = d_out.get()
+    assert out.shape == (16, k) and out.dtype == np.complex64
+    ref = K.dotTonesScaling(-f1 / fs, -step / fs, k, g["src"])
+    assert np.max(np.abs(out - ref)) <= 1e-4 * np.abs(ref).max()
+    assert np.max(np.abs(out.sum(axis=0) - g["czt"])) <= 1e-4 * np.abs(g["czt"]).max()
+    rng = np.random.default_rng(12)
+    src = cn(rng, 64 * 40 + 17)
+    kk = 1000
+    o2 = cupyDotTonesScaling(0.013, 0.00037, kk, asarray(src)).get()
+    r2 = K.dotTonesScaling(0.013, 0.00037, kk, src)
+    assert o2.shape == (41, kk)
+    assert np.max(np.abs(o2 - r2)) <= 1e-4 * np.abs(r2).max()  # no drift over 1000 frequencies
+    with pytest.raises(TypeError):
+        cupyDotTonesScaling(0.0, 0.1, 4, src)  # host array
+
+
 # ---- TemplateCrossCorrelator (the reference's own unit test) --------------------------------
 def test_kat4_template_cross_correlator(golden):
     from pydsproutines_amd import asarray

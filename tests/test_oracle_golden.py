@@ -224,6 +224,19 @@ def test_finefreqtimesearch_and_genxcorr(golden):
     assert td1 == gtd
 
 
+def test_dottones_block_sums_are_the_czt(golden):
+    g = golden("dottones")
+    f1, f2, step = g["f1f2step"]
+    fs = float(g["fs"][0])
+    out = O.kernels.dotTonesScaling(-f1 / fs, -step / fs, g["czt"].size, g["src"])
+    assert out.shape == (16, 80)
+    np.testing.assert_allclose(out.sum(axis=0), g["czt"], atol=1e-9)
+    # a block row is the dot product of its 64 samples only
+    i = np.arange(64, 128)
+    want = np.sum(g["src"][64:128].astype(np.complex128) * np.exp(2j * np.pi * (-(f1 + 3 * step) / fs) * i))
+    assert abs(out[1, 3] - want) < 1e-9
+
+
 def test_kernel_semantics_against_scipy():
     """The reference pins its kernels to scipy (filterRoutines.py:1256,1319,1358;
     benchmark_upfirdnkernels.py:58-67, benchmark_filterkernels.py:72-74)."""
