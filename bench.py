@@ -81,7 +81,13 @@ def cpu_baseline_same_algorithm(rx_host, tmpl_host, bins, budget_s=10.0):
     template spectra) as the oracle's scipy.fft restatement on ALL host cores, bounded sample of delays."""
     import oracle
 
-    cores = os.cpu_count() or 1
+    # threads actually usable: the scheduler affinity, capped at the 16-core share a one-GPU box gives
+    # (os.cpu_count() reports all 256 host threads there); BENCH_CPU_WORKERS overrides
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = int(os.environ.get("BENCH_CPU_WORKERS", min(cores, 16)))
     blk = 1 << 16
     step = blk - tmpl_host.size + 1
     seg = 4 * step + tmpl_host.size - 1  # four overlap-save blocks per call
