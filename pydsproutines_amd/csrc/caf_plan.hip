@@ -46,6 +46,8 @@ struct caf_plan_t {
     float2* d_tw1 = nullptr;
     float2* d_tw23 = nullptr;
     FftPlan fwd, inv;
+    hipStream_t s_aux = nullptr;  // sliding-energy pass beside gather + forward FFTs
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int64_t workspace_bytes = 0;
     // profiling
     bool prof = false;
@@ -107,6 +109,9 @@ struct caf_plan_t {
         pool.clear();
         fwd.destroy();
         inv.destroy();
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        if (s_aux) (void)hipStreamDestroy(s_aux);
         void* ptrs[] = {d_hc,  d_shifts, d_tscale, d_gstart,  d_glen, d_tile_sums, d_prefix, d_inv_e,
                         d_xb,  d_pbuf,   d_partial, d_vt,     d_tw1,  d_tw23,      d_params, d_pq};
         for (void* p : ptrs)
@@ -411,6 +416,12 @@ static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
     if ((rc = p->fwd.create(false, (size_t)B, (size_t)p->fwd_chunk, (size_t)B))) return rc;
     if (!p->fused && (rc = p->inv.create(true, (size_t)B, (size_t)nb * T * F, (size_t)p->pitch))) return rc;
     p->workspace_bytes += (int64_t)p->fwd.work_bytes + (int64_t)p->inv.work_bytes;
+    const char* aux = getenv("CAF_AUX_STREAM");  // A/B switch, default on
+    if (!aux || atoi(aux)) {
+        CAF_HIP_TRY(hipStreamCreateWithFlags(&p->s_aux, hipStreamNonBlocking));
+        CAF_HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+        CAF_HIP_TRY(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
+    }
     return CAF_OK;
 }
 
@@ -487,10 +498,19 @@ int32_t caf_plan_execute(caf_plan p, const float* d_rx, int64_t rx_len, int64_t 
     const int T = p->T, F = p->F;
     const bool want_peak = out->d_peak_val || out->d_peak_delay || out->d_peak_freq;
 
-    p->stage_begin(0, st);
-    launch_energy_prefix(rx, rx_len, p->d_tile_sums, p->d_prefix, st);
-    launch_inv_energy(p->d_prefix, shift_start, num_shifts, p->d_gstart, p->d_glen, p->G, p->d_inv_e, st);
-    p->stage_end(st);
+    // The sliding-energy pass is independent of the block spectra: it runs on the plan's auxiliary stream beside
+    // gather + forward FFTs (small memory-bound kernels that do not fill the chip one at a time) and is joined
+    // before the first consumer of inv_e.
+    hipStream_t se = p->s_aux ? p->s_aux : st;
+    if (p->s_aux) {
+        CAF_HIP_TRY(hipEventRecord(p->ev_fork, st));
+        CAF_HIP_TRY(hipStreamWaitEvent(p->s_aux, p->ev_fork, 0));
+    }
+    p->stage_begin(0, se);
+    launch_energy_prefix(rx, rx_len, p->d_tile_sums, p->d_prefix, se);
+    launch_inv_energy(p->d_prefix, shift_start, num_shifts, p->d_gstart, p->d_glen, p->G, p->d_inv_e, se);
+    p->stage_end(se);
+    if (p->s_aux) CAF_HIP_TRY(hipEventRecord(p->ev_join, p->s_aux));
 
     const int64_t nblk = (num_shifts + p->step - 1) / p->step;
     const int64_t nblk_pad = (nblk + p->nb - 1) / p->nb * p->nb;
@@ -505,6 +525,7 @@ int32_t caf_plan_execute(caf_plan p, const float* d_rx, int64_t rx_len, int64_t 
         p->stage_end(st);
         if (rc) return rc;
     }
+    if (p->s_aux) CAF_HIP_TRY(hipStreamWaitEvent(st, p->ev_join, 0));
     if (p->fused) {
         CAF_REQUIRE(!out->d_cqf, "the fused engine has no complex-QF output (create the plan with CAF_ENGINE_ROCFFT)");
         for (int64_t b0 = 0; p->persistent && b0 < nblk; b0 += p->nb) {
