@@ -41,3 +41,41 @@ def simpleBinRead(filename, numSamps=-1, in_dtype=np.int16, out_dtype=np.complex
     # other on-disk types are plain host reinterpretation (no arithmetic involved)
     data = np.fromfile(filename, dtype=in_dtype, count=numSamps * 2 if numSamps >= 0 else -1, offset=offset)
     return data.astype(np.float32 if out_dtype == np.complex64 else np.float64).view(out_dtype)
+
+
+def multiBinRead(filenames, numSamps, in_dtype=np.int16, out_dtype=np.complex64, offset=0):
+    """ref: usrpRoutines.py:70-84.  Concatenated recordings, numSamps complex samples of each."""
+    alldata = np.zeros(len(filenames) * numSamps, out_dtype)
+    for i, fn in enumerate(filenames):
+        alldata[i * numSamps : (i + 1) * numSamps] = simpleBinRead(fn, numSamps, in_dtype, out_dtype, offset=offset)
+    return alldata
+
+
+def multiBinReadThreaded(filenames, numSamps, in_dtype=np.int16, out_dtype=np.complex64, offset=0, threads=2):
+    """ref: usrpRoutines.py:87-114.  The disk reads run in ``threads`` workers; the int16 -> complex64
+    conversions are issued from the calling thread (one device context) as the raw buffers arrive."""
+    import concurrent.futures
+
+    if in_dtype == np.complex64 or in_dtype == np.complex128:
+        raise TypeError("in_dtype must be a real type. You likely want float32 or float64 instead.")
+    alldata = np.zeros(len(filenames) * numSamps, out_dtype)
+    with concurrent.futures.ThreadPoolExecutor(max_workers=threads) as executor:
+        futs = {futureBinRead(executor, fn, numSamps, in_dtype, offset): i for i, fn in enumerate(filenames)}
+        for fut in concurrent.futures.as_completed(futs):
+            i = futs[fut]
+            raw = fut.result()
+            if in_dtype == np.int16 and out_dtype == np.complex64:
+                alldata[i * numSamps : (i + 1) * numSamps] = iq16_to_complex64(asarray(raw)).get()
+            else:
+                alldata[i * numSamps : (i + 1) * numSamps] = raw.astype(
+                    np.float32 if out_dtype == np.complex64 else np.float64).view(out_dtype)
+    return alldata
+
+
+def futureBinRead(executor, filename, numSamps, in_dtype=np.int16, offset=0):
+    """ref: usrpRoutines.py:117-156.  Submits the raw read (2 * numSamps values of ``in_dtype``) to an existing
+    ThreadPoolExecutor; ``future.result()`` is the interleaved array, ready for ``iq16_to_complex64(asarray(.))``
+    while the next file is already loading."""
+    if in_dtype == np.complex64 or in_dtype == np.complex128:
+        raise TypeError("in_dtype must be a real type. You likely want float32 or float64 instead.")
+    return executor.submit(np.fromfile, filename, dtype=in_dtype, count=numSamps * 2, offset=offset)

@@ -75,3 +75,24 @@ def test_iq16_ingest(tmp_path):
         simpleBinRead(str(p), in_dtype=np.complex64)
     with pytest.raises(TypeError):
         iq16_to_complex64(asarray(raw.astype(np.int32)))
+    # multi-file and prefetching readers (usrpRoutines.py:70-156)
+    import concurrent.futures
+
+    from pydsproutines_amd.usrpRoutines import futureBinRead, multiBinRead, multiBinReadThreaded
+
+    files = []
+    want = []
+    for i in range(3):
+        r = rng.integers(-3000, 3000, 2 * 700, dtype=np.int16)
+        q = tmp_path / ("f%d.bin" % i)
+        r.tofile(q)
+        files.append(str(q))
+        want.append(r[:2 * 500].astype(np.float32).view(np.complex64))
+    want = np.concatenate(want)
+    np.testing.assert_array_equal(multiBinRead(files, 500), want)
+    np.testing.assert_array_equal(multiBinReadThreaded(files, 500, threads=2), want)
+    with concurrent.futures.ThreadPoolExecutor(max_workers=1) as ex:
+        fut = futureBinRead(ex, files[1], 500)
+        np.testing.assert_array_equal(iq16_to_complex64(asarray(fut.result())).get(), want[500:1000])
+        with pytest.raises(TypeError):
+            futureBinRead(ex, files[0], 10, in_dtype=np.complex64)
