@@ -773,7 +773,9 @@ __device__ __attribute__((noinline)) void transpose_wave_f1(const PersistParams*
         for (int i = 0; i < TW_H / 4; ++i) {
             const int h = h0 + 4 * i + fq;
             const bool hv = h < nhyp;
-            const float x[4] = {q[i].x * g[0] * ts[i], q[i].y * g[1] * ts[i], q[i].z * g[2] * ts[i], q[i].w * g[3] * ts[i]};
+            // (value * (1/energy * 1/||t||^2): the same rounding as the other paths)
+            const float x[4] = {q[i].x * (g[0] * ts[i]), q[i].y * (g[1] * ts[i]), q[i].z * (g[2] * ts[i]),
+                                q[i].w * (g[3] * ts[i])};
             if (hv && nrows > 0) {
                 const int64_t o = (int64_t)h * num_shifts + rel0 + s4;
                 if (all4) {
