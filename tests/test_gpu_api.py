@@ -316,6 +316,28 @@ def test_dottones_scaling(golden):
         cupyDotTonesScaling(0.0, 0.1, 4, src)  # host array
 
 
+def test_integration_md_stub_runs(golden):
+    """The reference-side ctypes stub printed in INTEGRATION.md is executed as written (next to libcaf.so)
+    and checked against the golden CAF: documentation that cannot rot."""
+    import os
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    blocks = [b for b in re.findall(r"```python\n(.*?)```", text, flags=re.S) if "def cafSurface" in b]
+    assert len(blocks) == 1
+    ns = {"__file__": os.path.join(root, "pydsproutines_amd", "cafDll.py"), "__name__": "cafDll"}
+    exec(compile(blocks[0], "INTEGRATION.md", "exec"), ns)
+    g = golden("c2_mini")
+    surf, rmax, rarg, (pd, pf, pv) = ns["cafSurface"](g["template"], g["rx"], g["bins"], g["template"].size)
+    sh = g["shifts"]
+    assert np.max(np.abs(surf[sh] - g["caf"])) <= 1e-4 * g["caf"].max()
+    assert (pd, int(g["bins"][pf])) == (int(g["d0"][0]), int(g["k0"][0]))
+    np.testing.assert_array_equal(rmax, surf.max(axis=1))
+    np.testing.assert_array_equal(rarg, np.argmax(surf, axis=1))
+    assert abs(pv - surf.max()) == 0.0
+
+
 # ---- TemplateCrossCorrelator (the reference's own unit test) --------------------------------
 def test_kat4_template_cross_correlator(golden):
     from pydsproutines_amd import asarray
