@@ -327,9 +327,17 @@ def test_integration_md_stub_runs(golden):
     blocks = [b for b in re.findall(r"```python\n(.*?)```", text, flags=re.S) if "def cafSurface" in b]
     assert len(blocks) == 1
     ns = {"__file__": os.path.join(root, "pydsproutines_amd", "cafDll.py"), "__name__": "cafDll"}
-    exec(compile(blocks[0], "INTEGRATION.md", "exec"), ns)
+    from pydsproutines_amd import _lib
+
     g = golden("c2_mini")
-    surf, rmax, rarg, (pd, pf, pv) = ns["cafSurface"](g["template"], g["rx"], g["bins"], g["template"].size)
+    try:
+        exec(compile(blocks[0], "INTEGRATION.md", "exec"), ns)
+        surf, rmax, rarg, (pd, pf, pv) = ns["cafSurface"](g["template"], g["rx"], g["bins"], g["template"].size)
+    finally:
+        # ctypes caches one CDLL object per path: the stub has put its own argtypes on the shared function
+        # objects, so the package's signature table is applied again
+        _lib._lib = None
+        _lib.load()
     sh = g["shifts"]
     assert np.max(np.abs(surf[sh] - g["caf"])) <= 1e-4 * g["caf"].max()
     assert (pd, int(g["bins"][pf])) == (int(g["d0"][0]), int(g["k0"][0]))
