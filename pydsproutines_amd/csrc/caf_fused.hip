@@ -123,7 +123,10 @@ __device__ __forceinline__ void idft16(float2 (&v)[16]) {
 // threads of a workgroup.  s_d / s_tw2 / s_tw3 are the caller's LDS arrays (the tables already loaded and
 // published by a barrier, or by the first barrier inside the loop).  Shared by the one-item-per-workgroup
 // kernel k_fused_caf and by the work-queue kernel k_caf_persistent.
-template <int FT, bool WT = false>
+// MODE 0: |y|^2 tiles with plain stores; 1: with write-through (sc1) stores; 2: no tiles at all -- every thread
+// keeps the running maximum (value + hypothesis) of its 16 delays over the item's hypotheses and writes one
+// (value, hypothesis) pair per delay at the end (callers that want no surface: per-delay traces and peaks only).
+template <int FT, int MODE = 0>
 __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float2* __restrict__ s_tw2,
                                            const float2* __restrict__ s_tw3,
                                            const float2* __restrict__ xb,       // [blocks][FB] spectra
@@ -131,9 +134,19 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
                                            const int32_t* __restrict__ shifts,  // [F] (shift modes)
                                            const float2* __restrict__ tw1,      // [16][1024]
                                            int32_t table_mode, int32_t nfreq, int32_t nhyp, int blk, int h0, int h1,
-                                           int32_t tiles_per_blk, float* __restrict__ vt) {
+                                           int32_t tiles_per_blk, float* __restrict__ vt,
+                                           int32_t* __restrict__ imax = nullptr) {
     constexpr int BPT = 1024 / FT;
+    static_assert(MODE != 2 || BPT == 1, "the running-maximum mode is written for one butterfly per thread");
     const int tid = threadIdx.x;
+    float bv[16];     // MODE 2: running maxima of this thread's 16 delays ...
+    uint32_t bi[4];   // ... and the item-local hypothesis (8 bits each) that produced them
+    if (MODE == 2) {
+#pragma unroll
+        for (int o = 0; o < 16; ++o) bv[o] = -1.f;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) bi[o] = 0u;
+    }
 
     // hypothesis-independent per-thread state: the pass-1 twiddle base e^{+j 2 pi m2 / 16384}
     float2 w[BPT];
@@ -241,11 +254,13 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
         // next hypothesis' template-spectrum row: issued before pass 3 so that the L2 latency is covered by
         // the pass-3 butterfly and the pass-4 work
         float2 hn[BPT][16];
+        if (MODE != 2) {
 #pragma unroll
-        for (int j = 0; j < BPT; ++j)
+            for (int j = 0; j < BPT; ++j)
 #pragma unroll
-            for (int a = 0; a < 16; ++a)
-                hn[j][a] = ld2(hrow_cur, (uint32_t)(((1024 * a + tid + j * FT - sh_cur) & (FB - 1)) + lz));
+                for (int a = 0; a < 16; ++a)
+                    hn[j][a] = ld2(hrow_cur, (uint32_t)(((1024 * a + tid + j * FT - sh_cur) & (FB - 1)) + lz));
+        }
         // ---- pass 3: DFT16 over c, in place (n1 = idx >> 6, n2 = (idx >> 2) & 15, d = idx & 3) ----
         {
             float2 v[BPT][16];
@@ -266,6 +281,15 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
 #pragma unroll
                 for (int n3 = 0; n3 < 16; ++n3) s_d[base + 4 * n3] = v[j][n3];
             }
+        }
+        if (MODE == 2) {
+            // (the 20 registers of the running maxima leave no room for the row during pass 3: it is fetched here,
+            // under the barrier and the pass-4 work; there are no tile stores to compete with in this mode)
+#pragma unroll
+            for (int j = 0; j < BPT; ++j)
+#pragma unroll
+                for (int a = 0; a < 16; ++a)
+                    hn[j][a] = ld2(hrow_cur, (uint32_t)(((1024 * a + tid + j * FT - sh_cur) & (FB - 1)) + lz));
         }
         __syncthreads();
         // ---- pass 4: DFT4 over d ; |y|^2 -> vt tiles (lanes <-> consecutive delays) ----
@@ -297,11 +321,22 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
                     const int tile_t = (n2 >> 2) + 4 * q;                     // per-thread part
                     float* pu = vt_blk + (int64_t)tile_u * nhyp * 64 + hoff;  // uniform (scalar) base
                     const uint32_t voff = ((uint32_t)tile_t * (uint32_t)nhyp * 64u + (uint32_t)(n1 + 16 * (n2 & 3))) << 2;
-                    if (tile_u + tile_t < tiles_per_blk) {
-                        if (WT)
-                            gst1_wt(pu, voff, y[n4].x * y[n4].x + y[n4].y * y[n4].y);
+                    const float val = y[n4].x * y[n4].x + y[n4].y * y[n4].y;
+                    if (MODE == 2) {
+                        // hypotheses come in increasing order: the first maximum stays (NaN never enters)
+                        constexpr int o = 0;  // (placeholder, see below)
+                        (void)o;
+                        const int oo = 4 * i + n4;
+                        const bool up = val > bv[oo];
+                        bv[oo] = up ? val : bv[oo];
+                        const uint32_t sh8 = 8u * (uint32_t)(oo & 3);
+                        const uint32_t repl = (bi[oo >> 2] & ~(0xffu << sh8)) | ((uint32_t)(h - h0) << sh8);
+                        bi[oo >> 2] = up ? repl : bi[oo >> 2];
+                    } else if (tile_u + tile_t < tiles_per_blk) {
+                        if (MODE == 1)
+                            gst1_wt(pu, voff, val);
                         else
-                            gst1(pu, voff, y[n4].x * y[n4].x + y[n4].y * y[n4].y);
+                            gst1(pu, voff, val);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);  // keep the four sub-steps from being co-scheduled (registers)
@@ -310,6 +345,24 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
             for (int a = 0; a < 16; ++a) pr[j][a] = cmul(xr[j][a], hn[j][a]);
             __builtin_amdgcn_sched_barrier(0);
         }
+    }
+    if (MODE == 2) {
+        // one (value, hypothesis) pair per delay of the block, in 64-delay tiles: vt[tile][64], imax[tile][64]
+        const int n1 = tid & 15, n2 = (tid >> 4) & 15, q = tid >> 8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int n4 = 0; n4 < 4; ++n4) {
+                const int tile = 16 * i + 64 * n4 + (n2 >> 2) + 4 * q;
+                const int oo = 4 * i + n4;
+                if (tile < tiles_per_blk) {
+                    const uint32_t off = ((uint32_t)tile * 64u + (uint32_t)(n1 + 16 * (n2 & 3))) << 2;
+                    gst1_wt(vt, off, bv[oo]);
+                    __hip_atomic_store(reinterpret_cast<CAF_AS1 int32_t*>((CAF_AS1 char*)imax + off),
+                                       (int32_t)(h0 + ((bi[oo >> 2] >> (8 * (oo & 3))) & 0xffu)), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
     }
 }
 
@@ -825,6 +878,89 @@ __device__ __attribute__((noinline)) void transpose_wave_f1(const PersistParams*
     }
 }
 
+// Tile role when no surface is wanted (PersistParams::nosurf): the FFT items have left one (maximum |y|^2,
+// hypothesis) pair per delay and hypothesis group; a wave takes a 64-delay tile (lane = delay), combines the
+// groups of each template (increasing hypothesis order: the first maximum wins, as everywhere), normalises, and
+// writes the per-delay trace and the tile's peak record.  Groups never straddle templates (nfreq is a multiple of
+// the group size in this mode), and value * (1/energy * 1/||t||^2) rounds exactly as in the surface paths.
+__device__ __attribute__((noinline)) void reduce_wave_nosurf(const PersistParams* pp_in, int z_in, int tile0_in) {
+    const PersistParams* pp = uniform_ptr(pp_in);
+    const int z = __builtin_amdgcn_readfirstlane(z_in), tile0 = __builtin_amdgcn_readfirstlane(tile0_in);
+    const CAF_AS4 PersistParams* P = params_of(pp);
+    const int32_t ntmpl = P->ntmpl, nfreq = P->nfreq, step = P->step, tiles_per_blk = P->tiles_per_blk;
+    const int32_t ngroups = P->ngroups, gpt = nfreq / P->hyp_per_wg;
+    const int64_t num_shifts = P->num_shifts, shift_start = P->shift_start;
+    const int wave_id = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const int tile = tile0 + wave_id;
+    if (tile >= tiles_per_blk) return;
+    const int blk = P->blk0 + z;
+    const int sl0 = tile * 64;
+    const int64_t rel0 = (int64_t)blk * step + sl0;
+    int64_t nv = num_shifts - (int64_t)blk * step;
+    if (nv > step) nv = step;
+    const int nrows = sl0 < nv ? (int)min((int64_t)64, nv - sl0) : 0;
+    const int64_t pidx = (int64_t)blk * tiles_per_blk + tile;
+    PeakRec* partial = P->partial;
+    const int64_t ppt = P->partial_per_tmpl;
+    float* row_max = P->row_max;
+    int32_t* row_arg = P->row_arg;
+    const bool live = lane < nrows;
+    const float ie = live ? P->inv_e[rel0 + lane] : 0.f;
+    const uint32_t group_bytes = (uint32_t)tiles_per_blk * 256u;  // one (block, group): tiles x 64 floats
+    for (int t = 0; t < ntmpl; ++t) {
+        const int64_t g0 = (int64_t)z * ngroups + (int64_t)t * gpt;
+        const __amdgpu_buffer_rsrc_t rv = buf_of(uniform_ptr(P->vmax + g0 * tiles_per_blk * 64), group_bytes * (uint32_t)gpt);
+        const __amdgpu_buffer_rsrc_t ri = buf_of(uniform_ptr(P->imax + g0 * tiles_per_blk * 64), group_bytes * (uint32_t)gpt);
+        float bv = -1.f;
+        int32_t bh = 0;
+        for (int g = 0; g < gpt; ++g) {
+            const int voff = (tile * 64 + lane) * 4;
+            const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, voff, g * (int)group_bytes, CAF_AUX_SC1));
+            const int32_t hh = __builtin_amdgcn_raw_buffer_load_b32(ri, voff, g * (int)group_bytes, CAF_AUX_SC1);
+            if (v > bv) {
+                bv = v;
+                bh = hh;
+            }
+        }
+        const float x = bv * (ie * P->tscale[t]);
+        const int32_t f = bh - t * nfreq;
+        float best = -1.f;
+        int32_t bdel = 0x7fffffff, bfrq = 0;
+        if (live) {
+            const int64_t o = (int64_t)t * num_shifts + rel0 + lane;
+            const float xv = bv < 0.f ? -1.f : x;  // (no hypothesis beat the initial value: all NaN)
+            if (row_max) row_max[o] = xv;
+            if (row_arg) row_arg[o] = bv < 0.f ? 0 : f;
+            if (xv > best) {
+                best = xv;
+                bdel = lane;
+                bfrq = bv < 0.f ? 0 : f;
+            }
+        }
+        if (partial) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(best, o, 64);
+                const int32_t od = __shfl_xor(bdel, o, 64);
+                const int32_t of = __shfl_xor(bfrq, o, 64);
+                if (ov > best || (ov == best && od < bdel)) {
+                    best = ov;
+                    bdel = od;
+                    bfrq = of;
+                }
+            }
+            if (lane == 0) {
+                PeakRec r;
+                r.v = best;
+                r.delay = bdel != 0x7fffffff ? (int32_t)(shift_start + rel0 + bdel) : 0x7fffffff;
+                r.f = bfrq;
+                partial[(int64_t)t * ppt + pidx] = r;
+            }
+        }
+    }
+}
+
 // waits (bounded) until every hypothesis group of the block of tile item `item` is published
 __device__ __forceinline__ void pq_wait_block(int32_t* pq, int item, int ipb, int ngroups, bool lane0) {
     // The block's FFT items are either running on resident workgroups or still in the FFT queue, which the
@@ -863,7 +999,9 @@ __device__ __attribute__((noinline)) void persistent_tile_run(lds_float* lds_in,
         const CAF_AS4 PersistParams* P = params_of(pp);
         const int ipb = P->ipb;
         const int z = item / ipb;
-        if (P->nfreq == 1)
+        if (P->nosurf)
+            reduce_wave_nosurf(pp, z, (item - z * ipb) * PQ_TILES);
+        else if (P->nfreq == 1)
             transpose_wave_f1(pp, z, (item - z * ipb) * PQ_TILES);
         else if (P->surface)
             transpose_wave<true>(lds, pp, z, (item - z * ipb) * PQ_TILES);
@@ -905,6 +1043,7 @@ __device__ __forceinline__ void pq_mark(const PersistParams* pp, int slot, int v
 // spilled values every hypothesis).  Called ~21 times per workgroup: the call and the callee-saved register
 // traffic are negligible.  Arguments arrive in VGPRs; v_readfirstlane makes them scalar again.
 typedef __attribute__((address_space(3))) float2 lds_float2;
+template <bool NOSURF>
 __device__ __attribute__((noinline)) void persistent_fft_item(lds_float2* s_d, const lds_float2* s_tw2,
                                                               const lds_float2* s_tw3, const PersistParams* pp_in,
                                                               int item_in) {
@@ -916,9 +1055,16 @@ __device__ __attribute__((noinline)) void persistent_fft_item(lds_float2* s_d, c
     const int grp = item - blk * ngroups;
     const int h0 = grp * hyp_per_wg;
     const int h1 = min(h0 + hyp_per_wg, nhyp);
-    // the |y|^2 tiles are stored write-through (sc1): device-visible once the store has completed
-    fused_item<1024, true>((float2*)s_d, (const float2*)s_tw2, (const float2*)s_tw3, P->xb, P->hc, P->shifts, P->tw1,
-                           P->table_mode, P->nfreq, nhyp, blk, h0, h1, P->tiles_per_blk, P->vt);
+    if (NOSURF) {
+        // no surface wanted: one (maximum, hypothesis) pair per delay and item instead of the |y|^2 tiles
+        const int64_t o = ((int64_t)blk * ngroups + grp) * P->tiles_per_blk * 64;
+        fused_item<1024, 2>((float2*)s_d, (const float2*)s_tw2, (const float2*)s_tw3, P->xb, P->hc, P->shifts, P->tw1,
+                            P->table_mode, P->nfreq, nhyp, blk, h0, h1, P->tiles_per_blk, P->vmax + o, P->imax + o);
+    } else {
+        // the |y|^2 tiles are stored write-through (sc1): device-visible once the store has completed
+        fused_item<1024, 1>((float2*)s_d, (const float2*)s_tw2, (const float2*)s_tw3, P->xb, P->hc, P->shifts, P->tw1,
+                            P->table_mode, P->nfreq, nhyp, blk, h0, h1, P->tiles_per_blk, P->vt);
+    }
     // publish: every wave waits for its own stores (workgroup-scope release = s_waitcnt vmcnt(0); an
     // agent-scope release would add an L2 write-back per item, which stalls the 32 CUs sharing that L2:
     // measured +30 % on every FFT item), then one thread counts the group in
@@ -1023,7 +1169,10 @@ __global__ __launch_bounds__(1024) void k_caf_persistent(const PersistParams* __
             break;
         }
         if (kind == 1) {
-            persistent_fft_item((lds_float2*)s_d, (const lds_float2*)s_tw2, (const lds_float2*)s_tw3, pp, item);
+            if (__builtin_amdgcn_readfirstlane(params_of(pp)->nosurf))
+                persistent_fft_item<true>((lds_float2*)s_d, (const lds_float2*)s_tw2, (const lds_float2*)s_tw3, pp, item);
+            else
+                persistent_fft_item<false>((lds_float2*)s_d, (const lds_float2*)s_tw2, (const lds_float2*)s_tw3, pp, item);
             if (STATS) {
                 const uint64_t now = wall_clock64();
                 t_fft += (uint32_t)(now - tmark);

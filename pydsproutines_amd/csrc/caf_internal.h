@@ -127,7 +127,10 @@ struct PersistParams {
     int64_t partial_per_tmpl;
     // queues: pq[0] next FFT item, pq[1] next tile item, pq[4 + b] finished hypothesis groups of block b
     int32_t* pq;
-    int32_t tr_slots, ngroups, n_fft, ipb, n_tr, pad1;
+    int32_t tr_slots, ngroups, n_fft, ipb, n_tr;
+    int32_t nosurf;  // 1: no |y|^2 tiles; per item one (maximum, hypothesis) pair per delay in vmax / imax
+    float* vmax;     // [block][group][tile][64]
+    int32_t* imax;
     int32_t* dbg;  // optional host-mapped progress marks (CAF_PERSIST_DEBUG), 4 ints per workgroup
 };
 // copies *h to d_params, clears the queue block and launches n_wgs resident workgroups

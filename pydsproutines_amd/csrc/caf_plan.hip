@@ -562,6 +562,18 @@ int32_t caf_plan_execute(caf_plan p, const float* d_rx, int64_t rx_len, int64_t 
             h.n_fft = nbk * h.ngroups;
             h.ipb = (p->tiles_per_blk + 15) / 16;  // 16 tiles per item (PQ_TILES, caf_fused.hip)
             h.n_tr = nbk * h.ipb;
+            // No surface wanted (per-delay traces / peaks only) and hypothesis groups that do not straddle
+            // templates: the FFT items keep running per-delay maxima and write one (value, hypothesis) pair per
+            // delay and group instead of the |y|^2 tiles (1/32 of the bytes at 64 hypotheses per group).
+            // The pairs live in the tile buffer: vmax [block][group][tile][64] f32, then imax (same shape, i32).
+            {
+                const char* e = getenv("CAF_PERSIST_NOSURF");  // A/B switch, default on
+                // the two pair arrays must fit the tile buffer they replace (true for >= 2 hypotheses per group)
+                const bool fits = 2 * (int64_t)h.ngroups <= (int64_t)T * F;
+                h.nosurf = (!out->d_surface && fits && F % p->hyp_per_wg == 0 && (!e || atoi(e))) ? 1 : 0;
+                h.vmax = p->d_vt;
+                h.imax = reinterpret_cast<int32_t*>(p->d_vt + (int64_t)p->nb * h.ngroups * p->tiles_per_blk * 64);
+            }
             // both stages are one kernel: its time is booked on the multiply/FFT stage
             int32_t* h_dbg = nullptr;
             if (getenv("CAF_PERSIST_DEBUG")) {  // host-mapped role statistics, 8 ints per workgroup

@@ -62,6 +62,15 @@ def test_random_shapes_all_engines(seed):
         r = plan.run(d_rx, shift_start=c["lo"], num_shifts=c["cnt"], surface=True)
         out[engine] = (r.surface.get(), r.row_max.get(), r.row_arg.get(), r.peak_val.get(), r.peak_delay.get(),
                        r.peak_freq.get())
+        # the same call without a surface (the persistent engine then keeps running maxima instead of tiles
+        # where the hypothesis groups allow it): identical per-delay results and peaks
+        r2 = plan.run(d_rx, shift_start=c["lo"], num_shifts=c["cnt"], surface=False, rows=True, peak=True)
+        for a, b in zip(out[engine][1:], (r2.row_max.get(), r2.row_arg.get(), r2.peak_val.get(), r2.peak_delay.get(),
+                                          r2.peak_freq.get())):
+            np.testing.assert_array_equal(a, b)
+        r3 = plan.run(d_rx, shift_start=c["lo"], num_shifts=c["cnt"], surface=False, rows=False, peak=True)
+        np.testing.assert_array_equal(r3.peak_delay.get(), out[engine][4])
+        np.testing.assert_array_equal(r3.peak_val.get(), out[engine][3])
         plan.close()
     sp, rmp, rap, pvp, pdp, pfp = out["persistent"]
     for a, b in zip(out["persistent"], out["fused"]):
