@@ -312,6 +312,14 @@ static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p->device);
         const int64_t want = ((int64_t)T * F * total_blocks + 2 * cus - 1) / (2 * cus);
         p->hyp_per_wg = (int)std::min<int64_t>(p->hyp_per_wg, std::max<int64_t>(4, want));
+        // groups that do not straddle templates allow the no-surface mode (running maxima instead of tiles):
+        // prefer the largest divisor of F that is not much smaller than the group size chosen above
+        if (F % p->hyp_per_wg != 0)
+            for (int dv = p->hyp_per_wg; dv >= std::max(4, p->hyp_per_wg / 3); --dv)
+                if (F % dv == 0) {
+                    p->hyp_per_wg = dv;
+                    break;
+                }
     }
 
     // device buffers
