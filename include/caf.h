@@ -50,8 +50,14 @@ CAF_EXPORT int32_t caf_device_count(int32_t* count);
 CAF_EXPORT int32_t caf_set_device(int32_t device);
 CAF_EXPORT int32_t caf_device_info(int32_t device, char* name, int32_t name_len, int64_t* total_mem,
                                    int32_t* compute_units);
+/* caf_malloc / caf_free go through a caching allocator (the counterpart of cupy's default memory pool, which
+ * every cp.empty / cp.zeros of the reference's wrappers hits): freed blocks are kept and reused in stream order;
+ * CAF_POOL_MB bounds the cached bytes (default 8192, 0 = plain hipMalloc / hipFree).  caf_pool_trim returns the
+ * cache to the driver (cp.get_default_memory_pool().free_all_blocks()). */
 CAF_EXPORT int32_t caf_malloc(void** d_ptr, int64_t bytes);
 CAF_EXPORT int32_t caf_free(void* d_ptr);
+CAF_EXPORT int32_t caf_pool_trim(void);
+CAF_EXPORT int32_t caf_pool_stats(int64_t* cached_bytes, int64_t* in_use_bytes, int64_t* hits, int64_t* misses);
 CAF_EXPORT int32_t caf_memset(void* d_ptr, int32_t value, int64_t bytes, void* stream);
 CAF_EXPORT int32_t caf_h2d(void* d_dst, const void* h_src, int64_t bytes, void* stream);
 CAF_EXPORT int32_t caf_d2h(void* h_dst, const void* d_src, int64_t bytes, void* stream);

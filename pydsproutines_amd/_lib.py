@@ -97,6 +97,8 @@ _SIGNATURES = {
     "caf_device_info": [_I32, ct.c_char_p, _I32, ct.POINTER(_I64), ct.POINTER(_I32)],
     "caf_malloc": [ct.POINTER(_P), _I64],
     "caf_free": [_P],
+    "caf_pool_trim": [],
+    "caf_pool_stats": [ct.POINTER(_I64), ct.POINTER(_I64), ct.POINTER(_I64), ct.POINTER(_I64)],
     "caf_memset": [_P, _I32, _I64, _P],
     "caf_h2d": [_P, _P, _I64, _P],
     "caf_d2h": [_P, _P, _I64, _P],

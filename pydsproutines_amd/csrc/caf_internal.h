@@ -31,6 +31,12 @@ void set_error(const std::string& msg);
         }                                                                                          \
     } while (0)
 
+// caching device allocator (caf_pool.hip)
+int pool_alloc(void** out, int64_t bytes);
+int pool_free(void* p);
+void pool_trim();
+void pool_stats(int64_t* cached, int64_t* in_use, int64_t* hits, int64_t* misses);
+
 int64_t prefix_num_tiles(int64_t m);
 void launch_energy_prefix(const float2* rx, int64_t m, double* tile_sums, double* prefix, hipStream_t st);
 void launch_inv_energy(const double* prefix, int64_t shift_start, int64_t num_shifts, const int32_t* gstart,
@@ -60,6 +66,9 @@ void launch_magnsq(const void* x, int64_t n, int in_c128, void* out, int out_f64
 int64_t moving_num_tiles(int64_t n);
 void launch_moving_average(const float* x, int64_t n, int32_t L, int32_t sum_instead, double* tile_sums,
                            double* prefix, float* out, hipStream_t st);
+int moving_tile_max_window();
+void launch_moving_tile(const float* x, int64_t rows, int64_t n, int32_t L, int32_t sum_instead, float* out,
+                        hipStream_t st);
 void launch_complex_moving_sum(const float2* x, int64_t n, int32_t L, float* out, hipStream_t st);
 void launch_multi_template_dot(const float2* tm, const float* te, int32_t ntm, int32_t L, const float2* x, int64_t xlen,
                                const double* prefix, int64_t start, int64_t nslides, int32_t* tidx, float* qf2,

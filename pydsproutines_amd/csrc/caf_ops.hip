@@ -75,13 +75,14 @@ struct Scratch {
     template <typename T>
     int get(T** p, int64_t count) {
         void* q = nullptr;
-        CAF_HIP_TRY(hipMalloc(&q, (size_t)std::max<int64_t>(count * (int64_t)sizeof(T), 16)));
+        const int rc = pool_alloc(&q, std::max<int64_t>(count * (int64_t)sizeof(T), 16));
+        if (rc) return rc;
         ptrs.push_back(q);
         *p = (T*)q;
         return CAF_OK;
     }
     ~Scratch() {
-        for (void* q : ptrs) (void)hipFree(q);
+        for (void* q : ptrs) (void)pool_free(q);
     }
 };
 
@@ -225,6 +226,11 @@ int32_t caf_moving_average(const float* d_x, int64_t rows, int64_t n, int32_t av
                            float* d_out, void* stream) {
     CAF_REQUIRE(d_x && d_out && rows >= 1 && n >= 1 && avg_length >= 1, "caf_moving_average: bad arguments");
     hipStream_t st = (hipStream_t)stream;
+    if (avg_length <= moving_tile_max_window() && rows <= 65535) {  // one launch, no scratch, asynchronous
+        launch_moving_tile(d_x, rows, n, avg_length, sum_instead, d_out, st);
+        CAF_HIP_TRY(hipGetLastError());
+        return CAF_OK;
+    }
     Scratch sc;
     double *tiles = nullptr, *prefix = nullptr;
     int rc = sc.get(&tiles, moving_num_tiles(n) + 1024);

@@ -167,11 +167,15 @@ int32_t caf_device_info(int32_t device, char* name, int32_t name_len, int64_t* t
 
 int32_t caf_malloc(void** d_ptr, int64_t bytes) {
     CAF_REQUIRE(d_ptr && bytes >= 0, "caf_malloc: bad arguments");
-    CAF_HIP_TRY(hipMalloc(d_ptr, (size_t)std::max<int64_t>(bytes, 16)));
+    return pool_alloc(d_ptr, bytes);
+}
+int32_t caf_free(void* d_ptr) { return pool_free(d_ptr); }
+int32_t caf_pool_trim(void) {
+    pool_trim();
     return CAF_OK;
 }
-int32_t caf_free(void* d_ptr) {
-    if (d_ptr) CAF_HIP_TRY(hipFree(d_ptr));
+int32_t caf_pool_stats(int64_t* cached_bytes, int64_t* in_use_bytes, int64_t* hits, int64_t* misses) {
+    pool_stats(cached_bytes, in_use_bytes, hits, misses);
     return CAF_OK;
 }
 int32_t caf_memset(void* d_ptr, int32_t value, int64_t bytes, void* stream) {

@@ -228,6 +228,57 @@ __global__ __launch_bounds__(256) void k_moving_from_prefix(const double* __rest
     out[i] = sum_instead ? (float)s : (float)(s / (double)L);
 }
 
+// Causal moving sum / mean in ONE launch for windows up to MAT_MAXL: a workgroup stages its MAT_TILE outputs' inputs
+// (tile + L - 1 samples, zeros before the start) in LDS, builds their float64 prefix there and writes differences.
+// No global prefix array, no scratch allocation, 4 B read + 4 B written per sample (plus the halo).
+constexpr int MAT_TILE = 4096;
+constexpr int MAT_MAXL = 1024;  // (tile + window in LDS as float32 + float64 prefix: 64 KB of dynamic LDS)
+
+__global__ __launch_bounds__(256) void k_moving_tile(const float* __restrict__ x, int64_t n, int32_t L, int32_t sum_instead,
+                                                     float* __restrict__ out) {
+    extern __shared__ double s_mat[];
+    const int W = MAT_TILE + L - 1;                 // samples i0 - L + 1 .. i0 + MAT_TILE - 1
+    const int per = ((W + 255) / 256) | 1;          // samples per thread, odd (LDS banks)
+    double* s_p = s_mat;                            // exclusive prefix, 256 * per + 1 entries
+    float* s_x = reinterpret_cast<float*>(s_mat + 256 * per + 1);
+    __shared__ double s_wave[4];
+    const float* xr = x + (int64_t)blockIdx.y * n;
+    float* outr = out + (int64_t)blockIdx.y * n;
+    const int64_t i0 = (int64_t)blockIdx.x * MAT_TILE;
+    for (int t = threadIdx.x; t < 256 * per; t += 256) {
+        const int64_t j = i0 - (L - 1) + t;
+        s_x[t] = (t < W && j >= 0 && j < n) ? xr[j] : 0.f;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int e0 = threadIdx.x * per;
+    double tot = 0.0;
+    for (int j = 0; j < per; ++j) tot += (double)s_x[e0 + j];
+    double incl = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double u = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += u;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    double run = incl - tot;
+    for (int w = 0; w < wave; ++w) run += s_wave[w];
+    for (int j = 0; j < per; ++j) {
+        s_p[e0 + j] = run;
+        run += (double)s_x[e0 + j];
+    }
+    if (threadIdx.x == 255) s_p[256 * per] = run;
+    __syncthreads();
+    for (int l = threadIdx.x; l < MAT_TILE; l += 256) {
+        const int64_t i = i0 + l;
+        if (i >= n) break;
+        // window of output i: samples i - L + 1 .. i  ->  tile-local l .. l + L - 1
+        const double s = s_p[l + L] - s_p[l];
+        outr[i] = sum_instead ? (float)s : (float)(s / (double)L);
+    }
+}
+
 // valid-only forward moving complex sum -> |sum|^2 (filter.cu:374-438): direct O(L) per output in f64
 // staged through LDS (L is small in the reference's use: symbol-length sums).
 __global__ __launch_bounds__(256) void k_complex_moving_sum(const float2* __restrict__ x, int64_t n, int32_t L,
@@ -459,6 +510,70 @@ __global__ __launch_bounds__(256) void k_fir(const float2* __restrict__ x, int64
         }
         const int64_t o = (i - phase) / dsr;
         if (o < nout) out[o] = make_float2(ar, ai);
+    }
+}
+
+// Undecimated FIR, register-tiled: a thread produces FIRF_R consecutive outputs from a sliding window that lives
+// in registers, so every tap costs one LDS read of a new sample + one (broadcast) read of the tap for FIRF_R complex
+// FMAs -- the kernel above reads a tap and a sample per FMA and is bound by the LDS instruction rate.  The tap loop is
+// unrolled by FIRF_R so that the window rotates through fixed register names (no moves).  The input window of the
+// workgroup is stored transposed, element e at (e % FIRF_R) * pitch + e / FIRF_R: lanes, whose windows start
+// FIRF_R samples apart, then read consecutive addresses (no bank conflicts).
+constexpr int FIRF_R = 8;
+constexpr int FIRF_TILE = 256 * FIRF_R;  // outputs per workgroup
+
+__global__ __launch_bounds__(256) void k_fir_fast(const float2* __restrict__ x, int64_t n, const float* __restrict__ taps,
+                                                  int32_t ntaps, const float2* __restrict__ delay, int32_t dlen,
+                                                  float2* __restrict__ out) {
+    extern __shared__ float s_firf[];
+    const int ntp = (ntaps + FIRF_R - 1) / FIRF_R * FIRF_R;  // taps padded with zeros to a multiple of FIRF_R
+    float* s_taps = s_firf;                                  // ntp
+    float2* s_in = reinterpret_cast<float2*>(s_firf + ntp);  // FIRF_R rows of `pitch`
+    const int span = FIRF_TILE + ntp;                        // samples i0 - ntp .. i0 + FIRF_TILE - 1
+    const int pitch = span / FIRF_R + 1;
+    const int64_t i0 = (int64_t)blockIdx.x * FIRF_TILE;
+    for (int t = threadIdx.x; t < ntp; t += 256) s_taps[t] = t < ntaps ? taps[t] : 0.f;
+    for (int t = threadIdx.x; t < span; t += 256) {
+        const int64_t j = i0 - ntp + t;
+        float2 v = make_float2(0.f, 0.f);
+        if (j >= 0) {
+            if (j < n) v = x[j];
+        } else if (delay && -j <= dlen) {
+            v = delay[dlen + j];
+        }
+        s_in[(t % FIRF_R) * pitch + t / FIRF_R] = v;
+    }
+    __syncthreads();
+    // outputs l0 .. l0 + R - 1 of the tile; sample index (tile-local, offset ntp) of output l and tap k: ntp + l - k
+    const int l0 = threadIdx.x * FIRF_R;
+    float2 acc[FIRF_R], win[FIRF_R];
+#pragma unroll
+    for (int r = 0; r < FIRF_R; ++r) {
+        acc[r] = make_float2(0.f, 0.f);
+        const int e = ntp + l0 + r;  // tap 0
+        win[r] = s_in[(e % FIRF_R) * pitch + e / FIRF_R];
+    }
+    for (int k0 = 0; k0 < ntp; k0 += FIRF_R) {
+#pragma unroll
+        for (int kk = 0; kk < FIRF_R; ++kk) {
+            const float c = s_taps[k0 + kk];
+            // at tap k = k0 + kk output r needs sample e = ntp + l0 + r - k, held in win[(r - kk) mod R]
+#pragma unroll
+            for (int r = 0; r < FIRF_R; ++r) {
+                const float2 w = win[(r - kk + FIRF_R) % FIRF_R];
+                acc[r].x += c * w.x;
+                acc[r].y += c * w.y;
+            }
+            // the sample of output R-1 (slot (R-1-kk) mod R) is not needed again: replace it with the one output 0
+            // needs at the next tap, e = ntp + l0 - (k + 1)
+            const int e = ntp + l0 - (k0 + kk + 1);
+            win[(FIRF_R - 1 - kk) % FIRF_R] = s_in[((e % FIRF_R + FIRF_R) % FIRF_R) * pitch + e / FIRF_R];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < FIRF_R; ++r) {
+        const int64_t i = i0 + l0 + r;
+        if (i < n) out[i] = acc[r];
     }
 }
 
@@ -798,8 +913,25 @@ void launch_find_local_maxima(const float* x, int64_t n, float min_height, uint8
     hipLaunchKernelGGL(k_compact_flags, dim3(1), dim3(1024), 0, st, flags, n, max_out, idx, count);
 }
 
+int moving_tile_max_window() { return MAT_MAXL; }
+
+void launch_moving_tile(const float* x, int64_t rows, int64_t n, int32_t L, int32_t sum_instead, float* out,
+                        hipStream_t st) {
+    const int W = MAT_TILE + L - 1;
+    const int per = ((W + 255) / 256) | 1;
+    const size_t sm = (size_t)(256 * per + 1) * sizeof(double) + (size_t)(256 * per) * sizeof(float);
+    hipLaunchKernelGGL(k_moving_tile, dim3(cdiv(n, MAT_TILE), (unsigned)rows), dim3(256), sm, st, x, n, L, sum_instead, out);
+}
+
 void launch_fir(const float2* x, int64_t n, const float* taps, int32_t ntaps, const float2* delay, int32_t dlen,
                 int32_t dsr, int32_t phase, float2* out, int64_t nout, hipStream_t st) {
+    if (dsr == 1 && phase == 0 && nout >= n && ntaps <= 2048) {  // undecimated: the register-tiled kernel (LDS < 64 KB)
+        const int ntp = (ntaps + FIRF_R - 1) / FIRF_R * FIRF_R;
+        const int pitch = (FIRF_TILE + ntp) / FIRF_R + 1;
+        const size_t smf = (size_t)ntp * sizeof(float) + (size_t)FIRF_R * pitch * sizeof(float2);
+        hipLaunchKernelGGL(k_fir_fast, dim3(cdiv(n, FIRF_TILE)), dim3(256), smf, st, x, n, taps, ntaps, delay, dlen, out);
+        return;
+    }
     const size_t sm = (size_t)((ntaps + 1) & ~1) * sizeof(float) + (size_t)(FIR_TILE + ntaps) * sizeof(float2);
     hipLaunchKernelGGL(k_fir, dim3(cdiv(n, FIR_TILE)), dim3(256), sm, st, x, n, taps, ntaps, delay, dlen, dsr, phase, out,
                        nout);

@@ -4,7 +4,8 @@ The reference's GPU functions take and return ``cupy.ndarray``
 (xcorrRoutines.py:169-371, cupyExtensions.py) and its unit test requires a
 TypeError for host arrays (xcorrRoutines.py:2150-2157).  cupy does not exist on
 ROCm here and must not be shimmed, so the host layer ships this small HBM-backed
-array: contiguous, C-order, allocated with ``caf_malloc`` (hipMalloc), with the
+array: contiguous, C-order, allocated with ``caf_malloc`` (a caching allocator over
+hipMalloc, the counterpart of cupy's default memory pool), with the
 handful of members the reference code paths touch: ``shape / dtype / size /
 ndim / nbytes / get() / reshape() / [row or range slicing] / conj() / copy()``.
 
@@ -154,8 +155,19 @@ def zeros(shape, dtype=np.float32):
     a = DeviceArray(shape, dtype)
     if a.nbytes:
         _lib.check(_lib.load().caf_memset(ct.c_void_p(a.ptr), 0, a.nbytes, None), "caf_memset")
-        _lib.check(_lib.load().caf_stream_sync(None), "sync")
     return a
+
+
+def free_all_blocks():
+    """Return the allocator's cached blocks to the driver (cp.get_default_memory_pool().free_all_blocks())."""
+    _lib.check(_lib.load().caf_pool_trim(), "caf_pool_trim")
+
+
+def pool_stats():
+    """dict(cached_bytes, in_use_bytes, hits, misses) of the caching allocator."""
+    v = [ct.c_int64() for _ in range(4)]
+    _lib.check(_lib.load().caf_pool_stats(*[ct.byref(x) for x in v]), "caf_pool_stats")
+    return dict(zip(("cached_bytes", "in_use_bytes", "hits", "misses"), (int(x.value) for x in v)))
 
 
 def requireDeviceArray(var):

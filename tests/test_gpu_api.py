@@ -480,6 +480,14 @@ def test_moving_average_kernels_fuzz():
         np.testing.assert_allclose(got, sps.lfilter(np.ones(L) / L, 1, x), atol=3e-6)
         gs = cupyMovingAverage(asarray(x), L, sumInstead=True).get()
         np.testing.assert_allclose(gs, K.movingAverage(x, L, True), rtol=1e-6, atol=1e-5)
+    # windows either side of the single-launch kernel's limit (1024), lengths around its 4096-output tile
+    for n, L in ((4096, 1024), (4097, 1025), (12289, 1023), (9000, 3000), (100, 1024), (5000, 4096)):
+        x = rng.standard_normal(n).astype(np.float32)
+        got = cupyMovingAverage(asarray(x), L).get()
+        np.testing.assert_allclose(got, K.movingAverage(x, L, False), rtol=1e-6, atol=3e-6)
+    x3 = rng.standard_normal((3, 10000)).astype(np.float32)
+    np.testing.assert_allclose(cupyMultiMovingAverage(asarray(x3), 2000).get(),
+                               sps.lfilter(np.ones(2000) / 2000, 1, x3.astype(np.float64), axis=1), atol=3e-6)
     x2 = rng.standard_normal((5, 3333)).astype(np.float32)
     np.testing.assert_allclose(cupyMultiMovingAverage(asarray(x2), 77).get(), sps.lfilter(np.ones(77) / 77, 1, x2, axis=1), atol=3e-6)
     with pytest.raises(ValueError):
@@ -527,6 +535,13 @@ def test_fir_and_upfirdn_kernels():
     with pytest.raises(TypeError):
         CupyKernelFilter().run_filter_smtaps(asarray(x), asarray(taps))
 
+    # tap counts around the register-tiled kernel's padding (multiples of 8) and its 2048-tap limit, ragged lengths
+    for nt, nx in ((1, 17), (5, 2047), (129, 2049), (1000, 7001), (2047, 5000), (2048, 4097), (2049, 3000)):
+        tp = (rng.standard_normal(nt) / np.sqrt(nt)).astype(np.float32)
+        xx = cn(rng, nx)
+        got = f.filter_smtaps(asarray(xx), asarray(tp)).get()
+        np.testing.assert_allclose(got, sps.lfilter(tp.astype(np.float64), 1, xx.astype(np.complex128)), atol=3e-5)
+
     # upfirdn: benchmark_upfirdnkernels.py:58-67 asserts fractional error < 1e-4
     taps2 = sps.firwin(64, 0.2).astype(np.float32)
     xs = cn(rng, 10000)
@@ -542,6 +557,30 @@ def test_fir_and_upfirdn_kernels():
     np.testing.assert_allclose(oa.get(), np.abs(refm), atol=1e-4)
     with pytest.raises(ValueError):
         f.upfirdn_sm(asarray(xm), asarray(taps2), 4, 3, d_out=asarray(np.zeros((6, 10), np.complex64)))
+
+
+def test_device_pool_reuses_blocks():
+    """caf_malloc / caf_free behind DeviceArray: a freed block of the same rounded size is handed out again,
+    contents of live arrays are never touched, trim empties the cache."""
+    from pydsproutines_amd import asarray, empty
+    from pydsproutines_amd.devarray import free_all_blocks, pool_stats
+
+    free_all_blocks()
+    keep = asarray(np.arange(1000, dtype=np.float32))
+    a = empty(300000, np.float32)
+    pa = a.ptr
+    s0 = pool_stats()
+    del a
+    s1 = pool_stats()
+    assert s1["cached_bytes"] > s0["cached_bytes"] and s1["in_use_bytes"] < s0["in_use_bytes"]
+    b = empty(290000, np.float32)  # same 2 MiB bin
+    assert b.ptr == pa and pool_stats()["hits"] == s1["hits"] + 1
+    c = empty(300000, np.float32)
+    assert c.ptr != b.ptr and c.ptr != keep.ptr
+    np.testing.assert_array_equal(keep.get(), np.arange(1000, dtype=np.float32))
+    del b, c
+    free_all_blocks()
+    assert pool_stats()["cached_bytes"] == 0
 
 
 def test_copy_and_peak_kernels():
