@@ -76,18 +76,54 @@ def cpu_baseline(rx_host, tmpl_host, bins, budget_s=12.0):
     }
 
 
-def cpu_baseline_same_algorithm(rx_host, tmpl_host, bins, budget_s=10.0):
-    """BASELINE.md baseline B3: the algorithm the GPU runs (hypothesis-domain overlap-save CAF with shifted
-    template spectra) as the oracle's scipy.fft restatement on ALL host cores, bounded sample of delays."""
-    import oracle
-
+def _host_cores():
     # threads actually usable: the scheduler affinity, capped at the 16-core share a one-GPU box gives
     # (os.cpu_count() reports all 256 host threads there); BENCH_CPU_WORKERS overrides
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = int(os.environ.get("BENCH_CPU_WORKERS", min(cores, 16)))
+    return int(os.environ.get("BENCH_CPU_WORKERS", min(cores, 16)))
+
+
+def cpu_baseline_threaded(rx_host, tmpl_host, budget_s=8.0):
+    """SURVEY 8(d) baseline 2: the reference's threaded native correlator (IppXcorrFFT.cpp:94-178, threads strided
+    over delays, full 4096-bin FFT per delay) as the plain-C restatement oracle/c/ippxcorrfft_port.c on all host
+    cores, bounded sample of delays around the planted peak."""
+    from oracle import cport
+
+    cores = _host_cores()
+    obj = cport.IppXcorrFFT(tmpl_host, cores)
+    chunk = 4096 * cores
+    done, pos = 0, 0
+    start = D0 - 4096
+    t0 = time.perf_counter()
+    while True:
+        if start + pos + chunk + tmpl_host.size > rx_host.size:
+            pos = 0  # wrap: the host sample of rx is short
+        obj.xcorr(rx_host, start + pos, start + pos + chunk, 1)
+        done += chunk
+        pos += chunk
+        el = time.perf_counter() - t0
+        if el > budget_s:
+            break
+    return {
+        "value": done / el / 1e6,
+        "unit": "Msamples/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": "%d delays from %d on (wrapping), 4096-bin FFT + argmax per delay (scalar C FFT, not IPP), "
+        "%d threads, %.1f s" % (done, start, cores, el),
+        "us_per_delay_per_thread": el / done * 1e6 * cores,
+    }
+
+
+def cpu_baseline_same_algorithm(rx_host, tmpl_host, bins, budget_s=10.0):
+    """BASELINE.md baseline B3: the algorithm the GPU runs (hypothesis-domain overlap-save CAF with shifted
+    template spectra) as the oracle's scipy.fft restatement on ALL host cores, bounded sample of delays."""
+    import oracle
+
+    cores = _host_cores()
     blk = 1 << 16
     step = blk - tmpl_host.size + 1
     seg = 4 * step + tmpl_host.size - 1  # four overlap-save blocks per call
@@ -354,6 +390,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             rx_h, tm_h = rx[: D0 + 560000].cpu().numpy(), tmpl.cpu().numpy()
             out["cpu_baseline"] = cpu_baseline(rx_h, tm_h, bins)
+            out["cpu_baseline_threaded"] = cpu_baseline_threaded(rx_h, tm_h)
             out["cpu_baseline_same_algorithm"] = cpu_baseline_same_algorithm(rx_h, tm_h, bins)
         print(json.dumps(out))
     if world > 1:

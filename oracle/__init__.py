@@ -14,7 +14,10 @@ the committed golden vectors / known-answer tests in ``tests/golden/``
 (CyIppXcorrFFT, CyGroupXcorrFFT, pbIppCZT32fc, pbIppGroupXcorrCZT) are NOT
 buildable here (Intel IPP and the un-vendored ``ipp_ext`` submodule are
 absent), so those are restated from source text and pinned to the Python
-oracle, which computes the same mathematics.
+oracle, which computes the same mathematics.  ``oracle/c/ippxcorrfft_port.c``
+(bound by ``oracle/cport.py``) is such a restatement in plain C with pthreads
+-- the threaded CPU baseline of bench.py -- pinned by
+``tests/test_oracle_c_port.py`` to KAT-2 and to the NumPy oracle.
 """
 
 from .spectral import makeFreq, next_fast_len, czt, CZTCached, dft  # noqa: F401
