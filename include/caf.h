@@ -245,6 +245,14 @@ CAF_EXPORT int32_t caf_argmax3d_u32(const uint32_t* d_x, int64_t num_items, int3
  * np.fromfile(int16).astype(float32).view(complex64) of usrpRoutines.simpleBinRead (usrpRoutines.py:51-67)
  * done after the (half-size) H2D copy as in benchmarks/benchmark_cupyCopyAndConvert.py:17-25 */
 CAF_EXPORT int32_t caf_iq16_to_c64(const int16_t* d_iq, int64_t num_samples, float scale, float* d_out, void* stream);
+/* Front-end filter/decimate fused into the rx load: one kernel that is
+ *   caf_iq16_to_c64 -> filter_smtaps(dsr, dsPhase)   (usrpRoutines.py:51-67 + filter.cu:9-58, filterRoutines.py:417-501)
+ * i.e. d_out[o] = lfilter(taps, 1, scale * iq)[ds_phase + o*dsr] as complex64, reading the raw int16 pairs (4 B per
+ * input sample) and computing only the kept outputs.  d_delay = the delay_len int16 IQ pairs that precede d_iq
+ * (streaming state: the tail of the previous chunk), NULL/0 for zeros.  num_taps <= 2048, dsr <= 16. */
+CAF_EXPORT int32_t caf_iq16_fir_decimate(const int16_t* d_iq, int64_t num_samples, float scale, const float* d_taps,
+                                         int32_t num_taps, const int16_t* d_delay, int32_t delay_len, int32_t dsr,
+                                         int32_t ds_phase, float* d_out, int64_t out_len, void* stream);
 /* per column of a complex64 (rows, n) matrix: max_r |z| and the first row attaining it
  * (TemplateCrossCorrelator.correlate(returnMax=True), xcorrRoutines.py:361-371) */
 CAF_EXPORT int32_t caf_colmax_abs(const float* d_z, int32_t rows, int64_t n, float* d_max, int32_t* d_arg, void* stream);

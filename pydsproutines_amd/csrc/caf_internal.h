@@ -84,6 +84,9 @@ void launch_find_local_maxima(const float* x, int64_t n, float min_height, uint8
                               int32_t* idx, int32_t* count, hipStream_t st);
 void launch_fir(const float2* x, int64_t n, const float* taps, int32_t ntaps, const float2* delay, int32_t dlen,
                 int32_t dsr, int32_t phase, float2* out, int64_t nout, hipStream_t st);
+bool fir_decim_ok(int32_t ntaps, int32_t dsr);
+void launch_iq16_fir(const int16_t* iq, int64_t n, float scale, const float* taps, int32_t ntaps, const int16_t* delay,
+                     int32_t dlen, int32_t dsr, int32_t phase, float2* out, int64_t nout, hipStream_t st);
 void launch_upfirdn(const float2* x, int64_t rows, int64_t n, const float* taps, int32_t ntaps, int32_t up, int32_t down,
                     int64_t nout, float2* out, float* out_abs, hipStream_t st);
 void launch_rows_mul_vec(const float2* x, int64_t in_pitch, int64_t in_off, const float2* v, int64_t len, float2* y,

@@ -292,8 +292,25 @@ int32_t caf_fir_lfilter(const float* d_x, int64_t n, const float* d_taps, int32_
     CAF_REQUIRE(dsr >= 1 && ds_phase >= 0 && ds_phase < dsr, "dsPhase must be between in the range [0,dsr-1].");
     CAF_REQUIRE(num_taps <= 4096, "more than 4096 taps: use an overlap-save FIR (hypothesis engine) instead");
     CAF_REQUIRE(delay_len >= 0 && (delay_len == 0 || d_delay), "delay_len > 0 needs d_delay");
+    CAF_REQUIRE(out_len >= 0 && out_len <= (n - ds_phase + dsr - 1) / dsr, "caf_fir_lfilter: out_len exceeds len(x[dsPhase::dsr])");
     launch_fir((const float2*)d_x, n, d_taps, num_taps, (const float2*)d_delay, delay_len, dsr, ds_phase, (float2*)d_out,
                out_len, (hipStream_t)stream);
+    CAF_HIP_TRY(hipGetLastError());
+    return CAF_OK;
+}
+
+int32_t caf_iq16_fir_decimate(const int16_t* d_iq, int64_t num_samples, float scale, const float* d_taps, int32_t num_taps,
+                              const int16_t* d_delay, int32_t delay_len, int32_t dsr, int32_t ds_phase, float* d_out,
+                              int64_t out_len, void* stream) {
+    CAF_REQUIRE(d_iq && d_taps && d_out && num_samples >= 1 && num_taps >= 1, "caf_iq16_fir_decimate: bad arguments");
+    CAF_REQUIRE(dsr >= 1 && ds_phase >= 0 && ds_phase < dsr, "dsPhase must be between in the range [0,dsr-1].");
+    CAF_REQUIRE(fir_decim_ok(num_taps, dsr), "caf_iq16_fir_decimate: at most 2048 taps and dsr <= 16");
+    CAF_REQUIRE(delay_len >= 0 && (delay_len == 0 || d_delay), "delay_len > 0 needs d_delay");
+    CAF_REQUIRE(((uintptr_t)d_iq & 3) == 0 && ((uintptr_t)d_delay & 3) == 0, "caf_iq16_fir_decimate: IQ pairs must be 4-byte aligned");
+    CAF_REQUIRE(out_len >= 0 && out_len <= (num_samples - ds_phase + dsr - 1) / dsr,
+                "caf_iq16_fir_decimate: out_len exceeds len(x[dsPhase::dsr])");
+    launch_iq16_fir(d_iq, num_samples, scale, d_taps, num_taps, d_delay, delay_len, dsr, ds_phase, (float2*)d_out, out_len,
+                    (hipStream_t)stream);
     CAF_HIP_TRY(hipGetLastError());
     return CAF_OK;
 }

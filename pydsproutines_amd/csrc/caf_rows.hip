@@ -577,6 +577,76 @@ __global__ __launch_bounds__(256) void k_fir_fast(const float2* __restrict__ x, 
     }
 }
 
+// Decimating FIR (2 <= dsr <= FIRD_MAXDSR), optionally fused with the int16 IQ ingest (the front-end
+// filter/decimate folded into the rx load): out[o] = y[o*dsr + phase], y = lfilter(taps, 1, scale * x).  Only the
+// kept outputs are computed -- k_fir evaluates the tile un-decimated and leaves (dsr-1)/dsr of its lanes idle.
+// A thread owns `per` kept outputs o0 + lane + r*256; the workgroup's input window is stored in polyphase order
+// (element e at (e % dsr) * pitch + e / dsr), so that at every tap the lanes, whose samples are dsr apart, read
+// consecutive LDS words.  TIn = float2 (complex64) or short2 (interleaved int16 IQ: 4 B read per sample).
+constexpr int FIRD_MAXDSR = 16;
+constexpr int FIRD_MAXPER = 4;
+
+__device__ __forceinline__ float2 fird_load(const float2* p, int64_t i, float) { return p[i]; }
+__device__ __forceinline__ float2 fird_load(const short2* p, int64_t i, float scale) {
+    const short2 v = p[i];
+    return make_float2((float)v.x * scale, (float)v.y * scale);
+}
+
+template <typename TIn>
+__global__ __launch_bounds__(256) void k_fir_decim(const TIn* __restrict__ x, int64_t n, float scale,
+                                                   const float* __restrict__ taps, int32_t ntaps,
+                                                   const TIn* __restrict__ delay, int32_t dlen, int32_t dsr, int32_t phase,
+                                                   int32_t per, float2* __restrict__ out, int64_t nout) {
+    extern __shared__ float s_fird[];
+    float* s_taps = s_fird;                                              // ntaps
+    float2* s_in = reinterpret_cast<float2*>(s_fird + ((ntaps + 1) & ~1));  // dsr rows of `pitch`
+    const int tile = 256 * per;                                          // kept outputs per workgroup
+    const int span = (tile - 1) * dsr + ntaps;                           // inputs i0 .. i0 + span - 1
+    const int pitch = span / dsr + 1;
+    const int64_t o0 = (int64_t)blockIdx.x * tile;
+    const int64_t i0 = o0 * dsr + phase - (ntaps - 1);                   // input index of window element 0
+    for (int t = threadIdx.x; t < ntaps; t += 256) s_taps[t] = taps[t];
+    for (int t = threadIdx.x; t < span; t += 256) {
+        const int64_t j = i0 + t;
+        float2 v = make_float2(0.f, 0.f);
+        if (j >= 0) {
+            if (j < n) v = fird_load(x, j, scale);
+        } else if (delay && -j <= dlen) {
+            v = fird_load(delay, dlen + j, scale);
+        }
+        s_in[(t % dsr) * pitch + t / dsr] = v;
+    }
+    __syncthreads();
+    // output l of the tile at tap k reads window element e = l*dsr + (ntaps-1-k): row (ntaps-1-k) % dsr,
+    // column l + (ntaps-1-k) / dsr
+    float2 acc[FIRD_MAXPER];
+#pragma unroll
+    for (int r = 0; r < FIRD_MAXPER; ++r) acc[r] = make_float2(0.f, 0.f);
+    int m = ntaps - 1;
+    int row = m % dsr, col = m / dsr;
+    for (int k = 0; k < ntaps; ++k) {
+        const float c = s_taps[k];
+        const float2* w = s_in + row * pitch + col + threadIdx.x;
+#pragma unroll
+        for (int r = 0; r < FIRD_MAXPER; ++r) {
+            if (r < per) {
+                const float2 v = w[r * 256];
+                acc[r].x += c * v.x;
+                acc[r].y += c * v.y;
+            }
+        }
+        if (--row < 0) {
+            row = dsr - 1;
+            --col;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < FIRD_MAXPER; ++r) {
+        const int64_t o = o0 + threadIdx.x + r * 256;
+        if (r < per && o < nout && o * dsr + phase < n) out[o] = acc[r];
+    }
+}
+
 // upfirdn == scipy.signal.upfirdn(taps, x, up, down) per row; out[r][o] = sum_k taps[k] xu[o*down - k],
 // xu = x upsampled by `up` (zeros between samples).  Optional |.| output.
 __global__ __launch_bounds__(256) void k_upfirdn(const float2* __restrict__ x, int64_t n, const float* __restrict__ taps,
@@ -923,6 +993,21 @@ void launch_moving_tile(const float* x, int64_t rows, int64_t n, int32_t L, int3
     hipLaunchKernelGGL(k_moving_tile, dim3(cdiv(n, MAT_TILE), (unsigned)rows), dim3(256), sm, st, x, n, L, sum_instead, out);
 }
 
+bool fir_decim_ok(int32_t ntaps, int32_t dsr) { return dsr >= 1 && dsr <= FIRD_MAXDSR && ntaps <= 2048; }
+
+template <typename TIn>
+static void launch_fir_decim(const TIn* x, int64_t n, float scale, const float* taps, int32_t ntaps, const TIn* delay,
+                             int32_t dlen, int32_t dsr, int32_t phase, float2* out, int64_t nout, hipStream_t st) {
+    // kept outputs per thread: the window (tile - 1) * dsr + ntaps stays below ~6200 samples (LDS < 64 KB with the taps)
+    const int per = dsr <= 4 ? 4 : (dsr <= 8 ? 2 : 1);
+    const int tile = 256 * per;
+    const int span = (tile - 1) * dsr + ntaps;
+    const size_t sm = (size_t)((ntaps + 1) & ~1) * sizeof(float) + (size_t)dsr * (span / dsr + 1) * sizeof(float2);
+    if (nout > 0)
+        hipLaunchKernelGGL(k_fir_decim<TIn>, dim3(cdiv(nout, tile)), dim3(256), sm, st, x, n, scale, taps, ntaps, delay,
+                           dlen, dsr, phase, per, out, nout);
+}
+
 void launch_fir(const float2* x, int64_t n, const float* taps, int32_t ntaps, const float2* delay, int32_t dlen,
                 int32_t dsr, int32_t phase, float2* out, int64_t nout, hipStream_t st) {
     if (dsr == 1 && phase == 0 && nout >= n && ntaps <= 2048) {  // undecimated: the register-tiled kernel (LDS < 64 KB)
@@ -932,9 +1017,19 @@ void launch_fir(const float2* x, int64_t n, const float* taps, int32_t ntaps, co
         hipLaunchKernelGGL(k_fir_fast, dim3(cdiv(n, FIRF_TILE)), dim3(256), smf, st, x, n, taps, ntaps, delay, dlen, out);
         return;
     }
+    if (fir_decim_ok(ntaps, dsr)) {  // decimating: only the kept outputs are computed
+        launch_fir_decim(x, n, 1.0f, taps, ntaps, delay, dlen, dsr, phase, out, nout, st);
+        return;
+    }
     const size_t sm = (size_t)((ntaps + 1) & ~1) * sizeof(float) + (size_t)(FIR_TILE + ntaps) * sizeof(float2);
     hipLaunchKernelGGL(k_fir, dim3(cdiv(n, FIR_TILE)), dim3(256), sm, st, x, n, taps, ntaps, delay, dlen, dsr, phase, out,
                        nout);
+}
+
+void launch_iq16_fir(const int16_t* iq, int64_t n, float scale, const float* taps, int32_t ntaps, const int16_t* delay,
+                     int32_t dlen, int32_t dsr, int32_t phase, float2* out, int64_t nout, hipStream_t st) {
+    launch_fir_decim(reinterpret_cast<const short2*>(iq), n, scale, taps, ntaps, reinterpret_cast<const short2*>(delay),
+                     dlen, dsr, phase, out, nout, st);
 }
 
 void launch_upfirdn(const float2* x, int64_t rows, int64_t n, const float* taps, int32_t ntaps, int32_t up, int32_t down,

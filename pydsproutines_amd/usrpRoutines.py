@@ -24,6 +24,67 @@ def iq16_to_complex64(d_iq16, scale=1.0):
     return out
 
 
+class Iq16FrontEnd:
+    """Front-end filter + decimate fused into the rx load: raw interleaved int16 IQ on the device ->
+    ``lfilter(taps, 1, scale * iq)[dsPhase::dsr]`` as complex64 in one kernel, with the streaming state of the
+    reference's ``CupyKernelFilter.run_filter_smtaps`` (filterRoutines.py:482-501): the tail of every chunk is
+    carried into the next call, so chunked calls equal one long filter.  Equivalent to
+    ``iq16_to_complex64`` followed by ``CupyKernelFilter.filter_smtaps(dsr=, dsPhase=)``.
+
+    The decimation phase is tracked across chunks, so chunk lengths need not be multiples of ``dsr``."""
+
+    def __init__(self, d_taps, dsr=1, dsPhase=0, scale=1.0):
+        if d_taps.dtype != np.float32:
+            raise TypeError("Must be float32, found %s" % d_taps.dtype)
+        if d_taps.ndim != 1:
+            raise ValueError("d_taps must be 1D.")
+        if dsPhase >= dsr or dsPhase < 0:
+            raise ValueError("dsPhase must be between in the range [0,dsr-1].")
+        if d_taps.size > 2048 or dsr > 16:
+            raise MemoryError("at most 2048 taps and dsr <= 16")
+        self.d_taps, self.dsr, self.scale = d_taps, int(dsr), float(scale)
+        self.phase = int(dsPhase)  # phase of the next chunk
+        self.delay = None  # int16 (2 * (ntaps - 1),): the IQ pairs preceding the next chunk
+
+    def reset(self, dsPhase=0):
+        self.phase, self.delay = int(dsPhase), None
+
+    def run(self, d_iq16):
+        if d_iq16.dtype != np.int16:
+            raise TypeError("Must be int16, found %s" % d_iq16.dtype)
+        if d_iq16.ndim != 1 or d_iq16.size % 2 or d_iq16.size == 0:
+            raise ValueError("interleaved IQ needs a 1D, non-empty, even number of int16 values")
+        n = d_iq16.size // 2
+        nout = max(0, (n - self.phase + self.dsr - 1) // self.dsr)
+        out = empty(nout, np.complex64)
+        lib = _lib.load()
+        dl = self.delay.size // 2 if self.delay is not None else 0
+        _lib.check(lib.caf_iq16_fir_decimate(ct.c_void_p(d_iq16.ptr), n, self.scale, ct.c_void_p(self.d_taps.ptr),
+                                             self.d_taps.size, ct.c_void_p(self.delay.ptr) if dl else None, dl, self.dsr,
+                                             self.phase, ct.c_void_p(out.ptr), nout, None), "caf_iq16_fir_decimate")
+        # carry the last ntaps-1 input pairs (old history + this chunk) and the phase into the next call
+        keep = self.d_taps.size - 1
+        if keep > 0:
+            nd = empty(2 * keep, np.int16)
+            from_x = min(keep, n)
+            from_old = keep - from_x
+            if from_old:
+                if dl >= from_old:
+                    _lib.check(lib.caf_d2d(ct.c_void_p(nd.ptr), ct.c_void_p(self.delay.ptr + 4 * (dl - from_old)),
+                                           4 * from_old, None))
+                else:  # not enough history yet: zeros in front
+                    _lib.check(lib.caf_memset(ct.c_void_p(nd.ptr), 0, 4 * (from_old - dl), None))
+                    if dl:
+                        _lib.check(lib.caf_d2d(ct.c_void_p(nd.ptr + 4 * (from_old - dl)), ct.c_void_p(self.delay.ptr),
+                                               4 * dl, None))
+            _lib.check(lib.caf_d2d(ct.c_void_p(nd.ptr + 4 * from_old), ct.c_void_p(d_iq16.ptr + 4 * (n - from_x)),
+                                   4 * from_x, None))
+            self.delay = nd
+        # next kept sample index relative to the next chunk's start
+        self.phase = self.phase + nout * self.dsr - n
+        return out
+
+
 def simpleBinReadToDevice(filename, numSamps=-1, in_dtype=np.int16, offset=0, scale=1.0):
     """Read numSamps complex samples of interleaved int16 and return them as a complex64 DeviceArray."""
     if in_dtype != np.int16:

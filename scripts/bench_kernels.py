@@ -72,3 +72,23 @@ report("FIR filter_smtaps, 128 taps, 1 M complex64", t, "317 us (smtaps), 230 us
 d_f = asarray(rng.standard_normal(10_000_000).astype(np.float32))
 t = timeit(lambda: cupyMovingAverage(d_f, 100), reps=20)
 report("cupyMovingAverage, L = 100, 10 M float32", t, "472 us (kernel), 1.259 ms (FIR)")
+
+# decimating FIR and the fused int16 front-end (no published figures: SURVEY 8f.2)
+from pydsproutines_amd.usrpRoutines import Iq16FrontEnd, iq16_to_complex64  # noqa: E402
+
+t = timeit(lambda: f.filter_smtaps(d_x, d_taps, dsr=4, dsPhase=1), reps=20)
+report("FIR filter_smtaps dsr=4, 128 taps, 1 M complex64", t, "-")
+raw = rng.integers(-2048, 2048, 2 * 16_777_216, dtype=np.int16)
+d_raw = asarray(raw)
+fe = Iq16FrontEnd(d_taps, 4, 0, 1.0 / 2048)
+
+
+def fused():
+    fe.reset(0)
+    return fe.run(d_raw)
+
+
+t = timeit(fused, reps=10)
+report("int16 ingest + 128-tap FIR + decimate by 4 fused, 16 M samples", t, "-")
+t = timeit(lambda: f.filter_smtaps(iq16_to_complex64(d_raw, 1.0 / 2048), d_taps, dsr=4), reps=10)
+report("  same as convert kernel + decimating FIR kernel", t, "-")

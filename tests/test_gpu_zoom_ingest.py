@@ -96,3 +96,55 @@ def test_iq16_ingest(tmp_path):
         np.testing.assert_array_equal(iq16_to_complex64(asarray(fut.result())).get(), want[500:1000])
         with pytest.raises(TypeError):
             futureBinRead(ex, files[0], 10, in_dtype=np.complex64)
+
+
+@pytest.mark.parametrize("dsr,phase,ntaps", [(1, 0, 64), (2, 1, 33), (4, 0, 128), (5, 3, 100), (8, 7, 257), (16, 5, 2048),
+                                              (3, 2, 1)])
+def test_iq16_frontend_fir_decimate(dsr, phase, ntaps):
+    """SURVEY 8f.2: ingest + FIR + decimation in one kernel == convert -> lfilter -> [phase::dsr] (filter.cu:9-58),
+    one call and ragged streaming chunks; the same decimating kernel behind filter_smtaps(dsr=, dsPhase=)."""
+    import scipy.signal as sps
+
+    from pydsproutines_amd import asarray
+    from pydsproutines_amd.filterRoutines import CupyKernelFilter
+    from pydsproutines_amd.usrpRoutines import Iq16FrontEnd, iq16_to_complex64
+
+    rng = np.random.default_rng(1000 * dsr + ntaps)
+    n = 50_021
+    raw = rng.integers(-2048, 2048, 2 * n, dtype=np.int16)
+    taps = (sps.firwin(ntaps, 0.8 / dsr) if ntaps > 1 else np.array([0.75])).astype(np.float32)
+    scale = 1.0 / 2048
+    x = (raw.astype(np.float32) * np.float32(scale)).view(np.complex64)
+    ref = sps.lfilter(taps.astype(np.float64), 1, x.astype(np.complex128))[phase::dsr]
+    d_taps = asarray(taps)
+    fe = Iq16FrontEnd(d_taps, dsr, phase, scale)
+    got = fe.run(asarray(raw)).get()
+    assert got.dtype == np.complex64 and got.size == ref.size
+    np.testing.assert_allclose(got, ref, atol=2e-5)
+    # the unfused chain through the reference-signature wrappers gives the same values
+    chain = CupyKernelFilter().filter_smtaps(iq16_to_complex64(asarray(raw), scale), d_taps, dsr=dsr, dsPhase=phase).get()
+    np.testing.assert_allclose(chain, ref, atol=2e-5)
+    np.testing.assert_allclose(got, chain, atol=1e-6)
+    # streaming: ragged chunks (shorter than the taps, not multiples of dsr) == the one-shot result
+    fe.reset(phase)
+    cuts = [0, 7, 8, 1000, 1003, 20_000, 20_001, 37_777, n]
+    parts = [fe.run(asarray(raw[2 * a : 2 * b])).get() for a, b in zip(cuts[:-1], cuts[1:])]
+    np.testing.assert_allclose(np.concatenate(parts), ref, atol=2e-5)
+
+
+def test_iq16_frontend_validation():
+    from pydsproutines_amd import asarray
+    from pydsproutines_amd.usrpRoutines import Iq16FrontEnd
+
+    taps = asarray(np.ones(8, np.float32))
+    with pytest.raises(ValueError):
+        Iq16FrontEnd(taps, 4, 4)
+    with pytest.raises(TypeError):
+        Iq16FrontEnd(asarray(np.ones(8, np.float64)))
+    with pytest.raises(MemoryError):
+        Iq16FrontEnd(taps, 17, 0)
+    fe = Iq16FrontEnd(taps, 2)
+    with pytest.raises(TypeError):
+        fe.run(asarray(np.zeros(10, np.float32)))
+    with pytest.raises(ValueError):
+        fe.run(asarray(np.zeros(9, np.int16)))
