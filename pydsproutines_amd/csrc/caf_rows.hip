@@ -383,6 +383,93 @@ __global__ __launch_bounds__(256) void k_multi_template_dot(const float2* __rest
     }
 }
 
+// Register-tiled form of the above for templates up to MTR_MAXL samples: a thread owns MTR_R consecutive slides and
+// keeps their MTR_R-sample window of x in registers (it slides by one sample per template tap; the tap loop is
+// unrolled by MTR_R so that the window rotates through fixed register names), so a tap costs one LDS sample read
+// and one broadcast tap read for MTR_R complex MACs, where the kernel above reads both operands per MAC and
+// shuffle-reduces every dot product.  x window stored transposed (e % MTR_R major) as in k_fir_fast; templates
+// zero-padded to a multiple of MTR_R.
+constexpr int MTR_R = 8;
+constexpr int MTR_SLIDES = 256 * MTR_R;
+constexpr int MTR_MAXL = 2048;
+
+__global__ __launch_bounds__(256) void k_multi_template_dot_rt(const float2* __restrict__ tm, const float* __restrict__ te,
+                                                               int32_t ntm, int32_t L, const float2* __restrict__ x,
+                                                               int64_t xlen, const double* __restrict__ prefix,
+                                                               int64_t start, int64_t nslides,
+                                                               int32_t* __restrict__ tidx, float* __restrict__ qf2) {
+    extern __shared__ float2 s_mtr[];
+    const int Lp = (L + MTR_R - 1) / MTR_R * MTR_R;
+    const int span = MTR_SLIDES + Lp;
+    const int pitch = span / MTR_R + 1;
+    float2* s_t = s_mtr;        // Lp
+    float2* s_xs = s_mtr + Lp;  // MTR_R rows of `pitch`
+    const int64_t k0 = (int64_t)blockIdx.x * MTR_SLIDES;
+    for (int t = threadIdx.x; t < span; t += 256) {
+        const int64_t j = start + k0 + t;
+        s_xs[(t % MTR_R) * pitch + t / MTR_R] = (j < xlen) ? x[j] : make_float2(0.f, 0.f);
+    }
+    const int l0 = threadIdx.x * MTR_R;
+    float ewin[MTR_R], bv[MTR_R];  // ewin: ||x[k:k+L]||^2 per slide (1 for slides past the end)
+    int32_t bi[MTR_R];
+#pragma unroll
+    for (int r = 0; r < MTR_R; ++r) {
+        const int64_t s = start + k0 + l0 + r;
+        float e = 1.f;
+        if (k0 + l0 + r < nslides) {
+            int64_t e1 = s + L;
+            if (e1 > xlen) e1 = xlen;
+            e = (float)(prefix[e1] - prefix[s]);
+        }
+        ewin[r] = e;
+        bv[r] = 0.f;
+        bi[r] = 0;
+    }
+    for (int i = 0; i < ntm; ++i) {
+        __syncthreads();  // previous template consumed (and, first time, the x window written)
+        for (int t = threadIdx.x; t < Lp; t += 256) s_t[t] = t < L ? tm[(int64_t)i * L + t] : make_float2(0.f, 0.f);
+        __syncthreads();
+        float2 acc[MTR_R], win[MTR_R];
+#pragma unroll
+        for (int r = 0; r < MTR_R; ++r) {
+            acc[r] = make_float2(0.f, 0.f);
+            win[r] = s_xs[r * pitch + threadIdx.x];  // e = l0 + r
+        }
+        for (int t0 = 0; t0 < Lp; t0 += MTR_R) {
+#pragma unroll
+            for (int tt = 0; tt < MTR_R; ++tt) {
+                const float2 a = s_t[t0 + tt];
+                // slide r at tap t reads sample l0 + r + t, held in slot (r + tt) mod R
+#pragma unroll
+                for (int r = 0; r < MTR_R; ++r) {
+                    const float2 b = win[(r + tt) % MTR_R];
+                    acc[r].x += a.x * b.x - a.y * b.y;
+                    acc[r].y += a.x * b.y + a.y * b.x;
+                }
+                // sample l0 + t is done; slot tt takes l0 + t + R  (row tt, column tid + (t0 + R) / R)
+                win[tt] = s_xs[tt * pitch + threadIdx.x + t0 / MTR_R + 1];
+            }
+        }
+        const float inv_te = 1.0f / te[i];
+#pragma unroll
+        for (int r = 0; r < MTR_R; ++r) {
+            const float v = (acc[r].x * acc[r].x + acc[r].y * acc[r].y) * inv_te / ewin[r];
+            if (v > bv[r]) {
+                bv[r] = v;
+                bi[r] = i;
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < MTR_R; ++r) {
+        const int64_t k = k0 + l0 + r;
+        if (k < nslides) {
+            tidx[k] = bi[r];
+            qf2[k] = bv[r];
+        }
+    }
+}
+
 // out[i][t] = rows[row_idx[i]][t] * x[slice_start[i] + t] for t < slice_lens[i] (0 beyond), t < slice_len
 __global__ __launch_bounds__(256) void k_multiply_indexed_rows(const float2* __restrict__ x, int64_t xlen,
                                                                const float2* __restrict__ rows, int32_t row_len,
@@ -944,6 +1031,14 @@ void launch_complex_moving_sum(const float2* x, int64_t n, int32_t L, float* out
 void launch_multi_template_dot(const float2* tm, const float* te, int32_t ntm, int32_t L, const float2* x, int64_t xlen,
                                const double* prefix, int64_t start, int64_t nslides, int32_t* tidx, float* qf2,
                                hipStream_t st) {
+    const int Lp = (L + MTR_R - 1) / MTR_R * MTR_R;
+    if (Lp <= MTR_MAXL) {
+        const int span = MTR_SLIDES + Lp;
+        const size_t smr = (size_t)(Lp + MTR_R * (span / MTR_R + 1)) * sizeof(float2);
+        hipLaunchKernelGGL(k_multi_template_dot_rt, dim3(cdiv(nslides, MTR_SLIDES)), dim3(256), smr, st, tm, te, ntm, L, x,
+                           xlen, prefix, start, nslides, tidx, qf2);
+        return;
+    }
     const size_t sm = (size_t)(2 * L + MT_SLIDES) * sizeof(float2);
     hipLaunchKernelGGL(k_multi_template_dot, dim3(cdiv(nslides, MT_SLIDES)), dim3(256), sm, st, tm, te, ntm, L, x, xlen,
                        prefix, start, nslides, tidx, qf2);

@@ -448,6 +448,22 @@ def test_sliding_product_and_multitemplate_kernels():
     assert ti.get()[290] == 4 == oti[290]
     agree = np.mean(ti.get() == oti)
     assert agree > 0.999  # near-ties between templates in pure noise may differ in the last ulp
+    # template lengths around the register tile (multiples of 8), its 2048-sample limit and the fallback kernel;
+    # slide counts around the 2048-slide workgroup tile; every template planted once
+    for T2, L2, nx, st in ((1, 1, 50, 0), (3, 7, 3000, 5), (5, 8, 2048 + 7, 0), (2, 9, 2049 + 8, 0), (20, 100, 9000, 77),
+                           (2, 2048, 7000, 3), (2, 2049, 7000, 0)):
+        tm2 = cn(rng, T2 * L2).reshape(T2, L2)
+        x2 = cn(rng, nx)
+        nsl = nx - L2 + 1 - st
+        for i in range(T2):
+            p = st + (i + 1) * (nsl - 1) // (T2 + 1)
+            x2[p : p + L2] += 4 * tm2[i].conj()
+        ti2, q2 = multiTemplateSlidingDotProduct(asarray(x2), asarray(tm2), st, nsl)
+        oti2, oq2 = K.multiTemplateSlidingDotProduct(x2, tm2, st, nsl)
+        np.testing.assert_allclose(q2.get(), oq2, atol=TOL)
+        strong = oq2 > 0.5
+        assert strong.sum() >= 1
+        np.testing.assert_array_equal(ti2.get()[strong], oti2[strong])
     with pytest.raises(ValueError):
         multiTemplateSlidingDotProduct(asarray(xs), asarray(tm), 10, 1942)
     with pytest.raises(ValueError):
