@@ -147,7 +147,11 @@ typedef struct caf_outputs {
 } caf_outputs;
 
 /* d_rx: device complex64 [rx_len].  Requires shift_start >= 0 and
- * shift_start + num_shifts - 1 + N <= rx_len <= max_rx_len.  Asynchronous on `stream`. */
+ * shift_start + num_shifts - 1 + N <= rx_len <= max_rx_len.  Asynchronous on `stream`.
+ * The plan belongs to the device that was current at caf_plan_create (the same must be current here) and owns
+ * its workspace: executions of ONE plan must be ordered (same stream, or synchronised by the caller); different
+ * plans may run concurrently from different threads / streams (create -> use many -> destroy, like the
+ * reference's stateful correlator objects, IppXcorrFFT.h, xcorrRoutines.py:277-371). */
 CAF_EXPORT int32_t caf_plan_execute(caf_plan plan, const float* d_rx, int64_t rx_len, int64_t shift_start,
                                     int64_t num_shifts, const caf_outputs* out, void* stream);
 

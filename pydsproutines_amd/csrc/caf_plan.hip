@@ -134,7 +134,7 @@ int32_t caf_last_error(char* buf, int32_t len) {
     return CAF_OK;
 }
 
-int32_t caf_abi_version(void) { return (1 << 16) | 0; }
+int32_t caf_abi_version(void) { return (1 << 16) | 3; }  // minor: +1 per batch of added entry points
 
 int32_t caf_device_count(int32_t* count) {
     CAF_REQUIRE(count, "count is NULL");
@@ -505,6 +505,9 @@ int32_t caf_plan_execute(caf_plan p, const float* d_rx, int64_t rx_len, int64_t 
     CAF_REQUIRE(shift_start >= 0 && num_shifts >= 1, "need shift_start >= 0 and num_shifts >= 1");
     CAF_REQUIRE(shift_start + num_shifts - 1 + p->N <= rx_len, "delays run past the end of rx");
     CAF_REQUIRE((reinterpret_cast<uintptr_t>(d_rx) & 7) == 0, "d_rx must be 8-byte aligned");
+    int cur_dev = -1;
+    CAF_HIP_TRY(hipGetDevice(&cur_dev));
+    CAF_REQUIRE(cur_dev == p->device, "caf_plan_execute: the plan was created on another device than the current one");
     hipStream_t st = (hipStream_t)stream;
     const float2* rx = reinterpret_cast<const float2*>(d_rx);
     const int T = p->T, F = p->F;
@@ -718,7 +721,8 @@ int32_t caf_plan_execute_host(caf_plan p, const float* h_rx, int64_t rx_len, int
     std::memset(&o, 0, sizeof(o));
     std::vector<void*> owned;
     auto dalloc = [&](void** ptr, int64_t bytes) -> int {
-        CAF_HIP_TRY(hipMalloc(ptr, (size_t)std::max<int64_t>(bytes, 16)));
+        const int prc = pool_alloc(ptr, std::max<int64_t>(bytes, 16));  // cached across calls (caf_pool.hip)
+        if (prc) return prc;
         owned.push_back(*ptr);
         return CAF_OK;
     };
@@ -730,7 +734,7 @@ int32_t caf_plan_execute_host(caf_plan p, const float* h_rx, int64_t rx_len, int
     if (!rc && h_peak_delay) rc = dalloc((void**)&o.d_peak_delay, T * 4);
     if (!rc && h_peak_freq) rc = dalloc((void**)&o.d_peak_freq, T * 4);
     auto cleanup = [&]() {
-        for (void* q : owned) (void)hipFree(q);
+        for (void* q : owned) (void)pool_free(q);
     };
     if (rc) {
         cleanup();

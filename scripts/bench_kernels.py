@@ -92,3 +92,11 @@ t = timeit(fused, reps=10)
 report("int16 ingest + 128-tap FIR + decimate by 4 fused, 16 M samples", t, "-")
 t = timeit(lambda: f.filter_smtaps(iq16_to_complex64(d_raw, 1.0 / 2048), d_taps, dsr=4), reps=10)
 report("  same as convert kernel + decimating FIR kernel", t, "-")
+
+# benchmark_czts.py:20-47 -- CZT of 10 rows x 10 000 samples onto 2001 bins (published: CPU, 3.0-4.7 ms per row)
+from pydsproutines_amd.spectralRoutines import CZTCachedGPU  # noqa: E402
+
+cz = CZTCachedGPU(10000, -1000.0, 1000.0, 1.0, 10000)
+d_rows = asarray(cn(rng, 10 * 10000).reshape(10, 10000))
+t = timeit(lambda: cz.runMany(d_rows), reps=20)
+report("CZTCachedGPU.runMany, 10 rows x 10000 -> 2001 bins", t, "3.0-4.7 ms per row (CZTCached / scipy, CPU)")
