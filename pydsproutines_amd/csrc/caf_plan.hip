@@ -309,6 +309,8 @@ static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
     p->max_blocks = (total_blocks + nb - 1) / nb * nb;
     p->partial_per_tmpl = p->max_blocks * p->tiles_per_blk;
     p->hyp_per_wg = (int)std::min<int64_t>(p->fused ? 64 : 16, (int64_t)T * F);
+    if (const char* e = getenv("CAF_HYP_PER_WG"))  // A/B switch: hypotheses per FFT work item
+        if (atoi(e) >= 1) p->hyp_per_wg = (int)std::min<int64_t>(atoi(e), (int64_t)T * F);
     if (p->fused) {
         // small jobs: fewer hypotheses per FFT work item, so that there are about two items per CU when the job
         // allows it (one block x 32 hypotheses as ONE item kept 255 CUs idle for 0.25 ms)
