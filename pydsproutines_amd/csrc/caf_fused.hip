@@ -881,14 +881,14 @@ __device__ __attribute__((noinline)) void transpose_wave_f1(const PersistParams*
 // Tile role when no surface is wanted (PersistParams::nosurf): the FFT items have left one (maximum |y|^2,
 // hypothesis) pair per delay and hypothesis group; a wave takes a 64-delay tile (lane = delay), combines the
 // groups of each template (increasing hypothesis order: the first maximum wins, as everywhere), normalises, and
-// writes the per-delay trace and the tile's peak record.  Groups never straddle templates (nfreq is a multiple of
-// the group size in this mode), and value * (1/energy * 1/||t||^2) rounds exactly as in the surface paths.
+// writes the per-delay trace and the tile's peak record.  Groups never straddle templates (PersistParams::gpt
+// groups per template in this mode), and value * (1/energy * 1/||t||^2) rounds exactly as in the surface paths.
 __device__ __attribute__((noinline)) void reduce_wave_nosurf(const PersistParams* pp_in, int z_in, int tile0_in) {
     const PersistParams* pp = uniform_ptr(pp_in);
     const int z = __builtin_amdgcn_readfirstlane(z_in), tile0 = __builtin_amdgcn_readfirstlane(tile0_in);
     const CAF_AS4 PersistParams* P = params_of(pp);
     const int32_t ntmpl = P->ntmpl, nfreq = P->nfreq, step = P->step, tiles_per_blk = P->tiles_per_blk;
-    const int32_t ngroups = P->ngroups, gpt = nfreq / P->hyp_per_wg;
+    const int32_t ngroups = P->ngroups, gpt = P->gpt;
     const int64_t num_shifts = P->num_shifts, shift_start = P->shift_start;
     const int wave_id = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
@@ -1053,8 +1053,13 @@ __device__ __attribute__((noinline)) void persistent_fft_item(lds_float2* s_d, c
     const int ngroups = P->ngroups, hyp_per_wg = P->hyp_per_wg, nhyp = P->nhyp;
     const int blk = item / ngroups;
     const int grp = item - blk * ngroups;
-    const int h0 = grp * hyp_per_wg;
-    const int h1 = min(h0 + hyp_per_wg, nhyp);
+    int h0 = grp * hyp_per_wg;
+    int h1 = min(h0 + hyp_per_wg, nhyp);
+    if (const int gpt = P->gpt) {  // groups formed per template (they never straddle two templates)
+        const int t = grp / gpt;
+        h0 = t * P->nfreq + (grp - t * gpt) * hyp_per_wg;
+        h1 = min(h0 + hyp_per_wg, (t + 1) * P->nfreq);
+    }
     if (NOSURF) {
         // no surface wanted: one (maximum, hypothesis) pair per delay and item instead of the |y|^2 tiles
         const int64_t o = ((int64_t)blk * ngroups + grp) * P->tiles_per_blk * 64;

@@ -128,7 +128,9 @@ struct PersistParams {
     float* vt;
     int32_t table_mode, nfreq, nhyp, hyp_per_wg, nblk, tiles_per_blk;
     // tile items (same meaning as launch_transpose_norm_argmax)
-    int32_t ntmpl, step, blk0, pad0;
+    int32_t ntmpl, step, blk0;
+    int32_t gpt;  // > 0: hypothesis groups are formed per template, gpt per template (group g of template t covers
+                  // hypotheses t*nfreq + g*hyp_per_wg ...); 0: flat groups of hyp_per_wg over all T*F hypotheses
     const float* tscale;
     const float* inv_e;
     int64_t num_shifts, shift_start;

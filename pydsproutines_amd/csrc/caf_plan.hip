@@ -310,7 +310,7 @@ static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
     p->partial_per_tmpl = p->max_blocks * p->tiles_per_blk;
     p->hyp_per_wg = (int)std::min<int64_t>(p->fused ? 64 : 16, (int64_t)T * F);
     if (const char* e = getenv("CAF_HYP_PER_WG"))  // A/B switch: hypotheses per FFT work item
-        if (atoi(e) >= 1) p->hyp_per_wg = (int)std::min<int64_t>(atoi(e), (int64_t)T * F);
+        if (atoi(e) >= 1) p->hyp_per_wg = (int)std::min<int64_t>(std::min(atoi(e), 256), (int64_t)T * F);
     if (p->fused) {
         // small jobs: fewer hypotheses per FFT work item, so that there are about two items per CU when the job
         // allows it (one block x 32 hypotheses as ONE item kept 255 CUs idle for 0.25 ms)
@@ -576,21 +576,29 @@ int32_t caf_plan_execute(caf_plan p, const float* d_rx, int64_t rx_len, int64_t 
             h.pq = p->d_pq;
             h.tr_slots = p->tr_slots;
             h.ngroups = (T * F + p->hyp_per_wg - 1) / p->hyp_per_wg;
-            h.n_fft = nbk * h.ngroups;
-            h.ipb = (p->tiles_per_blk + 15) / 16;  // 16 tiles per item (PQ_TILES, caf_fused.hip)
-            h.n_tr = nbk * h.ipb;
-            // No surface wanted (per-delay traces / peaks only) and hypothesis groups that do not straddle
-            // templates: the FFT items keep running per-delay maxima and write one (value, hypothesis) pair per
-            // delay and group instead of the |y|^2 tiles (1/32 of the bytes at 64 hypotheses per group).
+            // No surface wanted (per-delay traces / peaks only): the FFT items keep running per-delay maxima and
+            // write one (value, hypothesis) pair per delay and group instead of the |y|^2 tiles (1/32 of the
+            // bytes at 64 hypotheses per group).  Needs groups that do not straddle templates: with at least one
+            // group per template they are formed per template, evenly sized (F = 201: 4 groups of 51/51/51/48).
             // The pairs live in the tile buffer: vmax [block][group][tile][64] f32, then imax (same shape, i32).
             {
                 const char* e = getenv("CAF_PERSIST_NOSURF");  // A/B switch, default on
-                // the two pair arrays must fit the tile buffer they replace (true for >= 2 hypotheses per group)
-                const bool fits = 2 * (int64_t)h.ngroups <= (int64_t)T * F;
-                h.nosurf = (!out->d_surface && fits && F % p->hyp_per_wg == 0 && (!e || atoi(e))) ? 1 : 0;
+                if (!out->d_surface && F >= p->hyp_per_wg && (!e || atoi(e))) {
+                    const int gpt = (F + p->hyp_per_wg - 1) / p->hyp_per_wg;
+                    // the two pair arrays must fit the tile buffer they replace (true for >= 2 hypotheses per group)
+                    if (2 * (int64_t)T * gpt <= (int64_t)T * F) {
+                        h.nosurf = 1;
+                        h.gpt = gpt;
+                        h.hyp_per_wg = (F + gpt - 1) / gpt;
+                        h.ngroups = T * gpt;
+                    }
+                }
                 h.vmax = p->d_vt;
                 h.imax = reinterpret_cast<int32_t*>(p->d_vt + (int64_t)p->nb * h.ngroups * p->tiles_per_blk * 64);
             }
+            h.n_fft = nbk * h.ngroups;
+            h.ipb = (p->tiles_per_blk + 15) / 16;  // 16 tiles per item (PQ_TILES, caf_fused.hip)
+            h.n_tr = nbk * h.ipb;
             // both stages are one kernel: its time is booked on the multiply/FFT stage
             int32_t* h_dbg = nullptr;
             if (getenv("CAF_PERSIST_DEBUG")) {  // host-mapped role statistics, 8 ints per workgroup

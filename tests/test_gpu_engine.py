@@ -102,6 +102,36 @@ def test_shift_range_and_peak_only():
     assert (int(res2.peak_delay.get()[0]), int(res2.peak_freq.get()[0])) == (100 + r2, c2)
 
 
+@pytest.mark.parametrize("T,F", [(2, 201), (1, 65), (3, 64), (2, 130)])
+def test_no_surface_mode_any_frequency_count(T, F):
+    """Per-delay traces and peaks without a surface (running maxima in the FFT role, hypothesis groups formed per
+    template, e.g. F = 201 -> 51/51/51/48) are bit-identical to the ones of the surface run, for frequency counts
+    that are and are not multiples of the 64-hypothesis group; CZT-like explicit frequency grid."""
+    from pydsproutines_amd import CAFPlan, asarray
+
+    rng = np.random.default_rng(7 * T + F)
+    n, m = 512, 300_000
+    tm = np.stack([qpsk(rng, n) for _ in range(T)])
+    rx = cn(rng, m)
+    freqs = (np.arange(F) - F // 2) * (0.25 / n)
+    for i in range(T):
+        rx[50_000 * (i + 1) : 50_000 * (i + 1) + n] += (2 * tm[i] * np.exp(2j * np.pi * freqs[(7 * i + 3) % F] * np.arange(n))).astype(np.complex64)
+    plan = CAFPlan(tm, max_rx_len=m, freqs_norm=freqs, engine="persistent")
+    d_rx = asarray(rx)
+    a = plan.run(d_rx, surface=True)
+    want = (a.row_max.get(), a.row_arg.get(), a.peak_val.get(), a.peak_delay.get(), a.peak_freq.get())
+    np.testing.assert_array_equal(want[0], a.surface.get().max(axis=2))
+    b = plan.run(d_rx, surface=False, rows=True, peak=True)
+    for x, y in zip(want, (b.row_max.get(), b.row_arg.get(), b.peak_val.get(), b.peak_delay.get(), b.peak_freq.get())):
+        np.testing.assert_array_equal(x, y)
+    for i in range(T):
+        assert int(want[3][i]) == 50_000 * (i + 1) and int(want[4][i]) == (7 * i + 3) % F
+    c = plan.run(d_rx, shift_start=1234, num_shifts=100_001, surface=False, rows=False, peak=True)
+    j = np.argmax(want[0][:, 1234 : 1234 + 100_001], axis=1)
+    np.testing.assert_array_equal(c.peak_delay.get(), 1234 + j)
+    plan.close()
+
+
 def test_freqs_norm_table_mode_vs_groupxcorr(golden):
     """Arbitrary (off-grid) frequencies + composite template == GroupXcorr (xcorrRoutines.py:852-954)."""
     from pydsproutines_amd import CAFPlan, asarray
