@@ -260,6 +260,9 @@ CAF_EXPORT int32_t caf_iq16_fir_decimate(const int16_t* d_iq, int64_t num_sample
 /* per column of a complex64 (rows, n) matrix: max_r |z| and the first row attaining it
  * (TemplateCrossCorrelator.correlate(returnMax=True), xcorrRoutines.py:361-371) */
 CAF_EXPORT int32_t caf_colmax_abs(const float* d_z, int32_t rows, int64_t n, float* d_max, int32_t* d_arg, void* stream);
+/* the same reduction on per-template QF^2 traces (float32 (rows, n), e.g. caf_outputs.d_row_max of an F = 1 plan):
+ * d_max[i] = max_r sqrt(q2[r][i]), d_arg[i] = its first row as int64 (the dtype cp.argmax returns) */
+CAF_EXPORT int32_t caf_colmax_sqrt(const float* d_q2, int32_t rows, int64_t n, float* d_max, int64_t* d_arg, void* stream);
 /* Tone-dot zoom, dotTonesScaling_32f (genTones.cu:165-283, cupyDotTonesScaling spectralRoutines.py:580-630):
  * d_out[b][k] (complex64, ceil(len/64) x num_freqs) = sum over the 64-sample block b of
  * d_src[i] * exp(j 2 pi (f0 + k fstep) i), f0 / fstep normalised (cycles per sample); summing over b gives the

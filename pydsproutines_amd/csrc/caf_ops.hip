@@ -380,6 +380,13 @@ int32_t caf_colmax_abs(const float* d_z, int32_t rows, int64_t n, float* d_max, 
     return CAF_OK;
 }
 
+int32_t caf_colmax_sqrt(const float* d_q2, int32_t rows, int64_t n, float* d_max, int64_t* d_arg, void* stream) {
+    CAF_REQUIRE(d_q2 && d_max && d_arg && rows >= 1 && n >= 1, "caf_colmax_sqrt: bad arguments");
+    launch_colmax_sqrt(d_q2, rows, n, d_max, d_arg, (hipStream_t)stream);
+    CAF_HIP_TRY(hipGetLastError());
+    return CAF_OK;
+}
+
 int32_t caf_dot_tones(const float* d_src, int64_t len, double f0, double fstep, int32_t num_freqs, float* d_out,
                       void* stream) {
     CAF_REQUIRE(d_src && d_out && len >= 1 && num_freqs >= 1, "caf_dot_tones: bad arguments");

@@ -845,6 +845,26 @@ __global__ __launch_bounds__(256) void k_colmax_abs(const float2* __restrict__ z
     arg[i] = bi;
 }
 
+// per column i of a real (rows, n) matrix of QF^2 values: max_r sqrt(q[r][i]) and its first row (int64, the dtype
+// of cp.argmax) -- TemplateCrossCorrelator.correlate(returnMax=True) on per-template QF^2 traces; the comparison
+// is made on the float32 square roots, like the reference's on |QF| (xcorrRoutines.py:361-371)
+__global__ __launch_bounds__(256) void k_colmax_sqrt(const float* __restrict__ q, int32_t rows, int64_t n,
+                                                     float* __restrict__ maxv, int64_t* __restrict__ arg) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float bv = -1.f;
+    int64_t bi = 0;
+    for (int r = 0; r < rows; ++r) {
+        const float v = sqrtf(q[(int64_t)r * n + i]);
+        if (v > bv) {
+            bv = v;
+            bi = r;
+        }
+    }
+    maxv[i] = bv;
+    arg[i] = bi;
+}
+
 // ---------------------------------------------------------------------------------------
 // launch wrappers
 // ---------------------------------------------------------------------------------------
@@ -1168,6 +1188,10 @@ void launch_scale(float2* y, int64_t n, float scale, hipStream_t st) {
 
 void launch_colmax_abs(const float2* z, int32_t rows, int64_t n, float* maxv, int32_t* arg, hipStream_t st) {
     hipLaunchKernelGGL(k_colmax_abs, dim3(cdiv(n, 256)), dim3(256), 0, st, z, rows, n, maxv, arg);
+}
+
+void launch_colmax_sqrt(const float* q, int32_t rows, int64_t n, float* maxv, int64_t* arg, hipStream_t st) {
+    hipLaunchKernelGGL(k_colmax_sqrt, dim3(cdiv(n, 256)), dim3(256), 0, st, q, rows, n, maxv, arg);
 }
 
 }  // namespace caf

@@ -25,7 +25,7 @@ def sync():
 cases = [("C3 64 templates x 1 bin, rows+peak", dict(bins=[0]), dict(rows=True, peak=True)),
          ("C4/GPU 64 templates x 512 bins, peak only", dict(bins=np.arange(-256, 256)), dict(rows=False, peak=True))]
 for name, pk, rk in cases:
-    for engine in sys.argv[1:] or ["persistent", "fused", "rocfft"]:
+    for engine in [a for a in sys.argv[1:] if a != "tcc"] or ["persistent", "fused", "rocfft"]:
         try:
             plan = CAFPlan(tm, max_rx_len=M, grid=N, engine=engine, **pk)
         except ValueError as e:
@@ -44,3 +44,22 @@ for name, pk, rk in cases:
             name, plan.engine_used, dt * 1e3, hyps * (M - N + 1) / dt / 1e9, plan.block, plan.blocks_per_batch,
             int(res.peak_delay.get()[7])), flush=True)
         plan.close()
+
+# C3 through the reference's own class: TemplateCrossCorrelator.correlate(returnMax=True)
+if not sys.argv[1:] or "tcc" in sys.argv[1:]:
+    from pydsproutines_amd.xcorrRoutines import TemplateCrossCorrelator  # noqa: E402
+
+    d_tm = asarray(tm)
+    for fast in (True, False):
+        tcc = TemplateCrossCorrelator(d_tm, M, fastMax=fast)
+        qf, ti = tcc.correlate(d_rx, returnMax=True)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            qf, ti = tcc.correlate(d_rx, returnMax=True)
+        sync()
+        dt = (time.perf_counter() - t0) / 2
+        j = int(np.argmax(qf.get()))
+        print("C3 TemplateCrossCorrelator.correlate(returnMax=True) fastMax=%-5s %8.1f ms  peak at %d template %d" % (
+            fast, dt * 1e3, j, int(ti.get()[j])), flush=True)
+        del tcc

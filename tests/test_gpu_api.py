@@ -381,6 +381,14 @@ def test_kat4_template_cross_correlator(golden):
     np.testing.assert_allclose(np.max(np.abs(z), axis=0), out1d.get(), rtol=3e-7)
     assert out1d.get()[20] == pytest.approx(1.0, abs=1e-5) and ti.get()[20] == 0
     assert out1d.get()[40] == pytest.approx(1.0, abs=1e-5) and ti.get()[40] == 1
+    # fastMax: per-template QF^2 traces from the one-launch engine, same values to float32 rounding
+    fast = TemplateCrossCorrelator(asarray(np.vstack((t1, t2))), x.size, fastMax=True)
+    f1d, fti = fast.correlate(dx, returnMax=True)
+    assert f1d.dtype == np.float32 and fti.dtype == np.int64 and f1d.shape == (81,)
+    np.testing.assert_allclose(f1d.get(), out1d.get(), atol=2e-6)
+    clear = np.abs(mag[0] - mag[1]) > 1e-5
+    np.testing.assert_array_equal(fti.get()[clear], ti.get()[clear])
+    np.testing.assert_allclose(fast.correlate(dx).get(), z, atol=1e-6)  # the complex output is unchanged
     with pytest.raises(ValueError):
         both.correlate(asarray(x[:50]))
     with pytest.raises(TypeError):
