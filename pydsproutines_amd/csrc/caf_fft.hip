@@ -2,7 +2,9 @@
 // batched 1-D complex64 transforms (in place or out of place) with an explicit batch distance.
 #include <rocfft/rocfft.h>
 
+#include <map>
 #include <mutex>
+#include <tuple>
 
 #include "caf_internal.h"
 
@@ -61,6 +63,65 @@ void FftPlan::destroy() {
     info = nullptr;
     plan = nullptr;
     work = nullptr;
+}
+
+// ---- checkout cache of rocFFT plans --------------------------------------------------------------------------
+// rocfft_plan_create costs milliseconds (kernel selection / code-object loading), more than a small CAF job
+// itself; the per-call entry points of the host layer (fastXcorr, cztXcorr, ...) build a CAF plan per call.
+// Plans are therefore parked on release and handed out again for the same (device, direction, length, batch,
+// distance, placement).  A parked plan has exactly one owner after acquire (its work buffer is not shared).
+namespace {
+struct FftKey {
+    int dev, inverse, inplace;
+    size_t len, batch, dist;
+    bool operator<(const FftKey& o) const {
+        return std::tie(dev, inverse, inplace, len, batch, dist) < std::tie(o.dev, o.inverse, o.inplace, o.len, o.batch, o.dist);
+    }
+};
+std::mutex g_fft_mu;
+std::multimap<FftKey, FftPlan> g_fft_parked;
+constexpr size_t FFT_PARK_MAX_PLANS = 32;
+constexpr size_t FFT_PARK_MAX_WORK = (size_t)256 << 20;  // plans with larger work buffers are destroyed
+}  // namespace
+
+int fft_plan_acquire(FftPlan* out, bool inverse, size_t len, size_t batch, size_t dist, bool inplace) {
+    int dev = 0;
+    CAF_HIP_TRY(hipGetDevice(&dev));
+    const FftKey k{dev, inverse ? 1 : 0, inplace ? 1 : 0, len, batch, dist};
+    {
+        std::lock_guard<std::mutex> lk(g_fft_mu);
+        auto it = g_fft_parked.find(k);
+        if (it != g_fft_parked.end()) {
+            *out = it->second;
+            g_fft_parked.erase(it);
+            return CAF_OK;
+        }
+    }
+    *out = FftPlan();
+    const int rc = out->create(inverse, len, batch, dist, inplace);
+    if (rc) out->destroy();
+    out->key_dev = dev;
+    out->key_inverse = inverse;
+    out->key_inplace = inplace;
+    out->key_len = len;
+    out->key_batch = batch;
+    out->key_dist = dist;
+    return rc;
+}
+
+void fft_plan_release(FftPlan* p) {
+    if (!p->plan) return;
+    {
+        std::lock_guard<std::mutex> lk(g_fft_mu);
+        if (p->key_len && p->work_bytes <= FFT_PARK_MAX_WORK && g_fft_parked.size() < FFT_PARK_MAX_PLANS) {
+            g_fft_parked.emplace(FftKey{p->key_dev, p->key_inverse ? 1 : 0, p->key_inplace ? 1 : 0, p->key_len, p->key_batch,
+                                        p->key_dist},
+                                 *p);
+            *p = FftPlan();
+            return;
+        }
+    }
+    p->destroy();
 }
 
 }  // namespace caf

@@ -44,6 +44,8 @@ void launch_inv_energy(const double* prefix, int64_t shift_start, int64_t num_sh
 void launch_gather_blocks(const float2* rx, int64_t rx_len, int64_t src0, int32_t step, int32_t bsz, int32_t nblk,
                           float2* xb, hipStream_t st);
 void launch_conj_scale(float2* h, int64_t n, float scale, hipStream_t st);
+void launch_build_hyp_time(const float2* tm, const double* nu, int32_t n_tmpl, int32_t bsz, int32_t nfreq, int32_t ntmpl,
+                           int32_t conj_u, float2* hc, hipStream_t st);
 void launch_spectral_mul(int mode, const float2* xb, const float2* hc, const int32_t* shifts, int32_t bsz,
                          int32_t pitch, int32_t nfreq, int32_t nhyp, int32_t hyp_per_wg, int32_t nblk, float2* pbuf,
                          hipStream_t st);
@@ -160,7 +162,14 @@ struct FftPlan {
     int create(bool inverse, size_t len, size_t batch, size_t dist, bool inplace = true);
     int exec(void* in, void* out, hipStream_t st);
     void destroy();
+    // identity for the checkout cache (set by fft_plan_acquire; key_len == 0: not cacheable)
+    int key_dev = 0;
+    bool key_inverse = false, key_inplace = true;
+    size_t key_len = 0, key_batch = 0, key_dist = 0;
 };
+// checkout cache: acquire hands out a parked plan of the same shape or creates one; release parks it again
+int fft_plan_acquire(FftPlan* out, bool inverse, size_t len, size_t batch, size_t dist, bool inplace = true);
+void fft_plan_release(FftPlan* p);
 
 #define CAF_REQUIRE(cond, msg)      \
     do {                            \

@@ -455,6 +455,38 @@ void launch_gather_blocks(const float2* rx, int64_t rx_len, int64_t src0, int32_
                        lb, total, xb);
 }
 
+// Explicit-frequency hypotheses in the time domain (plan creation, CAF_FREQ_NORM): row (t, f) of the B-point
+// spectrum table gets u_t[n] * exp(+j 2 pi nu_f n) for n < N and zeros up to B, u = tmpl or conj(tmpl).
+// The phase is reduced in cycles in float64 before the trig call (full accuracy for large nu * n), the product
+// is formed in float64 and rounded once -- what the host loop this replaces did, T*F*N sincos calls faster.
+__global__ __launch_bounds__(256) void k_build_hyp_time(const float2* __restrict__ tm, const double* __restrict__ nu,
+                                                        int32_t n_tmpl, int32_t bsz, int32_t nfreq, int32_t conj_u,
+                                                        float2* __restrict__ hc) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= bsz) return;
+    const int f = blockIdx.y, t = blockIdx.z;
+    float2 o = make_float2(0.f, 0.f);
+    if (n < n_tmpl) {
+        const float2 u = tm[(int64_t)t * n_tmpl + n];
+        const double ur = u.x, ui = conj_u ? -(double)u.y : (double)u.y;
+        double cyc = nu[f] * (double)n;
+        cyc -= floor(cyc);
+        double s, c;
+        sincos(2.0 * M_PI * cyc, &s, &c);
+        o = make_float2((float)(ur * c - ui * s), (float)(ur * s + ui * c));
+    }
+    hc[((int64_t)t * nfreq + f) * bsz + n] = o;
+}
+
+void launch_build_hyp_time(const float2* tm, const double* nu, int32_t n_tmpl, int32_t bsz, int32_t nfreq, int32_t ntmpl,
+                           int32_t conj_u, float2* hc, hipStream_t st) {
+    for (int f0 = 0; f0 < nfreq; f0 += 65535) {  // grid.y limit
+        const int nf = std::min(65535, nfreq - f0);
+        hipLaunchKernelGGL(k_build_hyp_time, dim3((unsigned)((bsz + 255) / 256), (unsigned)nf, (unsigned)ntmpl), dim3(256),
+                           0, st, tm, nu + f0, n_tmpl, bsz, nfreq, conj_u, hc + (int64_t)f0 * bsz);
+    }
+}
+
 void launch_conj_scale(float2* h, int64_t n, float scale, hipStream_t st) {
     hipLaunchKernelGGL(k_conj_scale, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, h, n, scale);
 }

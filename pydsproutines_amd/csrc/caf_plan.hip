@@ -20,6 +20,50 @@ void set_error(const std::string& msg) { g_last_error = msg; }
 
 using namespace caf;
 
+// Auxiliary stream + fork/join events of a plan, checked out of a small per-device list: creating and destroying
+// a HIP stream costs ~1 ms, as much as a whole small CAF job, and the per-call entry points of the host layer
+// build a plan per call.  A released set is idle (the plan synchronises the device before releasing).
+namespace {
+struct AuxSet {
+    int dev;
+    hipStream_t s;
+    hipEvent_t fork, join;
+};
+std::mutex g_aux_mu;
+std::vector<AuxSet> g_aux_idle;
+
+int aux_acquire(int dev, hipStream_t* s, hipEvent_t* fork, hipEvent_t* join) {
+    {
+        std::lock_guard<std::mutex> lk(g_aux_mu);
+        for (size_t i = 0; i < g_aux_idle.size(); ++i)
+            if (g_aux_idle[i].dev == dev) {
+                *s = g_aux_idle[i].s;
+                *fork = g_aux_idle[i].fork;
+                *join = g_aux_idle[i].join;
+                g_aux_idle.erase(g_aux_idle.begin() + (long)i);
+                return CAF_OK;
+            }
+    }
+    CAF_HIP_TRY(hipStreamCreateWithFlags(s, hipStreamNonBlocking));
+    CAF_HIP_TRY(hipEventCreateWithFlags(fork, hipEventDisableTiming));
+    CAF_HIP_TRY(hipEventCreateWithFlags(join, hipEventDisableTiming));
+    return CAF_OK;
+}
+
+void aux_release(int dev, hipStream_t s, hipEvent_t fork, hipEvent_t join) {
+    if (s && fork && join) {
+        std::lock_guard<std::mutex> lk(g_aux_mu);
+        if (g_aux_idle.size() < 16) {
+            g_aux_idle.push_back(AuxSet{dev, s, fork, join});
+            return;
+        }
+    }
+    if (fork) (void)hipEventDestroy(fork);
+    if (join) (void)hipEventDestroy(join);
+    if (s) (void)hipStreamDestroy(s);
+}
+}  // namespace
+
 struct caf_plan_t {
     int T = 0, N = 0, F = 0, G = 0;
     int freq_mode = 0, mul_mode = 0;
@@ -99,25 +143,65 @@ struct caf_plan_t {
     template <typename Tp>
     int alloc(Tp** p, int64_t count) {
         const int64_t bytes = count * (int64_t)sizeof(Tp);
-        CAF_HIP_TRY(hipMalloc((void**)p, (size_t)std::max<int64_t>(bytes, 16)));
+        // through the caching allocator: the per-call entry points of the host layer build a plan per call
+        const int rc = pool_alloc((void**)p, std::max<int64_t>(bytes, 16));
+        if (rc) return rc;
         workspace_bytes += bytes;
         return CAF_OK;
     }
     void release() {
         drain();
+        // nothing of this plan may still be running when its buffers and FFT plans go back to the caches
+        (void)hipDeviceSynchronize();
         for (auto e : pool) (void)hipEventDestroy(e);
         pool.clear();
-        fwd.destroy();
-        inv.destroy();
-        if (ev_fork) (void)hipEventDestroy(ev_fork);
-        if (ev_join) (void)hipEventDestroy(ev_join);
-        if (s_aux) (void)hipStreamDestroy(s_aux);
+        fft_plan_release(&fwd);
+        fft_plan_release(&inv);
+        aux_release(device, s_aux, ev_fork, ev_join);
+        s_aux = nullptr;
+        ev_fork = ev_join = nullptr;
         void* ptrs[] = {d_hc,  d_shifts, d_tscale, d_gstart,  d_glen, d_tile_sums, d_prefix, d_inv_e,
-                        d_xb,  d_pbuf,   d_partial, d_vt,     d_tw1,  d_tw23,      d_params, d_pq};
+                        d_xb,  d_pbuf,   d_partial, d_vt,     d_params, d_pq};  // (d_tw1 / d_tw23 are shared, per device)
         for (void* p : ptrs)
-            if (p) (void)hipFree(p);
+            if (p) (void)pool_free(p);
     }
 };
+
+// inter-pass twiddles of the 16*16*16*4 decomposition (caf_fused.hip), computed in f64 once per device and kept
+// for the life of the process: every fused plan reads the same two small tables
+static int fused_twiddles(int device, float2** tw1_out, float2** tw23_out) {
+    static std::mutex mu;
+    static std::vector<std::pair<float2*, float2*>> per_dev;
+    std::lock_guard<std::mutex> lk(mu);
+    if ((int)per_dev.size() <= device) per_dev.resize(device + 1, {nullptr, nullptr});
+    if (!per_dev[device].first) {
+        std::vector<std::complex<float>> tw1(16 * 1024), tw23(16 * 64 + 16 * 4);
+        auto cis = [](double num, double den) {
+            const double ph = 2.0 * M_PI * std::fmod(num, den) / den;
+            return std::complex<float>((float)std::cos(ph), (float)std::sin(ph));
+        };
+        for (int n1 = 0; n1 < 16; ++n1)
+            for (int m2 = 0; m2 < 1024; ++m2) tw1[n1 * 1024 + m2] = cis((double)n1 * m2, 16384.0);
+        for (int n2 = 0; n2 < 16; ++n2)
+            for (int c = 0; c < 64; ++c) tw23[n2 * 64 + c] = cis((double)n2 * c, 1024.0);
+        for (int n3 = 0; n3 < 16; ++n3)
+            for (int dd = 0; dd < 4; ++dd) tw23[1024 + n3 * 4 + dd] = cis((double)n3 * dd, 64.0);
+        float2 *a = nullptr, *b = nullptr;
+        CAF_HIP_TRY(hipMalloc((void**)&a, tw1.size() * 8));
+        hipError_t e = hipMalloc((void**)&b, tw23.size() * 8);
+        if (e == hipSuccess) e = hipMemcpy(a, tw1.data(), tw1.size() * 8, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(b, tw23.data(), tw23.size() * 8, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            (void)hipFree(a);
+            (void)hipFree(b);
+            CAF_HIP_TRY(e);
+        }
+        per_dev[device] = {a, b};
+    }
+    *tw1_out = per_dev[device].first;
+    *tw23_out = per_dev[device].second;
+    return CAF_OK;
+}
 
 static int ilog2_ceil(int64_t v) {
     int l = 0;
@@ -203,8 +287,11 @@ int32_t caf_stream_sync(void* stream) {
 
 int32_t caf_plan_destroy(caf_plan plan) {
     if (!plan) return CAF_OK;
-    (void)hipSetDevice(plan->device);
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    if (cur != plan->device) (void)hipSetDevice(plan->device);
     plan->release();
+    if (cur >= 0 && cur != plan->device) (void)hipSetDevice(cur);  // leave the caller's current device as it was
     delete plan;
     return CAF_OK;
 }
@@ -344,26 +431,11 @@ static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
     if ((rc = p->alloc(&p->d_xb, (p->max_blocks + p->fwd_chunk) * B))) return rc;
     if (p->fused) {
         if ((rc = p->alloc(&p->d_vt, (int64_t)nb * p->tiles_per_blk * T * F * 64))) return rc;
-        if ((rc = p->alloc(&p->d_tw1, 16 * 1024))) return rc;
-        if ((rc = p->alloc(&p->d_tw23, 16 * 64 + 16 * 4))) return rc;
-        // inter-pass twiddles of the 16*16*16*4 decomposition, computed in f64 (caf_fused.hip)
-        std::vector<std::complex<float>> tw1(16 * 1024), tw23(16 * 64 + 16 * 4);
-        auto cis = [](double num, double den) {
-            const double ph = 2.0 * M_PI * std::fmod(num, den) / den;
-            return std::complex<float>((float)std::cos(ph), (float)std::sin(ph));
-        };
-        for (int n1 = 0; n1 < 16; ++n1)
-            for (int m2 = 0; m2 < 1024; ++m2) tw1[n1 * 1024 + m2] = cis((double)n1 * m2, 16384.0);
-        for (int n2 = 0; n2 < 16; ++n2)
-            for (int c = 0; c < 64; ++c) tw23[n2 * 64 + c] = cis((double)n2 * c, 1024.0);
-        for (int n3 = 0; n3 < 16; ++n3)
-            for (int dd = 0; dd < 4; ++dd) tw23[1024 + n3 * 4 + dd] = cis((double)n3 * dd, 64.0);
-        CAF_HIP_TRY(hipMemcpy(p->d_tw1, tw1.data(), tw1.size() * 8, hipMemcpyHostToDevice));
-        CAF_HIP_TRY(hipMemcpy(p->d_tw23, tw23.data(), tw23.size() * 8, hipMemcpyHostToDevice));
+        if ((rc = fused_twiddles(p->device, &p->d_tw1, &p->d_tw23))) return rc;  // per device, shared by all plans
         if (p->persistent) {
-            hipDeviceProp_t prop;
-            CAF_HIP_TRY(hipGetDeviceProperties(&prop, p->device));
-            p->n_cus = prop.multiProcessorCount;  // one resident 1024-thread workgroup per CU
+            int ncu = 0;  // (hipGetDeviceProperties costs ~1 ms per call; the attribute query does not)
+            CAF_HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, p->device));
+            p->n_cus = ncu;  // one resident 1024-thread workgroup per CU
             p->tr_slots = 12;                     // 96 CUs look at the tile queue first (measured optimum on C2: 10..14)
             if (const char* e = getenv("CAF_PERSIST_WGS")) p->n_cus = std::max(1, atoi(e));
             if (const char* e = getenv("CAF_PERSIST_TR_SLOTS")) p->tr_slots = std::max(0, atoi(e));
@@ -380,13 +452,35 @@ static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
     // template spectra: u = auto_conj ? tmpl : conj(tmpl);  u_f[n] = u[n] exp(+j 2 pi nu_f n);
     // Hc = conj(FFT_B(u_f)) / B  (rocFFT's inverse is unnormalised, 1/B is folded in here)
     std::vector<float> tscale(T);
-    {
+    const std::complex<float>* tm = reinterpret_cast<const std::complex<float>*>(d->h_templates);
+    for (int t = 0; t < T; ++t) {
+        double e = 0.0;
+        for (int n = 0; n < N; ++n) e += std::norm(std::complex<double>(tm[(size_t)t * N + n]));
+        tscale[t] = (float)(1.0 / e);
+    }
+    void *tmp_tm = nullptr, *tmp_nu = nullptr;  // inputs of the device-side table build, freed after the sync below
+    auto free_tmp = [&]() {
+        (void)pool_free(tmp_tm);
+        (void)pool_free(tmp_nu);
+        tmp_tm = tmp_nu = nullptr;
+    };
+    if (p->mul_mode == 2 && T <= 65535) {
+        // explicit frequencies: the T*F modulated templates are generated on the device (k_build_hyp_time)
+        if ((rc = pool_alloc(&tmp_tm, (int64_t)T * N * 8)) || (rc = pool_alloc(&tmp_nu, (int64_t)F * 8))) {
+            free_tmp();
+            return rc;
+        }
+        hipError_t e1 = hipMemcpy(tmp_tm, tm, (size_t)T * N * 8, hipMemcpyHostToDevice);
+        if (e1 == hipSuccess) e1 = hipMemcpy(tmp_nu, d->h_freqs_norm, (size_t)F * 8, hipMemcpyHostToDevice);
+        if (e1 != hipSuccess) {
+            free_tmp();
+            CAF_HIP_TRY(e1);
+        }
+        launch_build_hyp_time((const float2*)tmp_tm, (const double*)tmp_nu, N, B, F, T, d->auto_conj ? 0 : 1, p->d_hc,
+                              nullptr);
+    } else {
         std::vector<std::complex<float>> host((size_t)nspec * B, std::complex<float>(0.f, 0.f));
-        const std::complex<float>* tm = reinterpret_cast<const std::complex<float>*>(d->h_templates);
         for (int t = 0; t < T; ++t) {
-            double e = 0.0;
-            for (int n = 0; n < N; ++n) e += std::norm(std::complex<double>(tm[(size_t)t * N + n]));
-            tscale[t] = (float)(1.0 / e);
             if (p->mul_mode != 2) {
                 for (int n = 0; n < N; ++n) {
                     std::complex<float> u = tm[(size_t)t * N + n];
@@ -413,11 +507,12 @@ static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
     }
     {
         FftPlan tmp;
-        rc = tmp.create(false, (size_t)B, (size_t)nspec, (size_t)B);
+        rc = fft_plan_acquire(&tmp, false, (size_t)B, (size_t)nspec, (size_t)B);
         if (rc == CAF_OK) rc = tmp.exec(p->d_hc, nullptr, nullptr);
         if (rc == CAF_OK) launch_conj_scale(p->d_hc, nspec * B, 1.0f / (float)B, nullptr);
         hipError_t e = hipStreamSynchronize(nullptr);
-        tmp.destroy();
+        fft_plan_release(&tmp);
+        free_tmp();
         if (rc) return rc;
         CAF_HIP_TRY(e);
     }
@@ -427,14 +522,12 @@ static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
     CAF_HIP_TRY(hipMemcpy(p->d_gstart, gs.data(), gs.size() * 4, hipMemcpyHostToDevice));
     CAF_HIP_TRY(hipMemcpy(p->d_glen, gl.data(), gl.size() * 4, hipMemcpyHostToDevice));
 
-    if ((rc = p->fwd.create(false, (size_t)B, (size_t)p->fwd_chunk, (size_t)B))) return rc;
-    if (!p->fused && (rc = p->inv.create(true, (size_t)B, (size_t)nb * T * F, (size_t)p->pitch))) return rc;
+    if ((rc = fft_plan_acquire(&p->fwd, false, (size_t)B, (size_t)p->fwd_chunk, (size_t)B))) return rc;
+    if (!p->fused && (rc = fft_plan_acquire(&p->inv, true, (size_t)B, (size_t)nb * T * F, (size_t)p->pitch))) return rc;
     p->workspace_bytes += (int64_t)p->fwd.work_bytes + (int64_t)p->inv.work_bytes;
     const char* aux = getenv("CAF_AUX_STREAM");  // A/B switch, default on
     if (!aux || atoi(aux)) {
-        CAF_HIP_TRY(hipStreamCreateWithFlags(&p->s_aux, hipStreamNonBlocking));
-        CAF_HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
-        CAF_HIP_TRY(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
+        if ((rc = aux_acquire(p->device, &p->s_aux, &p->ev_fork, &p->ev_join))) return rc;
     }
     return CAF_OK;
 }
