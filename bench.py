@@ -158,6 +158,8 @@ def main():
     ap.add_argument("--engine", default="auto", choices=["auto", "persistent", "fused", "rocfft"])
     ap.add_argument("--no-surface", action="store_true", help="peak-only mode (no CAF surface written)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side-figure", action="store_true",
+                    help="skip the untimed no-surface side run (profiling: only the measured configuration launches)")
     args = ap.parse_args()
 
     import torch
@@ -249,7 +251,7 @@ def main():
 
     # side figure (not the metric): the same job when only the per-delay argmax and the peak are wanted
     extra = None
-    if world == 1 and surface_on:
+    if world == 1 and surface_on and not args.no_side_figure:
         stream = torch.cuda.current_stream().cuda_stream
         for _ in range(2):
             plan.run(rx, surface=False, rows=True, peak=True, stream=stream, out=res)
