@@ -229,6 +229,11 @@ CAF_EXPORT int32_t caf_copy_groups(const float* d_x, float* d_y, const int32_t* 
 /* findLocalMaxima (peakfinding.cu:14-58): indices in ASCENDING order (deterministic), *d_count = total found */
 CAF_EXPORT int32_t caf_find_local_maxima(const float* d_x, int64_t n, float min_height, int32_t max_peaks,
                                          int32_t* d_peak_index, int32_t* d_count, void* stream);
+/* d_out[i] = d_x[d_index[i]] for 4-byte elements (float32 / int32; 0 for indices outside [0, xlen)): the values and
+ * frequency arguments at the candidate peaks without copying whole per-delay traces to the host (the fancy
+ * indexing d_trace[d_idx] of a cupy caller after cupyFindLocalMaxima, cupyExtensions.py:651-686) */
+CAF_EXPORT int32_t caf_gather_b32(const void* d_x, int64_t xlen, const int32_t* d_index, int64_t n, void* d_out,
+                                  void* stream);
 /* filter_smtaps* (filter.cu:9-181) == scipy.signal.lfilter(taps, 1, x)[ds_phase::dsr] with carried-in history */
 CAF_EXPORT int32_t caf_fir_lfilter(const float* d_x, int64_t n, const float* d_taps, int32_t num_taps,
                                    const float* d_delay, int32_t delay_len, int32_t dsr, int32_t ds_phase, float* d_out,

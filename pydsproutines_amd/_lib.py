@@ -124,6 +124,7 @@ _SIGNATURES = {
     "caf_copy_slices_to_matrix": [_P, _I64, _P, _I32, _I64, _I64, _I32, _I64, _P, _P],
     "caf_copy_groups": [_P, _P, _P, _P, _P, _I32, _P],
     "caf_find_local_maxima": [_P, _I64, ct.c_float, _I32, _P, _P, _P],
+    "caf_gather_b32": [_P, _I64, _P, _I64, _P, _P],
     "caf_fir_lfilter": [_P, _I64, _P, _I32, _P, _I32, _I32, _I32, _P, _I64, _P],
     "caf_upfirdn": [_P, _I64, _I64, _P, _I32, _I32, _I32, _P, _P, _I64, _P],
     "caf_czt_run_many": [_P, _I64, _I32, _I32, _I32, _P, _P, _P, _P, _P],

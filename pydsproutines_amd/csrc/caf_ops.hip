@@ -277,11 +277,18 @@ int32_t caf_find_local_maxima(const float* d_x, int64_t n, float min_height, int
     CAF_REQUIRE(d_x && d_peak_index && d_count && n >= 1 && max_peaks >= 1, "caf_find_local_maxima: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     Scratch sc;
-    uint8_t* flags = nullptr;
-    int rc = sc.get(&flags, n);
+    int32_t* tiles = nullptr;
+    int rc = sc.get(&tiles, local_maxima_scratch_ints(n));
     if (rc) return rc;
-    launch_find_local_maxima(d_x, n, min_height, flags, max_peaks, d_peak_index, d_count, st);
+    launch_find_local_maxima(d_x, n, min_height, tiles, max_peaks, d_peak_index, d_count, st);
     CAF_HIP_TRY(hipStreamSynchronize(st));
+    CAF_HIP_TRY(hipGetLastError());
+    return CAF_OK;
+}
+
+int32_t caf_gather_b32(const void* d_x, int64_t xlen, const int32_t* d_index, int64_t n, void* d_out, void* stream) {
+    CAF_REQUIRE(d_x && d_index && d_out && xlen >= 1 && n >= 0, "caf_gather_b32: bad arguments");
+    launch_gather_b32(d_x, xlen, d_index, n, d_out, (hipStream_t)stream);
     CAF_HIP_TRY(hipGetLastError());
     return CAF_OK;
 }

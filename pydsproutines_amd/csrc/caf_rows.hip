@@ -516,44 +516,102 @@ __global__ __launch_bounds__(256) void k_copy_groups(const float2* __restrict__ 
     for (int i = threadIdx.x; i < lens[b]; i += 256) y[yo + i] = x[xo + i];
 }
 
-// findLocalMaxima: ordered compaction in two passes (flags -> host-free ordered scan is overkill for the
-// sparse peak lists this is used for): pass 1 marks, pass 2 is an ordered atomic-free single-workgroup scan.
-__global__ __launch_bounds__(256) void k_local_max_flags(const float* __restrict__ x, int64_t n, float min_height,
-                                                         uint8_t* __restrict__ flags) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+// findLocalMaxima: ordered (ascending index) compaction without atomics, in three launches that all fill the chip:
+//   1. every workgroup counts the local maxima of its LM_TILE samples,
+//   2. one workgroup turns the tile counts into exclusive offsets (+ the total),
+//   3. every workgroup recomputes its flags and writes its indices at offset + rank.
+// (x is read twice instead of writing and re-reading a flag array; the single-workgroup compaction this replaces
+// took ~16 ms on a 2^24-sample trace.)
+constexpr int LM_TILE = 4096;  // samples per workgroup (16 per thread)
+
+__device__ __forceinline__ bool lm_flag(const float* __restrict__ x, int64_t n, int64_t i, float min_height) {
+    if (i >= n) return false;
     const float y = x[i];
     const float l = i > 0 ? x[i - 1] : 0.f;
     const float r = i + 1 < n ? x[i + 1] : 0.f;
-    flags[i] = (y > min_height && y > l && y > r) ? 1 : 0;
+    return y > min_height && y > l && y > r;
 }
 
-__global__ __launch_bounds__(1024) void k_compact_flags(const uint8_t* __restrict__ flags, int64_t n, int32_t max_out,
-                                                        int32_t* __restrict__ idx, int32_t* __restrict__ count) {
+__global__ __launch_bounds__(256) void k_local_max_count(const float* __restrict__ x, int64_t n, float min_height,
+                                                         int32_t* __restrict__ tile_count) {
+    __shared__ int32_t s_w[4];
+    const int64_t i0 = (int64_t)blockIdx.x * LM_TILE;
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < LM_TILE / 256; ++k) c += lm_flag(x, n, i0 + k * 256 + threadIdx.x, min_height) ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_count[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+// in place: tile_count[t] -> number of maxima before tile t; tile_count[ntiles] and *count = the total
+__global__ __launch_bounds__(1024) void k_local_max_scan(int32_t* __restrict__ tile_count, int64_t ntiles,
+                                                         int32_t* __restrict__ count) {
     __shared__ int32_t s_wave[16];
     __shared__ int32_t s_base;
     if (threadIdx.x == 0) s_base = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int64_t c = 0; c < n; c += 1024) {
-        const int64_t i = c + threadIdx.x;
-        const int f = (i < n) ? flags[i] : 0;
-        const unsigned long long m = __ballot(f);
-        const int within = __popcll(m & ((1ull << lane) - 1ull));
-        if (lane == 0) s_wave[wave] = __popcll(m);
+    for (int64_t c0 = 0; c0 < ntiles; c0 += 1024) {
+        const int64_t t = c0 + threadIdx.x;
+        const int v = t < ntiles ? tile_count[t] : 0;
+        int incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int u = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += u;
+        }
+        if (lane == 63) s_wave[wave] = incl;
         __syncthreads();
         int off = s_base;
         for (int w = 0; w < wave; ++w) off += s_wave[w];
-        if (f && off + within < max_out) idx[off + within] = (int32_t)i;
+        if (t < ntiles) tile_count[t] = off + incl - v;
         __syncthreads();
-        if (threadIdx.x == 0) {
-            int t = 0;
-            for (int w = 0; w < 16; ++w) t += s_wave[w];
-            s_base += t;
-        }
+        if (threadIdx.x == 1023) s_base = off + incl;
         __syncthreads();
     }
-    if (threadIdx.x == 0) *count = s_base;
+    if (threadIdx.x == 0) {
+        tile_count[ntiles] = s_base;
+        *count = s_base;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_local_max_write(const float* __restrict__ x, int64_t n, float min_height,
+                                                         const int32_t* __restrict__ tile_base, int32_t max_out,
+                                                         int32_t* __restrict__ idx) {
+    __shared__ int32_t s_w[4];
+    __shared__ int32_t s_run;
+    const int64_t i0 = (int64_t)blockIdx.x * LM_TILE;
+    if (tile_base[blockIdx.x + 1] == tile_base[blockIdx.x]) return;  // nothing in this tile (uniform)
+    if (threadIdx.x == 0) s_run = tile_base[blockIdx.x];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k = 0; k < LM_TILE / 256; ++k) {  // ascending index order: chunk k holds samples i0 + 256 k ...
+        const int64_t i = i0 + k * 256 + threadIdx.x;
+        const bool f = lm_flag(x, n, i, min_height);
+        const unsigned long long m = __ballot(f);
+        const int within = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) s_w[wave] = __popcll(m);
+        __syncthreads();
+        int off = s_run;
+        for (int w = 0; w < wave; ++w) off += s_w[w];
+        if (f && off + within < max_out) idx[off + within] = (int32_t)i;
+        __syncthreads();
+        if (threadIdx.x == 0) s_run += s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        __syncthreads();
+    }
+}
+
+// out[i] = x[idx[i]] for 4-byte elements (values / arguments of the candidate peaks without copying whole traces)
+__global__ __launch_bounds__(256) void k_gather_b32(const uint32_t* __restrict__ x, int64_t xlen,
+                                                    const int32_t* __restrict__ idx, int64_t n,
+                                                    uint32_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t j = idx[i];
+    out[i] = (j >= 0 && j < xlen) ? x[j] : 0u;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1092,10 +1150,21 @@ void launch_copy_groups(const float2* x, float2* y, const int32_t* xs, const int
     if (ngroups > 0) hipLaunchKernelGGL(k_copy_groups, dim3(ngroups), dim3(256), 0, st, x, y, xs, ys, lens);
 }
 
-void launch_find_local_maxima(const float* x, int64_t n, float min_height, uint8_t* flags, int32_t max_out,
+int64_t local_maxima_scratch_ints(int64_t n) { return (n + LM_TILE - 1) / LM_TILE + 1; }
+
+void launch_find_local_maxima(const float* x, int64_t n, float min_height, int32_t* tile_scratch, int32_t max_out,
                               int32_t* idx, int32_t* count, hipStream_t st) {
-    hipLaunchKernelGGL(k_local_max_flags, dim3(cdiv(n, 256)), dim3(256), 0, st, x, n, min_height, flags);
-    hipLaunchKernelGGL(k_compact_flags, dim3(1), dim3(1024), 0, st, flags, n, max_out, idx, count);
+    const int64_t ntiles = (n + LM_TILE - 1) / LM_TILE;
+    hipLaunchKernelGGL(k_local_max_count, dim3((unsigned)ntiles), dim3(256), 0, st, x, n, min_height, tile_scratch);
+    hipLaunchKernelGGL(k_local_max_scan, dim3(1), dim3(1024), 0, st, tile_scratch, ntiles, count);
+    hipLaunchKernelGGL(k_local_max_write, dim3((unsigned)ntiles), dim3(256), 0, st, x, n, min_height, tile_scratch, max_out,
+                       idx);
+}
+
+void launch_gather_b32(const void* x, int64_t xlen, const int32_t* idx, int64_t n, void* out, hipStream_t st) {
+    if (n > 0)
+        hipLaunchKernelGGL(k_gather_b32, dim3(cdiv(n, 256)), dim3(256), 0, st, (const uint32_t*)x, xlen, idx, n,
+                           (uint32_t*)out);
 }
 
 int moving_tile_max_window() { return MAT_MAXL; }

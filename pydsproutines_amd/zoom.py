@@ -13,16 +13,33 @@ benchmarks/benchmark_groupXcorrs.py:37-72) -- with device kernels end to end:
 Only the tiny peak list (<= maxNumPeaks indices) is ordered on the host.
 """
 
+import ctypes as ct
+
 import numpy as np
 
+from . import _lib
 from .cupyExtensions import (
     cupyArgmaxAbsRows_complex64,
     cupyComplexMagnSq,
     cupyFindLocalMaxima,
     multiplySlidesNormalised,
 )
-from .devarray import DeviceArray, asarray, requireDeviceArray
+from .devarray import DeviceArray, asarray, empty, requireDeviceArray
 from .spectralRoutines import CZTCachedGPU
+
+
+def gather(d_x, d_idx, n=None):
+    """d_x[d_idx[:n]] on the device for float32 / int32 arrays (``caf_gather_b32``); returns a host array."""
+    requireDeviceArray(d_x)
+    if d_x.dtype.itemsize != 4:
+        raise TypeError("4-byte element types only, found %s" % d_x.dtype)
+    if d_idx.dtype != np.int32:
+        raise TypeError("Must be int32, found %s" % d_idx.dtype)
+    n = d_idx.size if n is None else int(n)
+    out = empty(max(n, 1), d_x.dtype)
+    _lib.check(_lib.load().caf_gather_b32(ct.c_void_p(d_x.ptr), d_x.size, ct.c_void_p(d_idx.ptr), n, ct.c_void_p(out.ptr),
+                                          None), "caf_gather_b32")
+    return out.get()[:n]
 
 
 def topk_local_maxima(d_trace, k, min_height, maxNumPeaks=100000):
@@ -32,11 +49,11 @@ def topk_local_maxima(d_trace, k, min_height, maxNumPeaks=100000):
     n = int(cnt.get()[0])
     if n > maxNumPeaks:
         raise ValueError("%d local maxima above min_height=%g exceed maxNumPeaks=%d; raise min_height" % (n, min_height, maxNumPeaks))
-    idx = idx.get()[:n]
     if n == 0:
-        return idx.astype(np.int64), np.zeros(0, np.float32)
-    # fetch only the candidate values (one contiguous read of the trace is cheaper than n tiny copies)
-    vals = d_trace.get()[idx]
+        return np.zeros(0, np.int64), np.zeros(0, np.float32)
+    # only the candidates leave the device: their values are gathered there (a 2^24-sample trace is 67 MB)
+    vals = gather(d_trace, idx, n)
+    idx = idx.get()[:n]
     order = np.lexsort((idx, -vals))[:k]
     return idx[order].astype(np.int64), vals[order]
 
@@ -52,7 +69,8 @@ def czt_zoom(cutout, d_rx, delays, coarse_freqs, fs, span, step):
     fine_q = np.zeros(len(delays), np.float32)
     planes = []
     for i, (d, f0) in enumerate(zip(delays, coarse_freqs)):
-        row = multiplySlidesNormalised(d_cc, d_rx, int(d), 1)  # (1, n): rx[d:d+n] * conj(cutout) / norms
+        # (1, n): rx[d:d+n] * conj(cutout) / norms -- on the n-sample view, so that the energy pass covers n samples
+        row = multiplySlidesNormalised(d_cc, d_rx[int(d) : int(d) + n], 0, 1)
         cz = CZTCachedGPU(n, f0 - span, f0 + span, step, fs)
         z = cz.runMany(row)  # (1, k) complex64 on the device
         am, mx = cupyArgmaxAbsRows_complex64(z, returnMaxValues=True, useNormSqInstead=True)
@@ -74,8 +92,8 @@ def caf_with_zoom(cutout, d_rx, plan_result, bins, grid, fs, k=8, min_height=Non
     delays, vals = topk_local_maxima(trace, k, min_height)
     if delays.size == 0:
         return []
-    a = args.get()
-    cbins = np.asarray(bins)[a[delays]]
+    a = gather(args, asarray(delays.astype(np.int32)))
+    cbins = np.asarray(bins)[a]
     bin_hz = fs / float(grid)
     ff, fq, _ = czt_zoom(cutout, d_rx, delays, cbins * bin_hz, fs, span_bins * bin_hz, step_bins * bin_hz)
     return [

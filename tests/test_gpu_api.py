@@ -646,6 +646,25 @@ def test_copy_and_peak_kernels():
     small[5], small[8], small[49] = 1.0, 0.5, 2.0
     idx, cnt = cupyFindLocalMaxima(asarray(small), 0.6)
     assert int(cnt.get()[0]) == 2 and list(idx.get()[:2]) == [5, 49]
+    # sizes around the 4096-sample tiles and the 1024-tile scan chunk of the compaction; truncation at maxNumPeaks;
+    # device-side gather of the candidate values
+    from pydsproutines_amd.zoom import gather
+
+    for n in (1, 4095, 4096, 4097, 3 * 4096 + 1, 4096 * 1024 + 77):
+        v = np.abs(rng.standard_normal(n)).astype(np.float32)
+        h = 2.5 if n > 100000 else 0.3
+        ref = K.findLocalMaxima(v, h)
+        dv = asarray(v)
+        idx, cnt = cupyFindLocalMaxima(dv, h, maxNumPeaks=max(ref.size, 1))
+        assert int(cnt.get()[0]) == ref.size
+        np.testing.assert_array_equal(idx.get()[: ref.size], ref)
+        np.testing.assert_array_equal(gather(dv, idx, ref.size), v[ref])
+        if ref.size > 3:
+            idx2, cnt2 = cupyFindLocalMaxima(dv, h, maxNumPeaks=3)
+            assert int(cnt2.get()[0]) == ref.size  # the total found, as upstream's counter
+            np.testing.assert_array_equal(idx2.get(), ref[:3])
+    with pytest.raises(TypeError):
+        gather(asarray(np.zeros(4, np.float64)), asarray(np.zeros(1, np.int32)))
 
 
 def test_czt_objects(golden):
