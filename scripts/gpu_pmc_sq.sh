@@ -1,6 +1,8 @@
 #!/bin/bash
-# SQ counters of the fused engine's kernels (one rocprofv3 --pmc pass per counter group)
+# SQ counters of the engine's kernels (one rocprofv3 --pmc pass per counter group)
+# usage: bash scripts/gpu_pmc_sq.sh [engine]   (auto = persistent)
 set -e
+ENGINE=${1:-auto}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/pmc_sq
 mkdir -p $OUT
@@ -8,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/g$i -- python3 $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --engine fused > $OUT/b$i.json 2> $OUT/e$i.err || { tail -5 $OUT/e$i.err; exit 1; }
+  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/g$i -- python3 $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-side-figure --engine $ENGINE > $OUT/b$i.json 2> $OUT/e$i.err || { tail -5 $OUT/e$i.err; exit 1; }
 done
 cd $REPO
 python3 - <<'PY'
