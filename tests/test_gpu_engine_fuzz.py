@@ -14,7 +14,9 @@ from conftest import cn, qpsk
 
 pytestmark = pytest.mark.gpu
 
-CASES = list(range(28))
+import os
+
+CASES = list(range(int(os.environ.get("CAF_FUZZ_CASES", "28"))))  # CAF_FUZZ_CASES=400 for a soak run
 
 
 def _case(seed):
@@ -65,9 +67,23 @@ def test_random_shapes_all_engines(seed):
         # the same call without a surface (the persistent engine then keeps running maxima instead of tiles
         # where the hypothesis groups allow it): identical per-delay results and peaks
         r2 = plan.run(d_rx, shift_start=c["lo"], num_shifts=c["cnt"], surface=False, rows=True, peak=True)
-        for a, b in zip(out[engine][1:], (r2.row_max.get(), r2.row_arg.get(), r2.peak_val.get(), r2.peak_delay.get(),
-                                          r2.peak_freq.get())):
-            np.testing.assert_array_equal(a, b)
+        surf = out[engine][0]
+        for name, a, b in zip(("row_max", "row_arg", "peak_val", "peak_delay", "peak_freq"), out[engine][1:],
+                              (r2.row_max.get(), r2.row_arg.get(), r2.peak_val.get(), r2.peak_delay.get(),
+                               r2.peak_freq.get())):
+            if name == "row_arg":
+                # The running maxima compare |y|^2 before the common normalisation factor is applied, the surface
+                # path after it: two hypotheses whose normalised float32 values round to the same number are a tie
+                # there (first index wins) but not here (the larger raw value wins).  Any index the no-surface run
+                # reports must therefore hold the row maximum, and differ from the surface run only on such ties.
+                ti, si = np.nonzero(a != b)
+                assert ti.size <= max(2, a.size // 20000), "%d differing per-delay arguments" % ti.size
+                np.testing.assert_array_equal(surf[ti, si, b[ti, si]], out[engine][1][ti, si])
+                assert np.all(b[ti, si] > a[ti, si])
+            elif name == "peak_freq":
+                np.testing.assert_array_equal(surf[np.arange(a.size), out[engine][4] - c["lo"], b], out[engine][3])
+            else:
+                np.testing.assert_array_equal(a, b)
         r3 = plan.run(d_rx, shift_start=c["lo"], num_shifts=c["cnt"], surface=False, rows=False, peak=True)
         np.testing.assert_array_equal(r3.peak_delay.get(), out[engine][4])
         np.testing.assert_array_equal(r3.peak_val.get(), out[engine][3])
