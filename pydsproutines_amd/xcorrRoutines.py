@@ -152,18 +152,22 @@ def fastXcorr(cutout, rx, freqsearch=False, outputCAF=False, shifts=None, absRes
 
 
 def cztXcorr(cutout, rx, f_searchMin, f_searchMax, fs, cztStep=0.1, outputCAF=False, shifts=None):
-    """ref: xcorrRoutines.py:413-457.  The frequency grid is the reference's CZT grid
-    f1 + i*cztStep, i < int((f2-f1)/cztStep + 1); evaluated as explicit hypotheses."""
+    """ref: xcorrRoutines.py:413-457.  The frequency grid is the reference's CZT grid, evaluated as explicit
+    hypotheses: k = int((f2-f1)/cztStep + 1) bins, reported as f1 + i*cztStep (CZTCached.getFreq), computed
+    with CZTCached's chirp rate W = (f2 - f1 + cztStep) / (k * fs) (spectralRoutines.py:239-311), i.e. at
+    f1 + i*(f2 - f1 + cztStep)/k -- the same numbers whenever (f2-f1)/cztStep is an integer, and the reference's
+    actual values (not its labels) when it is not."""
     cutout = np.asarray(cutout)
     rx = np.asarray(rx)
     n = cutout.size
     k = int((f_searchMax - f_searchMin) / cztStep + 1)
     f_search = np.arange(k) * cztStep + f_searchMin
+    f_eval = f_searchMin + np.arange(k) * ((f_searchMax - f_searchMin + cztStep) / k)
     if shifts is None:
         shifts = np.arange(len(rx) - n + 1)
     shifts = np.asarray(shifts)
     lo, cnt, rel = _engine_range(shifts)
-    plan = CAFPlan(_c64(cutout), max_rx_len=len(rx), freqs_norm=f_search / fs,
+    plan = CAFPlan(_c64(cutout), max_rx_len=len(rx), freqs_norm=f_eval / fs,
                    engine="auto" if outputCAF else "rocfft")
     d_rx = asarray(_c64(rx))
     if outputCAF:

@@ -1,0 +1,142 @@
+"""Seeded random shapes through the reference-signature host layer against the oracle (the NumPy restatement
+pinned to the imported reference): template lengths that are not powers of two, ragged / non-contiguous shift
+lists, composite templates with gaps, arbitrary frequency lists and CZT grids, out-of-range delays of the
+native twin.  Every call builds its own plan, so this also exercises plan creation and the caches behind it
+with many different sizes.  CAF_FUZZ_CASES=N widens the seed range."""
+
+import os
+
+import numpy as np
+import pytest
+
+import oracle as O
+from conftest import cn
+
+pytestmark = pytest.mark.gpu
+CASES = list(range(int(os.environ.get("CAF_FUZZ_CASES", "12"))))
+TOL = 3e-5
+
+
+def _shifts(rng, total):
+    kind = int(rng.integers(0, 4))
+    if kind == 0:
+        return None
+    if kind == 1:
+        a = int(rng.integers(0, total))
+        return np.arange(a, int(rng.integers(a + 1, total + 1)))
+    if kind == 2:
+        return np.arange(int(rng.integers(0, total)), total, int(rng.integers(2, 9)))
+    return np.sort(rng.choice(total, size=int(rng.integers(1, min(total, 60) + 1)), replace=False))
+
+
+@pytest.mark.parametrize("seed", CASES)
+def test_fastxcorr_random(seed):
+    from pydsproutines_amd.xcorrRoutines import fastXcorr
+
+    rng = np.random.default_rng(9000 + seed)
+    n = int(rng.choice([1, 2, 3, 17, 30, 64, 100, 257, 512, 1000]))
+    m = n + int(rng.integers(0, 3000))
+    rx = cn(rng, m)
+    d = int(rng.integers(0, m - n + 1))
+    cut = (rx[d : d + n] * np.exp(2j * np.pi * int(rng.integers(0, n)) * np.arange(n) / n)).astype(np.complex64)
+    sh = _shifts(rng, m - n + 1)
+    # window energies are differences of a float64 running sum: a 1-3 sample window that happens to hold
+    # near-zero samples loses relative accuracy (|x|^2 = 1e-5 against a running sum of 3000: ~3e-5)
+    tol = TOL if n > 3 else 3e-4
+    a = fastXcorr(cut, rx, shifts=sh)
+    np.testing.assert_allclose(a, O.fastXcorr(cut, rx, shifts=sh), atol=tol)
+    ac = fastXcorr(cut, rx, shifts=sh, absResult=False)
+    np.testing.assert_allclose(ac, O.fastXcorr(cut, rx, shifts=sh, absResult=False), atol=tol)
+    b, bi = fastXcorr(cut, rx, freqsearch=True, shifts=sh)
+    ob, obi = O.fastXcorr(cut, rx, freqsearch=True, shifts=sh)
+    np.testing.assert_allclose(b, ob, atol=tol)
+    c = fastXcorr(cut, rx, True, True, sh)
+    oc = O.fastXcorr(cut, rx, True, True, sh)
+    np.testing.assert_allclose(c, oc, atol=tol)
+    if n > 1:
+        top2 = np.sort(oc, axis=1)[:, -2:]
+        clear = top2[:, 1] - top2[:, 0] > 1e-4
+        np.testing.assert_array_equal(bi[clear], obi[clear])
+
+
+@pytest.mark.parametrize("seed", CASES)
+def test_groupxcorr_and_czt_random(seed):
+    from pydsproutines_amd.xcorrRoutines import GroupXcorr, GroupXcorrCZT, cztXcorr
+
+    rng = np.random.default_rng(9500 + seed)
+    G = int(rng.integers(1, 4))
+    lengths = rng.integers(20, 200, G).astype(np.int32)
+    gaps = rng.integers(0, 150, G).astype(np.int32)
+    starts = (np.cumsum(np.concatenate(([0], lengths[:-1] + gaps[:-1]))) + int(rng.integers(0, 50))).astype(np.int32)
+    span = int(starts[-1] - starts[0] + lengths[-1])
+    m = int(starts[-1] + lengths[-1]) + int(rng.integers(100, 4000))
+    fs = float(rng.choice([100.0, 1000.0, 12345.0]))
+    rx = cn(rng, m)
+    # y is the full-length array the groups are cut from (y[starts[g] : starts[g] + lengths[g]], :895-905);
+    # taken from rx at off0, so the template sits at shift off = off0 + starts[0] with QF^2 = 1 at 0 Hz
+    off0 = int(rng.integers(0, m - int(starts[-1] + lengths[-1])))
+    y = rx[off0 : off0 + int(starts[-1] + lengths[-1])].copy()
+    off = off0 + int(starts[0])
+    F = int(rng.integers(1, 40))
+    freqs = np.sort(rng.uniform(-0.03 * fs, 0.03 * fs, F))
+    freqs[int(rng.integers(0, F))] = 0.0
+    total = m - span  # the reference asserts shifts[-1] + span < len(rx) (:922)
+    sh = _shifts(rng, total)
+    if sh is None:
+        sh = np.arange(total)
+    g = GroupXcorr(y, starts, lengths, freqs, fs)
+    og = O.GroupXcorr(y, starts, lengths, freqs, fs)
+    xc, fpk = g.xcorr(rx, sh)
+    oxc, ofpk = og.xcorr(rx, sh)
+    np.testing.assert_allclose(xc, oxc, atol=TOL)
+    if off in sh:
+        i = int(np.nonzero(sh == off)[0][0])
+        assert abs(xc[i] - 1.0) < 1e-4 and fpk[i] == 0.0
+    # CZT grid flavours: one composite template, uniform grid
+    # A grid with a whole number of steps: the reference sizes its output with int((f2 - f1) / binWidth + 1), its
+    # frequency vector with np.arange(f1, f2 + binWidth / 2, binWidth) and its chirp with (f2 - f1 + binWidth) / k
+    # (:1005-1007, spectralRoutines.py:239-311); they only describe one grid when (f2 - f1) / binWidth is whole
+    # (otherwise the reference raises a broadcast error or mixes two grids), hence the 1e-6 of a step of margin.
+    K = int(rng.integers(2, 30))
+    step = float(rng.uniform(0.0005, 0.004)) * fs
+    f1 = -(K // 2) * step
+    f2 = f1 + (K + 1e-6) * step
+    gz = GroupXcorrCZT(y, starts, lengths, f1, f2, step, fs)
+    ogz = O.GroupXcorrCZT(y, starts, lengths, f1, f2, step, fs)
+    cz, fz = gz.xcorr(rx, sh[:50])
+    ocz, ofz = ogz.xcorr(rx, sh[:50])
+    assert fz.size == K + 1
+    np.testing.assert_allclose(fz, ofz, atol=1e-9 * fs)
+    np.testing.assert_allclose(cz, ocz, atol=TOL)
+    n = int(lengths[0])
+    cut = y[:n].copy()
+    s0 = sh[:40][sh[:40] + n <= m]
+    if s0.size:
+        # cztXcorr also off the whole-step grids: its values follow CZTCached's chirp rate, as the reference's do
+        f2c = f1 + float(rng.uniform(2.0, K + 0.99)) * step
+        caf, f = cztXcorr(cut, rx, f1, f2c, fs, step, True, s0)
+        ocaf, of = O.cztXcorr(cut, rx, f1, f2c, fs, step, True, s0)
+        np.testing.assert_allclose(f, of, atol=1e-9 * fs)
+        np.testing.assert_allclose(caf, ocaf, atol=TOL)
+
+
+@pytest.mark.parametrize("seed", CASES)
+def test_native_twin_random(seed):
+    from pydsproutines_amd.xcorrRoutines import CyIppXcorrFFT
+
+    rng = np.random.default_rng(9900 + seed)
+    n = int(rng.choice([4, 30, 64, 100, 333]))
+    m = n + int(rng.integers(1, 2000))
+    rx = cn(rng, m)
+    cut = rx[m // 3 : m // 3 + n].copy() if m // 3 + n <= m else rx[:n].copy()
+    start = int(rng.integers(-50, m // 2))
+    end = int(rng.integers(start + 1, m + 60))
+    step = int(rng.integers(1, 7))
+    pk, fi = CyIppXcorrFFT(cut, int(rng.integers(1, 5))).xcorr(rx, start, end, step)
+    opk, ofi = O.IppXcorrFFT(cut, 1).xcorr(rx, start, end, step)
+    assert pk.dtype == np.float32 and fi.dtype == np.int32 and pk.shape == opk.shape
+    np.testing.assert_allclose(pk, opk, atol=TOL)
+    strong = opk > 0.5
+    np.testing.assert_array_equal(fi[strong], ofi[strong])
+    oor = (np.arange(start, end, step) < 0) | (np.arange(start, end, step) + n > m)
+    assert np.all(pk[oor] == 0) and np.all(fi[oor] == 0)
