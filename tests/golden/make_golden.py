@@ -254,6 +254,29 @@ def gen_c1():
          peak=np.array([q.max()]))
 
 
+def gen_czt_offgrid():
+    """cztXcorr on a grid whose span is not a whole number of steps ((f2 - f1) / step = 10.53): CZTCached then
+    evaluates at f1 + i (f2 - f1 + step) / k while labelling the bins f1 + i step (spectralRoutines.py:239-311)."""
+    rng = np.random.default_rng(909)
+    n, m, fs = 64, 600, 100.0
+    rx = cn(rng, m)
+    cut = rx[100 : 100 + n].copy()
+    rx[100 : 100 + n] *= np.exp(2j * np.pi * 1.9 * np.arange(n) / fs).astype(np.complex64)
+    sh = np.arange(80, 125)
+    f1, f2, step = -3.0, 4.37, 0.7
+    caf, f = quiet(R.cztXcorr, cut, rx, f1, f2, fs, cztStep=step, outputCAF=True, shifts=sh)
+    res, fpk = quiet(R.cztXcorr, cut, rx, f1, f2, fs, cztStep=step, outputCAF=False, shifts=sh)
+    print("cztXcorr, off-grid span")
+    ocaf, of = O.cztXcorr(cut, rx, f1, f2, fs, cztStep=step, outputCAF=True, shifts=sh)
+    ores, ofpk = O.cztXcorr(cut, rx, f1, f2, fs, cztStep=step, outputCAF=False, shifts=sh)
+    report("CAF", caf, ocaf)
+    report("freqs", f, of)
+    report("flattened value", res, ores)
+    report("flattened freq", fpk, ofpk)
+    save("cztxcorr_offgrid", cutout=cut, rx=rx, shifts=sh, grid=np.array([f1, f2, step, fs]), caf=caf, freqs=f, res=res,
+         fpk=fpk)
+
+
 def gen_kat4():
     """TemplateCrossCorrelator unit test inputs (xcorrRoutines.py:2130-2241): the class itself
     needs cupy upstream; its own test pins it to sqrt(fastXcorr) and |fastXcorr(absResult=False)|."""
@@ -377,6 +400,7 @@ if __name__ == "__main__":
     gen_kat2()
     gen_kat1_kat3()
     gen_czt()
+    gen_czt_offgrid()
     gen_group()
     gen_c2_mini()
     gen_c1()

@@ -129,6 +129,17 @@ def test_cztxcorr(golden):
     clear = top2[:, 1] - top2[:, 0] > 1e-4
     np.testing.assert_array_equal(fpk[clear], g["fpk"][clear])
     np.testing.assert_allclose(res[clear], g["res"][clear], atol=TOL)
+    # a span that is not a whole number of steps: the reference's values (stretched grid), its labels
+    g = golden("cztxcorr_offgrid")
+    f1, f2, step, fs = (float(v) for v in g["grid"])
+    caf, f = cztXcorr(g["cutout"], g["rx"], f1, f2, fs, step, True, g["shifts"])
+    np.testing.assert_allclose(caf, g["caf"], atol=TOL)
+    np.testing.assert_array_equal(f, g["freqs"])
+    res, fpk = cztXcorr(g["cutout"], g["rx"], f1, f2, fs, step, False, g["shifts"])
+    top2 = np.sort(g["caf"], axis=1)[:, -2:]
+    clear = top2[:, 1] - top2[:, 0] > 1e-4
+    np.testing.assert_array_equal(fpk[clear], g["fpk"][clear])
+    np.testing.assert_allclose(res[clear], g["res"][clear], atol=TOL)
 
 
 def test_groupxcorr_family(golden):

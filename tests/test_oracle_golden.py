@@ -81,6 +81,19 @@ def test_kat3_cztcached(golden):
         np.testing.assert_allclose(getattr(cz, name), g["kat3_" + name], atol=1e-6)
 
 
+def test_cztxcorr_offgrid_span(golden):
+    """(f2 - f1) / step = 10.53: CZTCached's chirp rate stretches the evaluated grid, the labels stay f1 + i step."""
+    g = golden("cztxcorr_offgrid")
+    f1, f2, step, fs = (float(v) for v in g["grid"])
+    caf, f = O.cztXcorr(g["cutout"], g["rx"], f1, f2, fs, step, True, g["shifts"])
+    assert caf.shape == (45, 11)
+    np.testing.assert_allclose(caf, g["caf"], atol=TOL)
+    np.testing.assert_array_equal(f, g["freqs"])
+    res, fpk = O.cztXcorr(g["cutout"], g["rx"], f1, f2, fs, step, False, g["shifts"])
+    np.testing.assert_allclose(res, g["res"], atol=TOL)
+    np.testing.assert_array_equal(fpk, g["fpk"])
+
+
 def test_cztxcorr_and_czt(golden):
     g = golden("cztxcorr_small")
     fs = float(g["fs"][0])
