@@ -140,3 +140,115 @@ def test_native_twin_random(seed):
     np.testing.assert_array_equal(fi[strong], ofi[strong])
     oor = (np.arange(start, end, step) < 0) | (np.arange(start, end, step) + n > m)
     assert np.all(pk[oor] == 0) and np.all(fi[oor] == 0)
+
+
+@pytest.mark.parametrize("seed", CASES)
+def test_czt_classes_random(seed):
+    """CZTCached (py rule), CZTCachedGPU (gpu rule), pbIppCZT32fc (cpp rule) on random lengths and grids, whole and
+    fractional numbers of steps, against the oracle's three rules (spectralRoutines.py:239-391, CZT.cpp:41-209)."""
+    from pydsproutines_amd import asarray
+    from pydsproutines_amd.spectralRoutines import CZTCached, CZTCachedGPU, pbIppCZT32fc
+
+    rng = np.random.default_rng(9700 + seed)
+    m = int(rng.choice([1, 2, 10, 30, 97, 256, 1000, 4097]))
+    fs = float(rng.choice([10.0, 1000.0, 48000.0]))
+    step = float(rng.uniform(0.0002, 0.01)) * fs
+    f1 = float(rng.uniform(-0.2, 0.1)) * fs
+    nsteps = float(rng.integers(1, 60)) + (float(rng.uniform(0.05, 0.95)) if rng.integers(0, 2) else 1e-6)
+    f2 = f1 + nsteps * step
+    rows = int(rng.integers(1, 5))
+    x = cn(rng, rows * m).reshape(rows, m)
+    scale = np.sqrt(m)
+    for cls, rule in ((CZTCached, "py"), (CZTCachedGPU, "gpu"), (pbIppCZT32fc, "cpp")):
+        obj = cls(m, f1, f2, step, fs) if cls is not CZTCached else cls(m, f1, f2, step, fs, convertTo32fc=True)
+        ref = O.CZTCached(m, f1, f2, step, fs, convertTo32fc=True, rule=rule)
+        assert (obj.k, obj.nfft) == (ref.k, ref.nfft)
+        xin = asarray(x) if cls is CZTCachedGPU else x
+        got = obj.runMany(xin)
+        got = got.get() if hasattr(got, "get") else got
+        want = ref.runMany(x)
+        assert got.shape == want.shape == (rows, ref.k)
+        np.testing.assert_allclose(got, want, atol=3e-5 * scale * max(1.0, np.sqrt(np.log2(ref.nfft))))
+        np.testing.assert_allclose(obj.getFreq(), ref.getFreq(), atol=1e-9 * fs)
+
+
+@pytest.mark.parametrize("seed", CASES)
+def test_groupxcorrfft_tcc_v2_random(seed):
+    from pydsproutines_amd import asarray
+    from pydsproutines_amd.xcorrRoutines import (CyGroupXcorrFFT, GroupXcorrFFT, TemplateCrossCorrelator,
+                                                 cp_fastXcorr_v2)
+
+    rng = np.random.default_rng(9800 + seed)
+    # GroupXcorrFFT: G equal-length groups at arbitrary offsets, FFT grid of fftlen bins
+    G = int(rng.integers(1, 4))
+    L = int(rng.choice([16, 50, 64, 100]))
+    st = np.sort(rng.choice(np.arange(0, 600, 5), G, replace=False)).astype(np.int64)
+    while np.any(np.diff(st) < L):
+        st = np.sort(rng.choice(np.arange(0, 600, 5), G, replace=False)).astype(np.int64)
+    fs = float(rng.choice([1.0, 100.0, 5000.0]))
+    fftlen = int(rng.choice([L, 128, 200, 256])) if L <= 128 else 256
+    fftlen = max(fftlen, L)
+    span = int(st[-1] - st[0] + max(L, fftlen))  # the reference asserts shifts[-1] + starts[-1] + fftlen < len(rx)
+    m = span + int(rng.integers(50, 2500))
+    rx = cn(rng, m)
+    off = int(rng.integers(0, m - span))
+    yg = np.stack([rx[off + (s - st[0]) : off + (s - st[0]) + L] for s in st])
+    sh = _shifts(rng, m - span)
+    if sh is None:
+        sh = np.arange(m - span)
+    sh = sh[:200]
+    gf = GroupXcorrFFT(yg, st, fs, fftlen=fftlen)
+    ogf = O.GroupXcorrFFT(yg, st, fs, fftlen=fftlen)
+    xc, fi = gf.xcorr(rx, sh)
+    oxc, ofi = ogf.xcorr(rx, sh)
+    np.testing.assert_allclose(xc, oxc, atol=TOL)
+    full = gf.xcorr(rx, sh, flattenToTime=False)
+    ofull = ogf.xcorr(rx, sh, flattenToTime=False)
+    np.testing.assert_allclose(full, ofull, atol=TOL)
+    top2 = np.sort(ofull, axis=1)[:, -2:]
+    clear = top2[:, 1] - top2[:, 0] > 1e-4
+    np.testing.assert_array_equal(fi[clear], ofi[clear])
+    if fftlen & (fftlen - 1) == 0 and fftlen >= L:
+        try:
+            nat = CyGroupXcorrFFT(yg, st.astype(np.int32), int(fs) if fs >= 1 else 1, fftlen)
+        except ValueError:
+            nat = None
+        if nat is not None and fs >= 1:
+            got = nat.xcorr(rx, sh.astype(np.int32), 2)
+            np.testing.assert_allclose(got, O.IppGroupXcorrFFT(yg, st, int(fs), fftlen).xcorr(rx, sh), atol=TOL)
+
+    # TemplateCrossCorrelator: T templates, both return modes, exact and fast maximum
+    T = int(rng.integers(1, 6))
+    Lt = int(rng.choice([8, 31, 100, 257]))
+    M = Lt + int(rng.integers(10, 3000))
+    x = cn(rng, M)
+    tm = np.stack([x[p : p + Lt] for p in rng.integers(0, M - Lt + 1, T)]) + 0.3 * cn(rng, T * Lt).reshape(T, Lt)
+    tm = tm.astype(np.complex64)
+    otc = O.TemplateCrossCorrelator(tm, M)
+    want = otc.correlate(x)
+    wv, wi = otc.correlate(x, returnMax=True)
+    for fast in (False, True):
+        tc = TemplateCrossCorrelator(asarray(tm), M, fastMax=fast)
+        np.testing.assert_allclose(tc.correlate(asarray(x)).get(), want, atol=TOL)
+        v, i = tc.correlate(asarray(x), returnMax=True)
+        np.testing.assert_allclose(v.get(), wv, atol=TOL)
+        a = np.sort(np.abs(want), axis=0)
+        clear = (a[-1] - a[-2] > 1e-4) if T > 1 else np.ones(want.shape[1], bool)
+        np.testing.assert_array_equal(i.get()[clear], wi[clear])
+
+    # cp_fastXcorr_v2: product kernel + row FFT + argmax / plane, random start and count
+    n = int(rng.choice([8, 30, 100, 128]))
+    m2 = n + int(rng.integers(5, 1500))
+    rx2 = cn(rng, m2)
+    cutc = rx2[m2 // 4 : m2 // 4 + n].conj().copy() if m2 // 4 + n <= m2 else rx2[:n].conj().copy()
+    start = int(rng.integers(0, m2 - n + 1))
+    cnt = int(rng.integers(1, m2 - n - start + 2))
+    fi2, q2 = cp_fastXcorr_v2(asarray(cutc), asarray(rx2), start, cnt, flattenCAF=True, BATCH=int(rng.integers(1, 400)))
+    ofi2, oq2 = O.cp_fastXcorr_v2(cutc, rx2, start, cnt, flattenCAF=True)
+    np.testing.assert_allclose(q2.get(), oq2, atol=TOL)
+    plane = cp_fastXcorr_v2(asarray(cutc), asarray(rx2), start, cnt, BATCH=int(rng.integers(1, 400)))
+    oplane = O.cp_fastXcorr_v2(cutc, rx2, start, cnt)
+    np.testing.assert_allclose(plane.get(), oplane, atol=TOL)
+    top2 = np.sort(oplane, axis=1)[:, -2:]
+    clear = top2[:, 1] - top2[:, 0] > 1e-4
+    np.testing.assert_array_equal(fi2.get()[clear], ofi2[clear])
