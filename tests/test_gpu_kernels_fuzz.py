@@ -107,3 +107,71 @@ def test_local_maxima_random_shapes(seed):
     ti, tv = topk_local_maxima(dv, k, h, maxNumPeaks=max(1, ref.size))
     np.testing.assert_array_equal(ti, K.topk_peaks(v, h, k))
     np.testing.assert_array_equal(tv, v[ti])
+
+
+@pytest.mark.parametrize("seed", CASES)
+def test_elementwise_and_resampling_random_shapes(seed):
+    """upfirdn (naive and shared-memory forms), complex moving sum, sliding normalised product, row argmax,
+    |.|^2, slice copies, tone dot products (upfirdn.cu, filter.cu:374-438, multiplySlices.cu:113-216,
+    argmax.cu:93-153, complex_magn.cu, copying.cu, genTones.cu:165-283)."""
+    from pydsproutines_amd import asarray
+    from pydsproutines_amd.cupyExtensions import (
+        cupyArgmaxAbsRows_complex64,
+        cupyComplexMagnSq,
+        cupyCopyEqualSlicesToMatrix_32fc,
+        cupyCopyIncrementalEqualSlicesToMatrix_32fc,
+        multiplySlidesNormalised,
+    )
+    from pydsproutines_amd.filterRoutines import CupyKernelFilter, cupyComplexMovingSum
+    from pydsproutines_amd.spectralRoutines import cupyDotTonesScaling
+
+    rng = np.random.default_rng(8500 + seed)
+    f = CupyKernelFilter()
+    # upfirdn
+    up, down = int(rng.integers(1, 12)), int(rng.integers(1, 9))
+    nt = int(rng.choice([1, 3, 32, 64, 129, 500]))
+    taps = (rng.standard_normal(nt) / np.sqrt(nt)).astype(np.float32)
+    rows, n = int(rng.integers(1, 5)), int(rng.integers(1, 3000))
+    xm = cn(rng, rows * n).reshape(rows, n)
+    ref = sps.upfirdn(taps.astype(np.float64), xm.astype(np.complex128), up, down, axis=1)
+    got = f.upfirdn_sm(asarray(xm), asarray(taps), up, down).get()
+    assert got.shape == ref.shape and ref.shape[1] == f.getUpfirdnSize(n, nt, up, down)
+    np.testing.assert_allclose(got, ref, atol=4e-5)
+    g1 = f.upfirdn_naive(asarray(xm[0].copy()), asarray(taps), up, down).get()
+    np.testing.assert_allclose(g1, ref[0], atol=4e-5)
+    # complex moving sum
+    n2 = int(rng.integers(2, 20000))
+    L = int(rng.integers(1, min(n2, 700) + 1))
+    z = cn(rng, n2)
+    got = cupyComplexMovingSum(asarray(z), L).get()
+    np.testing.assert_allclose(got, K.movingComplexSum(z, L), rtol=3e-4, atol=1e-4)
+    # sliding normalised product + row argmax + |.|^2
+    xl, yl = int(rng.integers(1, 300)), int(rng.integers(301, 5000))
+    x, y = cn(rng, xl), cn(rng, yl)
+    start = int(rng.integers(0, yl - xl))
+    cnt = int(rng.integers(1, min(400, yl - start) + 1))
+    coef = float(rng.uniform(0.5, 3.0)) if rng.integers(0, 2) else None
+    dz = multiplySlidesNormalised(asarray(x), asarray(y), start, cnt, coefficient=None if coef is None else np.array([coef]))
+    oz = K.slidingMultiplyNormalised(x, y, start, cnt, coef)
+    np.testing.assert_allclose(dz.get(), oz, atol=3e-6)
+    am, mx = cupyArgmaxAbsRows_complex64(dz, returnMaxValues=True)
+    oam, omx = K.argmaxAbsRows(dz.get())
+    np.testing.assert_array_equal(am.get(), oam)
+    np.testing.assert_allclose(mx.get(), omx, rtol=1e-6)
+    np.testing.assert_allclose(cupyComplexMagnSq(dz, np.float32).get(), K.complexMagnSq(dz.get(), np.float32), rtol=1e-6)
+    # slice copies
+    ln = int(rng.integers(1, 200))
+    stv = rng.integers(0, yl - ln, int(rng.integers(1, 30))).astype(np.int32)
+    np.testing.assert_array_equal(cupyCopyEqualSlicesToMatrix_32fc(asarray(y), asarray(stv), ln).get(),
+                                  K.copySlicesToMatrix(y, stv, ln))
+    inc, nr = int(rng.integers(1, 20)), int(rng.integers(1, 40))
+    s0 = int(rng.integers(0, max(1, yl - ln - inc * nr)))
+    if s0 + inc * (nr - 1) + ln <= yl:
+        np.testing.assert_array_equal(cupyCopyIncrementalEqualSlicesToMatrix_32fc(asarray(y), s0, inc, ln, nr).get(),
+                                      K.copyIncrementalEqualSlicesToMatrix(y, s0, inc, ln, nr))
+    # tone dot products
+    nf = int(rng.integers(1, 80))
+    src = cn(rng, int(rng.integers(1, 6000)))
+    f0, fstep = float(rng.uniform(-0.4, 0.4)), float(rng.uniform(1e-5, 1e-2))
+    got = cupyDotTonesScaling(f0, fstep, nf, asarray(src)).get()
+    np.testing.assert_allclose(got, K.dotTonesScaling(f0, fstep, nf, src), atol=3e-5 * np.sqrt(src.size) * 4)
