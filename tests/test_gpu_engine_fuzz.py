@@ -33,6 +33,19 @@ def _case(seed):
         lo = -(f // 2)
         bins = np.arange(lo, lo + f)
     tm = np.stack([qpsk(rng, n) for _ in range(t)])
+    # composite template (GroupXcorr semantics): 1-3 groups with gaps inside the span; zeros in the gaps and the
+    # energy normalisation over the support only
+    gs = gl = None
+    if n >= 100 and rng.integers(0, 3) == 0:
+        G = int(rng.integers(1, 4))
+        cuts = np.sort(rng.choice(np.arange(1, n), 2 * G - 1, replace=False))
+        edges = np.concatenate(([0], cuts, [n]))
+        gs = edges[0::2][:G].astype(np.int32)
+        gl = (edges[1::2][:G] - gs).astype(np.int32)
+        mask = np.zeros(n, bool)
+        for a, l in zip(gs, gl):
+            mask[a : a + l] = True
+        tm = (tm * mask).astype(np.complex64)
     rx = cn(rng, m)
     s_total = m - n + 1
     truth = []
@@ -47,8 +60,12 @@ def _case(seed):
     sub = bool(rng.integers(0, 2))
     lo_s = int(rng.integers(0, max(1, s_total // 3))) if sub else 0
     cnt = int(rng.integers(1, s_total - lo_s + 1)) if sub else s_total
+    if gs is not None:
+        kw.update(group_starts=gs, group_lens=gl)
+    conj_by_caller = bool(rng.integers(0, 4) == 0)  # autoConj=False: the caller hands over conj(template)
+    lb = int(rng.integers(max(9, int(np.ceil(np.log2(2 * n)))), 17))  # block size of the rocfft engine
     return dict(n=n, t=t, f=f, m=m, tm=tm, rx=rx, kw=kw, nb=nb, lo=lo_s, cnt=cnt, truth=truth, table=table,
-                nu=(freqs if table else bins / grid))
+                nu=(freqs if table else bins / grid), gs=gs, gl=gl, conj_by_caller=conj_by_caller, lb=lb)
 
 
 @pytest.mark.parametrize("seed", CASES)
@@ -59,7 +76,9 @@ def test_random_shapes_all_engines(seed):
     d_rx = asarray(c["rx"])
     out = {}
     for engine in ("persistent", "fused", "rocfft"):
-        plan = CAFPlan(c["tm"], max_rx_len=c["m"], engine=engine, blocks_per_batch=c["nb"], **c["kw"])
+        tmpl = c["tm"].conj() if c["conj_by_caller"] else c["tm"]
+        plan = CAFPlan(tmpl, max_rx_len=c["m"], engine=engine, blocks_per_batch=c["nb"],
+                       autoConj=not c["conj_by_caller"], log2_block=c["lb"] if engine == "rocfft" else 0, **c["kw"])
         assert plan.engine_used == engine
         r = plan.run(d_rx, shift_start=c["lo"], num_shifts=c["cnt"], surface=True)
         out[engine] = (r.surface.get(), r.row_max.get(), r.row_arg.get(), r.peak_val.get(), r.peak_delay.get(),
@@ -110,23 +129,29 @@ def test_random_shapes_all_engines(seed):
     rng = np.random.default_rng(seed)
     rows = np.unique(np.concatenate((rng.integers(0, c["cnt"], 24), [0, c["cnt"] - 1])))
     for i in range(c["t"]):
-        ref = _oracle_rows(c["tm"][i], c["rx"], c["nu"], c["lo"] + rows)
+        ref = _oracle_rows(c["tm"][i], c["rx"], c["nu"], c["lo"] + rows, c["gs"], c["gl"])
         tol = 1e-4 * max(float(ref.max()), float(scale))
         assert np.max(np.abs(sp[i][rows] - ref)) <= tol
 
 
-def _oracle_rows(tmpl, rx, nu, shifts):
+def _oracle_rows(tmpl, rx, nu, shifts, gs=None, gl=None):
     """QF^2 at the given delays and normalised frequencies: the reference's per-delay definition
-    (xcorrRoutines.py:511-566) with an explicit DFT row per frequency, float64."""
+    (xcorrRoutines.py:511-566) with an explicit DFT row per frequency, float64; with groups, the rx energy is
+    taken over the support of the composite template only (GroupXcorr, xcorrRoutines.py:917-954)."""
     n = tmpl.size
     k = np.arange(n)
+    sup = np.ones(n, bool)
+    if gs is not None:
+        sup[:] = False
+        for a, l in zip(gs, gl):
+            sup[a : a + l] = True
     e_t = float(np.sum(np.abs(tmpl.astype(np.complex128)) ** 2))
     steer = np.exp(-2j * np.pi * np.outer(np.asarray(nu, dtype=np.float64), k))
     out = np.empty((shifts.size, steer.shape[0]))
     for a, s in enumerate(shifts):
         seg = rx[s : s + n].astype(np.complex128)
         p = seg * np.conj(tmpl.astype(np.complex128))
-        out[a] = np.abs(steer @ p) ** 2 / (e_t * float(np.sum(np.abs(seg) ** 2)))
+        out[a] = np.abs(steer @ p) ** 2 / (e_t * float(np.sum(np.abs(seg[sup]) ** 2)))
     return out
 
 
