@@ -314,3 +314,43 @@ def test_engines_agree_with_oracle(engine, golden):
     r7 = plan6.run(asarray(rx6), shift_start=700, num_shifts=20001, surface=False, rows=True, peak=True)
     np.testing.assert_allclose(r7.row_max.get(), rm6[:, 700:20701], atol=2e-6)
     assert np.all(r7.peak_delay.get()[1:20] == d6[1:20])
+
+
+@pytest.mark.parametrize("n", [4095, 8191, 8192, 8193])
+def test_template_lengths_around_the_fused_limit(n):
+    """The LDS-resident engines take templates up to 8192 samples (16384-point blocks, >= 50 % valid delays);
+    longer ones go to the rocfft engine automatically and are refused by an explicit fused / persistent request."""
+    from pydsproutines_amd import CAFPlan, asarray
+    from test_gpu_engine_fuzz import _oracle_rows
+
+    rng = np.random.default_rng(n)
+    m = 40_000
+    t = qpsk(rng, n)
+    rx = cn(rng, m)
+    d0, bins = 12_345, np.arange(-4, 4)
+    grid = 1 << int(np.ceil(np.log2(n)))
+    rx[d0 : d0 + n] += (t * np.exp(2j * np.pi * 3 * np.arange(n) / grid)).astype(np.complex64)
+    d_rx = asarray(rx)
+    rows = np.array([0, 1, d0 - 1, d0, d0 + 1, m - n])
+    ref = _oracle_rows(t, rx, bins / grid, rows)
+    engines = ("persistent", "fused", "rocfft") if n <= 8192 else ("rocfft",)
+    surf = {}
+    for engine in engines:
+        plan = CAFPlan(t, max_rx_len=m, bins=bins, grid=grid, engine=engine)
+        res = plan.run(d_rx, surface=True)
+        surf[engine] = res.surface.get()[0]
+        np.testing.assert_allclose(surf[engine][rows], ref, atol=1e-4 * ref.max())
+        assert (int(res.peak_delay.get()[0]), int(bins[res.peak_freq.get()[0]])) == (d0, 3)
+        plan.close()
+    if n <= 8192:
+        np.testing.assert_array_equal(surf["persistent"], surf["fused"])
+        auto = CAFPlan(t, max_rx_len=m, bins=bins, grid=grid)
+        assert auto.engine_used == "persistent" and auto.block == 16384
+        auto.close()
+    else:
+        auto = CAFPlan(t, max_rx_len=m, bins=bins, grid=grid)
+        assert auto.engine_used == "rocfft"
+        auto.close()
+        for engine in ("persistent", "fused"):
+            with pytest.raises(ValueError):
+                CAFPlan(t, max_rx_len=m, bins=bins, grid=grid, engine=engine)
