@@ -121,10 +121,14 @@ def test_random_shapes_all_engines(seed):
         j = int(np.argmax(rmp[i]))
         assert pvp[i] == rmp[i][j] and pdp[i] == c["lo"] + j and pfp[i] == rap[i][j]
         d, fj = c["truth"][i]
-        if c["lo"] <= d < c["lo"] + c["cnt"]:
+        support = c["n"] if c["gl"] is None else int(np.sum(c["gl"]))
+        # (a composite template with a handful of samples scores QF^2 ~ 1 on noise alone: no planted-peak check)
+        if c["lo"] <= d < c["lo"] + c["cnt"] and support >= 32:
             # (explicit frequency lists may hold near-duplicates, which noise can lift above the planted one)
             assert int(pdp[i]) == d, "planted delay of template %d" % i
-            assert sp[i][d - c["lo"]][fj] >= 0.98 * pvp[i], "planted frequency of template %d" % i
+            # (a sanity check of the test's own planting, not of the engines: 1 of 3000 seeds has a neighbouring
+            # frequency of a short composite template 3 % above the planted one)
+            assert sp[i][d - c["lo"]][fj] >= 0.9 * pvp[i], "planted frequency of template %d" % i
     # sampled rows against the oracle
     rng = np.random.default_rng(seed)
     rows = np.unique(np.concatenate((rng.integers(0, c["cnt"], 24), [0, c["cnt"] - 1])))
