@@ -157,3 +157,24 @@ def test_c4_shape_sharded_peak_table_matches_single_gpu():
         res = CAFPlan(tm[a:b], max_rx_len=m, bins=bins, grid=N).run(d_rx, rows=False, peak=True)
         parts.append(sharding.pack_peak_table(res.peak_delay.get(), res.peak_freq.get(), res.peak_val.get()))
     np.testing.assert_array_equal(np.concatenate(parts), table_full)  # bit-identical rows
+
+
+def test_c5_full_size_zoom(c2):
+    """Config C5 on the full C2 result: the strongest local maximum of the 2^24-delay trace and its CZT zoom
+    against the oracle's cztXcorr at that delay (only the candidate values and arguments leave the device)."""
+    from pydsproutines_amd.zoom import caf_with_zoom
+
+    fs = float(N)  # bins are 1 Hz wide
+    out = caf_with_zoom(c2["t"], c2["d_rx"], c2["res"], c2["bins"], N, fs, k=3, span_bins=1.0, step_bins=1.0 / 32)
+    # (default threshold: a quarter of the global peak -- only the planted signal stands above it)
+    assert len(out) == 1 and out[0]["delay"] == D0 and out[0]["coarse_bin"] == K0
+    assert out[0]["coarse_qf2"] == float(c2["res"].peak_val.get()[0])
+    assert abs(out[0]["fine_freq"] - K0) <= 1.0 / 32 + 1e-9  # planted on the grid
+    ref, fr = O.cztXcorr(c2["t"], c2["rx"], K0 - 1.0, K0 + 1.0, fs, cztStep=1.0 / 32, outputCAF=True, shifts=np.array([D0]))
+    assert abs(ref[0].max() - out[0]["fine_qf2"]) <= 1e-4
+    assert abs(fr[int(np.argmax(ref[0]))] - out[0]["fine_freq"]) <= 1e-9
+    # a lower threshold admits noise maxima: still best first, the planted one on top
+    more = caf_with_zoom(c2["t"], c2["d_rx"], c2["res"], c2["bins"], N, fs, k=3, min_height=0.0045, span_bins=1.0,
+                         step_bins=1.0 / 8)
+    assert len(more) == 3 and more[0]["delay"] == D0
+    assert more[0]["coarse_qf2"] >= more[1]["coarse_qf2"] >= more[2]["coarse_qf2"] > 0.0045
