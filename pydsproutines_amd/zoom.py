@@ -58,27 +58,48 @@ def topk_local_maxima(d_trace, k, min_height, maxNumPeaks=100000):
     return idx[order].astype(np.int64), vals[order]
 
 
+_ZOOM_CZT = {}  # (n, span, step, fs) -> CZTCachedGPU on the relative grid -span ... +span
+
+
 def czt_zoom(cutout, d_rx, delays, coarse_freqs, fs, span, step):
     """For each (delay, coarse frequency) evaluate QF^2 on the fine grid coarse-span ... coarse+span (Hz) in
-    steps of ``step`` and return (fine_freq float64[k], qf2 float32[k], planes list of float32 arrays)."""
+    steps of ``step`` and return (fine_freq float64[k], qf2 float32[k], planes list of float32 arrays).
+
+    All peaks share ONE batched CZT: the product row of peak i is rotated by exp(-j 2 pi f0_i n / fs), which moves
+    its grid f0_i - span ... f0_i + span onto the common relative grid -span ... +span (cached chirp constants)."""
     requireDeviceArray(d_rx)
     cutout = np.ascontiguousarray(cutout, dtype=np.complex64)
     n = cutout.size
+    npk = len(delays)
+    if npk == 0:
+        return np.zeros(0, np.float64), np.zeros(0, np.float32), []
     d_cc = asarray(cutout.conj())
-    fine_f = np.zeros(len(delays), np.float64)
-    fine_q = np.zeros(len(delays), np.float32)
-    planes = []
-    for i, (d, f0) in enumerate(zip(delays, coarse_freqs)):
+    lib = _lib.load()
+    rows = empty((npk, n), np.complex64)
+    for i, d in enumerate(delays):
         # (1, n): rx[d:d+n] * conj(cutout) / norms -- on the n-sample view, so that the energy pass covers n samples
         row = multiplySlidesNormalised(d_cc, d_rx[int(d) : int(d) + n], 0, 1)
-        cz = CZTCachedGPU(n, f0 - span, f0 + span, step, fs)
-        z = cz.runMany(row)  # (1, k) complex64 on the device
-        am, mx = cupyArgmaxAbsRows_complex64(z, returnMaxValues=True, useNormSqInstead=True)
-        j = int(am.get()[0])
-        fine_f[i] = cz.getFreq()[j]
-        fine_q[i] = mx.get()[0]
-        planes.append(cupyComplexMagnSq(z, np.float32).get()[0])
-    return fine_f, fine_q, planes
+        _lib.check(lib.caf_d2d(ct.c_void_p(rows.ptr + 8 * n * i), ct.c_void_p(row.ptr), 8 * n, None), "caf_d2d")
+    f0 = np.asarray(coarse_freqs, dtype=np.float64)
+    cyc = np.outer(f0 / fs, np.arange(n, dtype=np.float64))
+    rot = np.exp(2j * np.pi * (cyc - np.floor(cyc))).astype(np.complex64)  # rows * conj(rot)
+    d_rot = asarray(rot)
+    _lib.check(lib.caf_mul_conj(ct.c_void_p(rows.ptr), ct.c_void_p(d_rot.ptr), npk * n, ct.c_void_p(rows.ptr), None),
+               "caf_mul_conj")
+    key = (n, float(span), float(step), float(fs))
+    cz = _ZOOM_CZT.get(key)
+    if cz is None:
+        if len(_ZOOM_CZT) > 16:
+            _ZOOM_CZT.clear()
+        cz = _ZOOM_CZT[key] = CZTCachedGPU(n, -span, span, step, fs)
+    z = cz.runMany(rows)  # (npk, k) complex64 on the device
+    am, mx = cupyArgmaxAbsRows_complex64(z, returnMaxValues=True, useNormSqInstead=True)
+    j = am.get().astype(np.int64)
+    # the labels of a per-peak CZT object: f1 + j * step with f1 = f0 - span (CZTCached.getFreq)
+    fine_f = j * step + (f0 - span)
+    fine_q = mx.get().astype(np.float32)
+    pl = cupyComplexMagnSq(z, np.float32).get()
+    return fine_f, fine_q, [pl[i] for i in range(npk)]
 
 
 def caf_with_zoom(cutout, d_rx, plan_result, bins, grid, fs, k=8, min_height=None, span_bins=1.0, step_bins=1.0 / 64):
