@@ -81,7 +81,7 @@ struct FftKey {
 std::mutex g_fft_mu;
 std::multimap<FftKey, FftPlan> g_fft_parked;
 constexpr size_t FFT_PARK_MAX_PLANS = 32;
-constexpr size_t FFT_PARK_MAX_WORK = (size_t)256 << 20;  // plans with larger work buffers are destroyed
+constexpr size_t FFT_PARK_MAX_WORK = (size_t)64 << 20;  // plans with larger work buffers are destroyed (<= 2 GiB parked)
 }  // namespace
 
 int fft_plan_acquire(FftPlan* out, bool inverse, size_t len, size_t batch, size_t dist, bool inplace) {
