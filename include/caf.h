@@ -264,7 +264,8 @@ CAF_EXPORT int32_t caf_iq16_fir_decimate(const int16_t* d_iq, int64_t num_sample
                                          int32_t ds_phase, float* d_out, int64_t out_len, void* stream);
 /* per column of a complex64 (rows, n) matrix: max_r |z| and the first row attaining it
  * (TemplateCrossCorrelator.correlate(returnMax=True), xcorrRoutines.py:361-371) */
-CAF_EXPORT int32_t caf_colmax_abs(const float* d_z, int32_t rows, int64_t n, float* d_max, int32_t* d_arg, void* stream);
+CAF_EXPORT int32_t caf_colmax_abs(const float* d_z, int32_t rows, int64_t n, float* d_max, void* d_arg,
+                                  int32_t arg_int64 /* d_arg is int64[n] (cp.argmax's dtype) instead of int32[n] */, void* stream);
 /* the same reduction on per-template QF^2 traces (float32 (rows, n), e.g. caf_outputs.d_row_max of an F = 1 plan):
  * d_max[i] = max_r sqrt(q2[r][i]), d_arg[i] = its first row as int64 (the dtype cp.argmax returns) */
 CAF_EXPORT int32_t caf_colmax_sqrt(const float* d_q2, int32_t rows, int64_t n, float* d_max, int64_t* d_arg, void* stream);

@@ -131,7 +131,7 @@ _SIGNATURES = {
     "caf_argmax3d_u32": [_P, _I64, _I32, _I32, _I32, _P, _P, _P],
     "caf_iq16_to_c64": [_P, _I64, ct.c_float, _P, _P],
     "caf_iq16_fir_decimate": [_P, _I64, ct.c_float, _P, _I32, _P, _I32, _I32, _I32, _P, _I64, _P],
-    "caf_colmax_abs": [_P, _I32, _I64, _P, _P, _P],
+    "caf_colmax_abs": [_P, _I32, _I64, _P, _P, _I32, _P],
     "caf_colmax_sqrt": [_P, _I32, _I64, _P, _P, _P],
     "caf_dot_tones": [_P, _I64, ct.c_double, ct.c_double, _I32, _P, _P],
     "caf_mul_conj": [_P, _P, _I64, _P, _P],

@@ -111,7 +111,7 @@ void launch_transpose_norm_argmax(const float* vt, int32_t ntmpl, int32_t nfreq,
                                   const float* inv_e, int64_t num_shifts, int64_t shift_start, int32_t step,
                                   int32_t blk0, int32_t nblk, int32_t tiles_per_blk, float* surface, float* row_max,
                                   int32_t* row_arg, PeakRec* partial, int64_t partial_per_tmpl, hipStream_t st);
-void launch_colmax_abs(const float2* z, int32_t rows, int64_t n, float* maxv, int32_t* arg, hipStream_t st);
+void launch_colmax_abs(const float2* z, int32_t rows, int64_t n, float* maxv, void* arg, int32_t arg64, hipStream_t st);
 void launch_colmax_sqrt(const float* q, int32_t rows, int64_t n, float* maxv, int64_t* arg, hipStream_t st);
 void launch_dot_tones(double f0, double fstep, int32_t num_freqs, int64_t len, const float2* src, float2* out,
                       hipStream_t st);

@@ -380,9 +380,10 @@ int32_t caf_iq16_to_c64(const int16_t* d_iq, int64_t num_samples, float scale, f
     return CAF_OK;
 }
 
-int32_t caf_colmax_abs(const float* d_z, int32_t rows, int64_t n, float* d_max, int32_t* d_arg, void* stream) {
+int32_t caf_colmax_abs(const float* d_z, int32_t rows, int64_t n, float* d_max, void* d_arg, int32_t arg_int64,
+                       void* stream) {
     CAF_REQUIRE(d_z && d_max && d_arg && rows >= 1 && n >= 1, "caf_colmax_abs: bad arguments");
-    launch_colmax_abs((const float2*)d_z, rows, n, d_max, d_arg, (hipStream_t)stream);
+    launch_colmax_abs((const float2*)d_z, rows, n, d_max, d_arg, arg_int64, (hipStream_t)stream);
     CAF_HIP_TRY(hipGetLastError());
     return CAF_OK;
 }

@@ -969,13 +969,14 @@ __global__ __launch_bounds__(256) void k_complex_norm(const float2* __restrict__
     cqf[(int64_t)h * num_shifts + rel] = make_float2(p.x * g, p.y * g);
 }
 
-// per column i of complex (rows, n): max_r |z[r][i]| and its first row index
+// per column i of complex (rows, n): max_r |z[r][i]| and its first row index (int32, or int64 = cp.argmax's dtype)
+template <typename TArg>
 __global__ __launch_bounds__(256) void k_colmax_abs(const float2* __restrict__ z, int32_t rows, int64_t n,
-                                                    float* __restrict__ maxv, int32_t* __restrict__ arg) {
+                                                    float* __restrict__ maxv, TArg* __restrict__ arg) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     float bv = -1.f;
-    int32_t bi = 0;
+    TArg bi = 0;
     for (int r = 0; r < rows; ++r) {
         const float2 a = z[(int64_t)r * n + i];
         // |z| via float64 so that the float32 result is the correctly rounded one (== numpy/hypotf)
@@ -1354,8 +1355,11 @@ void launch_scale(float2* y, int64_t n, float scale, hipStream_t st) {
     if (n > 0) hipLaunchKernelGGL(k_scale, dim3(std::min<unsigned>(cdiv(n, 256), 4096)), dim3(256), 0, st, y, n, scale);
 }
 
-void launch_colmax_abs(const float2* z, int32_t rows, int64_t n, float* maxv, int32_t* arg, hipStream_t st) {
-    hipLaunchKernelGGL(k_colmax_abs, dim3(cdiv(n, 256)), dim3(256), 0, st, z, rows, n, maxv, arg);
+void launch_colmax_abs(const float2* z, int32_t rows, int64_t n, float* maxv, void* arg, int32_t arg64, hipStream_t st) {
+    if (arg64)
+        hipLaunchKernelGGL(k_colmax_abs<int64_t>, dim3(cdiv(n, 256)), dim3(256), 0, st, z, rows, n, maxv, (int64_t*)arg);
+    else
+        hipLaunchKernelGGL(k_colmax_abs<int32_t>, dim3(cdiv(n, 256)), dim3(256), 0, st, z, rows, n, maxv, (int32_t*)arg);
 }
 
 void launch_colmax_sqrt(const float* q, int32_t rows, int64_t n, float* maxv, int64_t* arg, hipStream_t st) {
