@@ -1,0 +1,455 @@
+// Removal profiling of the FFT role (fused_item<1024> of pydsproutines_amd/csrc/caf_fused.hip) at the C2 shape:
+// the hypothesis loop is restated here with compile-time switches that each REMOVE one cost (results are wrong by
+// construction; only the time matters), so that the difference to the full loop prices that cost:
+//   1  no |y|^2 global stores (values folded into one register, stored once)
+//   2  no template-spectrum row loads per hypothesis (the first row is reused)
+//   4  workgroup barriers -> wave barriers
+//   8  no twiddle-table LDS reads in passes 2/3 (a register constant instead)
+//   16 no pass-1 twiddle recurrence (one constant)
+//   32 no LDS data traffic in passes 1-3 (registers kept; arithmetic unchanged)
+//   64 no pass-4 LDS reads
+//  128 no idft16 arithmetic (passes 1-3 butterflies skipped)
+// Build: hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -std=c++17 -I../../include -I../../pydsproutines_amd/csrc
+#include "caf_fused.hip"
+
+#include <cstdio>
+#include <vector>
+
+namespace caf {
+
+template <int FLAGS>
+__global__ __launch_bounds__(1024) void k_probe(const float2* __restrict__ xb, const float2* __restrict__ hc,
+                                                const int32_t* __restrict__ shifts, const float2* __restrict__ tw1,
+                                                const float2* __restrict__ tw23, int32_t nfreq, int32_t nhyp,
+                                                int32_t hyp_per_wg, int32_t nblk, int32_t tiles_per_blk,
+                                                float* __restrict__ vt) {
+    __shared__ __attribute__((aligned(16))) float2 s_d[F_LDS_DATA];
+    __shared__ float2 s_tw2[16 * 64];
+    __shared__ float2 s_tw3[16 * 4];
+    const int tid = threadIdx.x;
+    const int ngroups = (nhyp + hyp_per_wg - 1) / hyp_per_wg;
+    const int lin = blockIdx.x;
+    const int q = lin >> 3;
+    const int blk = (q / ngroups) * 8 + (lin & 7);
+    const int grp = q - (q / ngroups) * ngroups;
+    if (blk >= nblk) return;
+    const int h0 = grp * hyp_per_wg;
+    const int h1 = min(h0 + hyp_per_wg, nhyp);
+    s_tw2[tid] = tw23[tid];
+    if (tid < 64) s_tw3[tid] = tw23[1024 + tid];
+
+    auto bar = [&](int which = 0) {
+        if ((FLAGS & 4) || ((FLAGS & 256) && which == 3) || ((FLAGS & 512) && which == 1))
+            __builtin_amdgcn_wave_barrier();
+        else
+            __syncthreads();
+    };
+    const float2 w = ld2(tw1, (uint32_t)(1024 + tid));
+    const float2* xp = xb + (int64_t)blk * FB;
+    float* vt_blk = vt + (int64_t)blk * tiles_per_blk * nhyp * 64;
+    const float2* hrow_cur;
+    int sh_cur;
+    auto row_of = [&](int h) {
+        const int t = h / nfreq;
+        sh_cur = *((const CAF_AS1 int32_t*)shifts + (h - t * nfreq));
+        hrow_cur = hc + (int64_t)t * FB;
+    };
+    float2 pr[16], xr[16];
+#pragma unroll
+    for (int a = 0; a < 16; ++a) xr[a] = ld2(xp, (uint32_t)(1024 * a + tid));
+    row_of(h0);
+#pragma unroll
+    for (int a = 0; a < 16; ++a) pr[a] = cmul(xr[a], ld2(hrow_cur, (uint32_t)((1024 * a + tid - sh_cur) & (FB - 1))));
+    float acc = 0.f;
+    __syncthreads();
+
+    for (int h = h0; h < h1; ++h) {
+        const bool more = h + 1 < h1;
+        int64_t hoff = (int64_t)h * 64;
+        asm volatile("" : "+s"(hoff));
+        int lz = 0;
+        asm volatile("" : "+v"(lz));
+        float2 v1[16];
+#pragma unroll
+        for (int a = 0; a < 16; ++a) v1[a] = pr[a];
+        if (!(FLAGS & 128)) idft16(v1);
+        {
+            float2 p = w;
+            asm volatile("" : "+v"(p.x), "+v"(p.y));
+            const float2 wj = p;
+            v1[1] = cmul(v1[1], p);
+#pragma unroll
+            for (int n1 = 2; n1 < 16; ++n1) {
+                if (!(FLAGS & 16)) p = cmul(p, wj);
+                v1[n1] = cmul(v1[n1], p);
+            }
+        }
+        bar(1);
+        {
+            const int off = (tid >> 6) * F_ROW + (tid & 63);
+            if (!(FLAGS & 32)) {
+#pragma unroll
+                for (int n1 = 0; n1 < 16; ++n1) s_d[n1 * F_N1 + off] = v1[n1];
+            }
+        }
+        bar(2);
+        row_of(more ? h + 1 : h);
+        float2 v[16];
+        {
+            const int base = (tid >> 6) * F_N1 + (tid & 63);
+            if (!(FLAGS & 32)) {
+#pragma unroll
+                for (int b = 0; b < 16; ++b) v[b] = s_d[base + b * F_ROW];
+            } else {
+#pragma unroll
+                for (int b = 0; b < 16; ++b) v[b] = v1[b];
+            }
+            if (!(FLAGS & 128)) idft16(v);
+#pragma unroll
+            for (int n2 = 1; n2 < 16; ++n2) v[n2] = cmul(v[n2], (FLAGS & 8) ? w : s_tw2[n2 * 64 + (tid & 63) + lz]);
+            if (!(FLAGS & 32)) {
+#pragma unroll
+                for (int n2 = 0; n2 < 16; ++n2) s_d[base + n2 * F_ROW] = v[n2];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        float2 hn[16];
+        if (FLAGS & 4096) {
+            // doubled table (no wrap): one per-thread offset for all 16 loads, the 1024 a part in the scalar base
+            const uint32_t off = (uint32_t)(((tid - sh_cur) & (FB - 1)) + lz);
+#pragma unroll
+            for (int a = 0; a < 16; ++a) hn[a] = ld2(hrow_cur + 1024 * a, off);
+        } else if (!(FLAGS & 2)) {
+#pragma unroll
+            for (int a = 0; a < 16; ++a) hn[a] = ld2(hrow_cur, (uint32_t)(((1024 * a + tid - sh_cur) & (FB - 1)) + lz));
+        } else {
+#pragma unroll
+            for (int a = 0; a < 16; ++a) hn[a] = make_float2(w.x + a, w.y);
+        }
+        {
+            const int base = (tid >> 6) * F_N1 + ((tid >> 2) & 15) * F_ROW + (tid & 3);
+            if (!(FLAGS & 32)) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) v[c] = s_d[base + 4 * c];
+            }
+            if (!(FLAGS & 128)) idft16(v);
+#pragma unroll
+            for (int n3 = 1; n3 < 16; ++n3) v[n3] = cmul(v[n3], (FLAGS & 8) ? w : s_tw3[n3 * 4 + (tid & 3) + lz]);
+            if (!(FLAGS & 32)) {
+#pragma unroll
+                for (int n3 = 0; n3 < 16; ++n3) s_d[base + 4 * n3] = v[n3];
+            }
+        }
+        bar(3);
+        {
+            const int n1 = tid & 15, n2 = (tid >> 4) & 15, q4 = tid >> 8;
+            const int base = n1 * F_N1 + n2 * F_ROW;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int n3 = q4 + 4 * i;
+                int lzi = 0;
+                asm volatile("" : "+v"(lzi));
+                float4 lo, hi;
+                if (!(FLAGS & 64)) {
+                    lo = *reinterpret_cast<const float4*>(&s_d[base + 4 * n3 + lzi]);
+                    hi = *reinterpret_cast<const float4*>(&s_d[base + 4 * n3 + 2 + lzi]);
+                } else {
+                    lo = make_float4(v[4 * i].x, v[4 * i].y, v[4 * i + 1].x, v[4 * i + 1].y);
+                    hi = make_float4(v[4 * i + 2].x, v[4 * i + 2].y, v[4 * i + 3].x, v[4 * i + 3].y);
+                }
+                float2 a0 = make_float2(lo.x, lo.y), a1 = make_float2(lo.z, lo.w);
+                float2 a2 = make_float2(hi.x, hi.y), a3 = make_float2(hi.z, hi.w);
+                idft4(a0, a1, a2, a3);
+                const float2 y[4] = {a0, a1, a2, a3};
+#pragma unroll
+                for (int n4 = 0; n4 < ((FLAGS & 1024) ? 3 : 4); ++n4) {
+                    const int tile_u = 16 * i + 64 * n4;
+                    const int tile_t = (n2 >> 2) + 4 * q4;
+                    float* pu = vt_blk + (int64_t)tile_u * nhyp * 64 + hoff;
+                    const uint32_t voff = ((uint32_t)tile_t * (uint32_t)nhyp * 64u + (uint32_t)(n1 + 16 * (n2 & 3))) << 2;
+                    const float val = y[n4].x * y[n4].x + y[n4].y * y[n4].y;
+                    if (FLAGS & 1)
+                        acc += val;
+                    else if ((FLAGS & 1024) || tile_u + tile_t < tiles_per_blk)
+                        gst1(pu, voff, val);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int a = 0; a < 16; ++a) pr[a] = cmul(xr[a], hn[a]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (FLAGS & 1) vt_blk[tid] = acc;
+}
+
+
+// Variant 2: the next hypothesis' pass-1 butterfly (X*H product, DFT16, twiddle recurrence: VALU only) is placed
+// INSIDE the LDS-bound stretch, between passes 2 and 3 of the current hypothesis, instead of after pass 4.
+// ORDER 0: P2, P1c(next), P3.   ORDER 1: P1c(next) split: product+DFT16 after P2, recurrence twiddles after P3.
+template <int FLAGS, int ORDER>
+__global__ __launch_bounds__(1024) void k_probe2(const float2* __restrict__ xb, const float2* __restrict__ hc,
+                                                 const int32_t* __restrict__ shifts, const float2* __restrict__ tw1,
+                                                 const float2* __restrict__ tw23, int32_t nfreq, int32_t nhyp,
+                                                 int32_t hyp_per_wg, int32_t nblk, int32_t tiles_per_blk,
+                                                 float* __restrict__ vt) {
+    __shared__ __attribute__((aligned(16))) float2 s_d[F_LDS_DATA];
+    __shared__ float2 s_tw2[16 * 64];
+    __shared__ float2 s_tw3[16 * 4];
+    const int tid = threadIdx.x;
+    const int ngroups = (nhyp + hyp_per_wg - 1) / hyp_per_wg;
+    const int lin = blockIdx.x;
+    const int q = lin >> 3;
+    const int blk = (q / ngroups) * 8 + (lin & 7);
+    const int grp = q - (q / ngroups) * ngroups;
+    if (blk >= nblk) return;
+    const int h0 = grp * hyp_per_wg;
+    const int h1 = min(h0 + hyp_per_wg, nhyp);
+    s_tw2[tid] = tw23[tid];
+    if (tid < 64) s_tw3[tid] = tw23[1024 + tid];
+    auto bar = [&]() {
+        if (FLAGS & 4)
+            __builtin_amdgcn_wave_barrier();
+        else
+            __syncthreads();
+    };
+    const float2 w = ld2(tw1, (uint32_t)(1024 + tid));
+    const float2* xp = xb + (int64_t)blk * FB;
+    float* vt_blk = vt + (int64_t)blk * tiles_per_blk * nhyp * 64;
+    const float2* hrow_cur;
+    int sh_cur;
+    auto row_of = [&](int h) {
+        const int t = h / nfreq;
+        sh_cur = *((const CAF_AS1 int32_t*)shifts + (h - t * nfreq));
+        hrow_cur = hc + (int64_t)t * FB;
+    };
+    float2 xr[16], v1[16];
+#pragma unroll
+    for (int a = 0; a < 16; ++a) xr[a] = ld2(xp, (uint32_t)(1024 * a + tid));
+    auto p1_dft = [&]() {  // v1 holds the template-spectrum row: product, DFT16
+#pragma unroll
+        for (int a = 0; a < 16; ++a) v1[a] = cmul(xr[a], v1[a]);
+        idft16(v1);
+    };
+    auto p1_tw = [&]() {
+        float2 p = w;
+        asm volatile("" : "+v"(p.x), "+v"(p.y));
+        const float2 wj = p;
+        v1[1] = cmul(v1[1], p);
+#pragma unroll
+        for (int n1 = 2; n1 < 16; ++n1) {
+            p = cmul(p, wj);
+            v1[n1] = cmul(v1[n1], p);
+        }
+    };
+    row_of(h0);
+#pragma unroll
+    for (int a = 0; a < 16; ++a) v1[a] = ld2(hrow_cur, (uint32_t)((1024 * a + tid - sh_cur) & (FB - 1)));
+    p1_dft();
+    p1_tw();
+    float acc = 0.f;
+    __syncthreads();
+
+    for (int h = h0; h < h1; ++h) {
+        const bool more = h + 1 < h1;
+        int64_t hoff = (int64_t)h * 64;
+        asm volatile("" : "+s"(hoff));
+        int lz = 0;
+        asm volatile("" : "+v"(lz));
+        bar();  // everybody has finished the pass-4 reads of the previous hypothesis
+        {
+            const int off = (tid >> 6) * F_ROW + (tid & 63);
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) s_d[n1 * F_N1 + off] = v1[n1];
+        }
+        bar();
+        row_of(more ? h + 1 : h);
+        // next hypothesis' template-spectrum row straight into the (now free) v1 registers
+        if (!(FLAGS & 2)) {
+#pragma unroll
+            for (int a = 0; a < 16; ++a) v1[a] = ld2(hrow_cur, (uint32_t)(((1024 * a + tid - sh_cur) & (FB - 1)) + lz));
+        }
+        float2 v[16];
+        {
+            const int base = (tid >> 6) * F_N1 + (tid & 63);
+#pragma unroll
+            for (int b = 0; b < 16; ++b) v[b] = s_d[base + b * F_ROW];
+            idft16(v);
+#pragma unroll
+            for (int n2 = 1; n2 < 16; ++n2) v[n2] = cmul(v[n2], (FLAGS & 8) ? w : s_tw2[n2 * 64 + (tid & 63) + lz]);
+#pragma unroll
+            for (int n2 = 0; n2 < 16; ++n2) s_d[base + n2 * F_ROW] = v[n2];
+        }
+        __builtin_amdgcn_wave_barrier();
+        {
+            const int base = (tid >> 6) * F_N1 + ((tid >> 2) & 15) * F_ROW + (tid & 3);
+#pragma unroll
+            for (int c = 0; c < 16; ++c) v[c] = s_d[base + 4 * c];
+            // pass-1 butterfly of the next hypothesis: arithmetic only, flies under the LDS traffic around it
+            p1_dft();
+            if (ORDER == 0) p1_tw();
+            idft16(v);
+#pragma unroll
+            for (int n3 = 1; n3 < 16; ++n3) v[n3] = cmul(v[n3], (FLAGS & 8) ? w : s_tw3[n3 * 4 + (tid & 3) + lz]);
+#pragma unroll
+            for (int n3 = 0; n3 < 16; ++n3) s_d[base + 4 * n3] = v[n3];
+            if (ORDER == 1) p1_tw();
+        }
+        bar();
+        {
+            const int n1 = tid & 15, n2 = (tid >> 4) & 15, q4 = tid >> 8;
+            const int base = n1 * F_N1 + n2 * F_ROW;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int n3 = q4 + 4 * i;
+                int lzi = 0;
+                asm volatile("" : "+v"(lzi));
+                const float4 lo = *reinterpret_cast<const float4*>(&s_d[base + 4 * n3 + lzi]);
+                const float4 hi = *reinterpret_cast<const float4*>(&s_d[base + 4 * n3 + 2 + lzi]);
+                float2 a0 = make_float2(lo.x, lo.y), a1 = make_float2(lo.z, lo.w);
+                float2 a2 = make_float2(hi.x, hi.y), a3 = make_float2(hi.z, hi.w);
+                idft4(a0, a1, a2, a3);
+                const float2 y[4] = {a0, a1, a2, a3};
+#pragma unroll
+                for (int n4 = 0; n4 < 4; ++n4) {
+                    const int tile_u = 16 * i + 64 * n4;
+                    const int tile_t = (n2 >> 2) + 4 * q4;
+                    float* pu = vt_blk + (int64_t)tile_u * nhyp * 64 + hoff;
+                    const uint32_t voff = ((uint32_t)tile_t * (uint32_t)nhyp * 64u + (uint32_t)(n1 + 16 * (n2 & 3))) << 2;
+                    const float val = y[n4].x * y[n4].x + y[n4].y * y[n4].y;
+                    if (FLAGS & 1)
+                        acc += val;
+                    else if (tile_u + tile_t < tiles_per_blk)
+                        gst1(pu, voff, val);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    if (FLAGS & 1) vt_blk[tid] = acc;
+}
+
+}  // namespace caf
+
+template <int FLAGS>
+static void run(const char* what, float2* xb, float2* hc, int32_t* sh, float2* tw1, float2* tw23, float* vt, int nblk) {
+    const int nfreq = 256, nhyp = 256, hpw = 64, tiles = 193;
+    const int ngroups = nhyp / hpw;
+    const dim3 grid((unsigned)(ngroups * 8 * ((nblk + 7) / 8)));
+    auto launch = [&]() {
+        hipLaunchKernelGGL((caf::k_probe<FLAGS>), grid, dim3(1024), 0, 0, xb, hc, sh, tw1, tw23, nfreq, nhyp, hpw, nblk, tiles, vt);
+    };
+    launch();
+    (void)hipDeviceSynchronize();
+    float ms = 1e9f;
+    for (int r = 0; r < 3; ++r) {
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0);
+        (void)hipEventCreate(&e1);
+        (void)hipEventRecord(e0);
+        launch();
+        (void)hipEventRecord(e1);
+        (void)hipEventSynchronize(e1);
+        float m1;
+        (void)hipEventElapsedTime(&m1, e0, e1);
+        ms = m1 < ms ? m1 : ms;
+    }
+    const double transforms = (double)nblk * nhyp;
+    // every CU runs transforms/256 of them back to back
+    printf("flags %3d  %-58s %8.3f ms   %6.2f us per transform per CU\n", FLAGS, what, ms, ms * 1e3 / (transforms / 256.0));
+    fflush(stdout);
+}
+
+template <int FLAGS, int ORDER>
+static void run2(const char* what, float2* xb, float2* hc, int32_t* sh, float2* tw1, float2* tw23, float* vt, int nblk) {
+    const int nfreq = 256, nhyp = 256, hpw = 64, tiles = 193;
+    const int ngroups = nhyp / hpw;
+    const dim3 grid((unsigned)(ngroups * 8 * ((nblk + 7) / 8)));
+    auto launch = [&]() {
+        hipLaunchKernelGGL((caf::k_probe2<FLAGS, ORDER>), grid, dim3(1024), 0, 0, xb, hc, sh, tw1, tw23, nfreq, nhyp, hpw, nblk, tiles, vt);
+    };
+    launch();
+    (void)hipDeviceSynchronize();
+    float best = 1e9f;
+    for (int r = 0; r < 3; ++r) {
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0);
+        (void)hipEventCreate(&e1);
+        (void)hipEventRecord(e0);
+        launch();
+        (void)hipEventRecord(e1);
+        (void)hipEventSynchronize(e1);
+        float ms;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        best = ms < best ? ms : best;
+    }
+    const double transforms = (double)nblk * nhyp;
+    printf("v2 order %d flags %3d  %-46s %8.3f ms   %6.2f us per transform per CU (best of 3)\n", ORDER, FLAGS, what, best,
+           best * 1e3 / (transforms / 256.0));
+    fflush(stdout);
+}
+
+int main() {
+    const int nblk = 512;  // 2048 workgroups = 8 rounds over 256 CUs
+    const size_t FBs = 16384;
+    float2 *xb, *hc, *tw1, *tw23;
+    int32_t* sh;
+    float* vt;
+    (void)hipMalloc(&xb, nblk * FBs * 8);
+    (void)hipMalloc(&hc, 2 * FBs * 8);
+    (void)hipMalloc(&tw1, 16 * 1024 * 8);
+    (void)hipMalloc(&tw23, (1024 + 64) * 8);
+    (void)hipMalloc(&sh, 256 * 4);
+    const size_t vt_bytes = (size_t)nblk * 193 * 256 * 64 * 4;
+    (void)hipMalloc(&vt, vt_bytes);
+    std::vector<float2> h(nblk * FBs);
+    uint32_t s = 12345;
+    auto rnd = [&]() {
+        s = s * 1664525u + 1013904223u;
+        return ((s >> 8) & 0xffff) / 65536.0f - 0.5f;
+    };
+    for (auto& e : h) e = make_float2(rnd(), rnd());
+    (void)hipMemcpy(xb, h.data(), nblk * FBs * 8, hipMemcpyHostToDevice);
+    (void)hipMemcpy(hc, h.data(), 2 * FBs * 8, hipMemcpyHostToDevice);
+    std::vector<float2> t(16 * 1024);
+    for (int n1 = 0; n1 < 16; ++n1)
+        for (int m2 = 0; m2 < 1024; ++m2) {
+            const double a = 2.0 * M_PI * n1 * m2 / 16384.0;
+            t[n1 * 1024 + m2] = make_float2((float)cos(a), (float)sin(a));
+        }
+    (void)hipMemcpy(tw1, t.data(), 16 * 1024 * 8, hipMemcpyHostToDevice);
+    (void)hipMemcpy(tw23, t.data(), (1024 + 64) * 8, hipMemcpyHostToDevice);
+    std::vector<int32_t> shv(256);
+    for (int k = 0; k < 256; ++k) shv[k] = 4 * (k - 128);
+    (void)hipMemcpy(sh, shv.data(), 256 * 4, hipMemcpyHostToDevice);
+
+    // the chip's clock sags over the first seconds of load: warm up, then measure every variant right after a baseline
+    for (int r = 0; r < 12; ++r) run<0>("full loop (warm-up)", xb, hc, sh, tw1, tw23, vt, nblk);
+#define AB(F, WHAT)                                              \
+    run<0>("full loop", xb, hc, sh, tw1, tw23, vt, nblk);       \
+    run<F>(WHAT, xb, hc, sh, tw1, tw23, vt, nblk);
+    AB(4096, "row loads from a doubled table (one offset, scalar bases)")
+    AB(4096, "row loads from a doubled table (again)")
+    AB(1, "- global |y|^2 stores")
+    AB(2, "- template-spectrum row loads")
+    AB(3, "- stores - row loads")
+    AB(4, "- workgroup barriers (all three)")
+    AB(256, "- B3 only (before pass 4)")
+    AB(512, "- B1 only (before pass-1 writes)")
+    AB(1024, "12 unconditional stores, n4 = 3 dropped")
+    AB(1024 + 256, "12 stores, - B3")
+    AB(8, "- twiddle-table LDS reads")
+    AB(16, "- pass-1 twiddle recurrence")
+    AB(64, "- pass-4 LDS reads")
+    AB(128, "- idft16 arithmetic")
+    AB(7, "- stores - rows - barriers")
+    AB(111, "arithmetic only (no memory, LDS, barriers)")
+    AB(155, "LDS + barriers only (no butterflies, no global memory)")
+    run<0>("full loop", xb, hc, sh, tw1, tw23, vt, nblk);
+    run2<0, 0>("pipelined pass 1 (P2, P1c, P3)", xb, hc, sh, tw1, tw23, vt, nblk);
+    run<0>("full loop", xb, hc, sh, tw1, tw23, vt, nblk);
+    run2<7, 0>("pipelined, - stores - rows - barriers", xb, hc, sh, tw1, tw23, vt, nblk);
+    return 0;
+}

@@ -1,5 +1,8 @@
 // Microbenchmark: sustained wave64 VALU issue rate on gfx950 for v_add_f32 / v_fma_f32 / mixed add+mul,
 // at 1, 2, 4 waves per SIMD (256 CUs, one workgroup per CU).  Prints cycles per wave-instruction per SIMD.
+// CAUTION (round 2): built with plain -O3 the loop below is SLP-vectorised into v_pk_add_f32 / v_pk_fma_f32, so the
+// "2 cycles per op" it printed in round 1 was a 4-cycle PACKED instruction doing two ops.  Build it with
+// -fno-slp-vectorize, or use valu_issue.hip / pk_rate.hip (inline asm, one instruction form per row) instead.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 template <int OP>
