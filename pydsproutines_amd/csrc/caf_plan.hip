@@ -68,6 +68,7 @@ struct caf_plan_t {
     int T = 0, N = 0, F = 0, G = 0;
     int freq_mode = 0, mul_mode = 0;
     int B = 0, step = 0, pitch = 0, nb = 0, tiles_per_blk = 0, hyp_per_wg = 16, fwd_chunk = 1;
+    int nb_nosurf = 0;  // persistent engine, no-surface mode: blocks per launch (the pair arrays are ~1/32 of the tiles)
     int64_t max_rx = 0, max_blocks = 0, partial_per_tmpl = 0;
     int device = 0;
     float2* d_hc = nullptr;
@@ -415,6 +416,19 @@ static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
                 }
     }
 
+    // No-surface mode of the persistent engine: one (value, hypothesis) pair per delay and hypothesis GROUP lives in
+    // the tile buffer instead of one value per delay and hypothesis, so the same buffer holds hyp_per_wg / 2 times
+    // as many blocks per launch (config C4's 512 templates x 512 bins on one GPU: 32 blocks instead of 1; fewer,
+    // longer launches = fewer drain tails where the last blocks' reductions run on a handful of CUs).
+    p->nb_nosurf = nb;
+    if (p->persistent && F >= p->hyp_per_wg) {
+        const int64_t gpt = (F + p->hyp_per_wg - 1) / p->hyp_per_wg;
+        if (2 * gpt <= F) {
+            const int64_t cap = (int64_t)nb * F / (2 * gpt);  // nb_nosurf * 2 * T * gpt <= nb * T * F pairs
+            p->nb_nosurf = (int)std::max<int64_t>(nb, std::min<int64_t>(std::min<int64_t>(cap, 4096), std::max<int64_t>(1, total_blocks)));
+        }
+    }
+
     // device buffers
     int rc;
     if ((rc = p->alloc(&p->d_hc, nspec * B))) return rc;
@@ -441,7 +455,7 @@ static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
             if (const char* e = getenv("CAF_PERSIST_TR_SLOTS")) p->tr_slots = std::max(0, atoi(e));
             p->tr_slots = std::min(p->tr_slots, 31);  // slot 0 of every XCD never prefers tiles (termination argument)
             if ((rc = p->alloc(&p->d_params, 1))) return rc;
-            if ((rc = p->alloc(&p->d_pq, 4 + nb))) return rc;
+            if ((rc = p->alloc(&p->d_pq, 4 + std::max(nb, p->nb_nosurf)))) return rc;
         }
     } else {
         if ((rc = p->alloc(&p->d_pbuf, (int64_t)nb * T * F * p->pitch))) return rc;
@@ -638,8 +652,23 @@ int32_t caf_plan_execute(caf_plan p, const float* d_rx, int64_t rx_len, int64_t 
     if (p->s_aux) CAF_HIP_TRY(hipStreamWaitEvent(st, p->ev_join, 0));
     if (p->fused) {
         CAF_REQUIRE(!out->d_cqf, "the fused engine has no complex-QF output (create the plan with CAF_ENGINE_ROCFFT)");
-        for (int64_t b0 = 0; p->persistent && b0 < nblk; b0 += p->nb) {
-            const int32_t nbk = (int32_t)std::min<int64_t>(p->nb, nblk - b0);
+        // No surface wanted (per-delay traces / peaks only): the FFT items keep running per-delay maxima and
+        // write one (value, hypothesis) pair per delay and group instead of the |y|^2 tiles (1/32 of the
+        // bytes at 64 hypotheses per group).  Needs groups that do not straddle templates: with at least one
+        // group per template they are formed per template, evenly sized (F = 201: 4 groups of 51/51/51/48).
+        // The pairs live in the tile buffer: vmax [block][group][tile][64] f32, then imax (same shape, i32).
+        int ns_gpt = 0;
+        {
+            const char* e = getenv("CAF_PERSIST_NOSURF");  // A/B switch, default on
+            if (p->persistent && !out->d_surface && F >= p->hyp_per_wg && (!e || atoi(e))) {
+                const int gpt = (F + p->hyp_per_wg - 1) / p->hyp_per_wg;
+                // the two pair arrays must fit the tile buffer they replace (true for >= 2 hypotheses per group)
+                if (2 * (int64_t)T * gpt <= (int64_t)T * F) ns_gpt = gpt;
+            }
+        }
+        const int nb_launch = ns_gpt ? p->nb_nosurf : p->nb;  // blocks per launch
+        for (int64_t b0 = 0; p->persistent && b0 < nblk; b0 += nb_launch) {
+            const int32_t nbk = (int32_t)std::min<int64_t>(nb_launch, nblk - b0);
             PersistParams h;
             std::memset(&h, 0, sizeof(h));
             h.xb = p->d_xb + b0 * (int64_t)p->B;
@@ -669,26 +698,14 @@ int32_t caf_plan_execute(caf_plan p, const float* d_rx, int64_t rx_len, int64_t 
             h.pq = p->d_pq;
             h.tr_slots = p->tr_slots;
             h.ngroups = (T * F + p->hyp_per_wg - 1) / p->hyp_per_wg;
-            // No surface wanted (per-delay traces / peaks only): the FFT items keep running per-delay maxima and
-            // write one (value, hypothesis) pair per delay and group instead of the |y|^2 tiles (1/32 of the
-            // bytes at 64 hypotheses per group).  Needs groups that do not straddle templates: with at least one
-            // group per template they are formed per template, evenly sized (F = 201: 4 groups of 51/51/51/48).
-            // The pairs live in the tile buffer: vmax [block][group][tile][64] f32, then imax (same shape, i32).
-            {
-                const char* e = getenv("CAF_PERSIST_NOSURF");  // A/B switch, default on
-                if (!out->d_surface && F >= p->hyp_per_wg && (!e || atoi(e))) {
-                    const int gpt = (F + p->hyp_per_wg - 1) / p->hyp_per_wg;
-                    // the two pair arrays must fit the tile buffer they replace (true for >= 2 hypotheses per group)
-                    if (2 * (int64_t)T * gpt <= (int64_t)T * F) {
-                        h.nosurf = 1;
-                        h.gpt = gpt;
-                        h.hyp_per_wg = (F + gpt - 1) / gpt;
-                        h.ngroups = T * gpt;
-                    }
-                }
-                h.vmax = p->d_vt;
-                h.imax = reinterpret_cast<int32_t*>(p->d_vt + (int64_t)p->nb * h.ngroups * p->tiles_per_blk * 64);
+            if (ns_gpt) {
+                h.nosurf = 1;
+                h.gpt = ns_gpt;
+                h.hyp_per_wg = (F + ns_gpt - 1) / ns_gpt;
+                h.ngroups = T * ns_gpt;
             }
+            h.vmax = p->d_vt;
+            h.imax = reinterpret_cast<int32_t*>(p->d_vt + (int64_t)nb_launch * h.ngroups * p->tiles_per_blk * 64);
             h.n_fft = nbk * h.ngroups;
             h.ipb = (p->tiles_per_blk + 15) / 16;  // 16 tiles per item (PQ_TILES, caf_fused.hip)
             h.n_tr = nbk * h.ipb;

@@ -56,3 +56,66 @@ def all_gather_peak_table(local_rows, num_templates, group=None):
     dist.all_gather_into_tensor(out, pad, group=group)
     keep = [out[r * cmax : r * cmax + counts[r]] for r in range(world)]
     return torch.cat(keep, dim=0)
+
+
+def all_gather_peak_columns(cols, num_templates, group=None):
+    """Same exchange as :func:`all_gather_peak_table` for the layout the engine writes: ``cols`` is this
+    rank's (3, t_local) int32 tensor -- row 0 delays, row 1 frequency indices, row 2 the float32 peak values
+    as bits, i.e. the three per-template output arrays of ``caf_plan_execute`` laid end to end in one
+    allocation -- so the collective reads the engine's outputs in place.  Returns the (num_templates, 3) table."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    counts = shard_counts(num_templates, world)
+    cmax = max(counts)
+    if cols.shape[1] == cmax:
+        send = cols.contiguous()
+    else:
+        send = torch.zeros((3, cmax), dtype=torch.int32, device=cols.device)
+        send[:, : cols.shape[1]] = cols
+    out = torch.empty((world * 3, cmax), dtype=torch.int32, device=cols.device)  # rank blocks stacked along dim 0
+    dist.all_gather_into_tensor(out, send, group=group)
+    keep = [out[3 * r : 3 * r + 3, : counts[r]].t() for r in range(world)]
+    return torch.cat(keep, dim=0).contiguous()
+
+
+def sharded_peak_table(num_templates, compute_local, group=None):
+    """One step of the template-sharded peak search (BASELINE config C4).
+
+    ``compute_local(lo, hi)`` evaluates templates [lo, hi) against the replicated rx and returns their peaks
+    as a (3, hi - lo) int32 torch tensor (delay, frequency index, float32 value bits) on the device the
+    process group communicates from (HBM for RCCL, host for gloo).  Templates are block-distributed over
+    the ranks of ``group``; the only collective is the all-gather of the table, which is returned --
+    identical on every rank -- as a (num_templates, 3) tensor.  Without an initialised process group the
+    call is the single-GPU job.  bench.py --workload c4, the gloo tests and the one-GPU full-share test all
+    go through this function."""
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized():
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+    else:
+        world, rank = 1, 0
+    lo, hi = shard_range(num_templates, world, rank)
+    cols = compute_local(lo, hi)
+    if tuple(cols.shape) != (3, hi - lo):
+        raise ValueError("compute_local returned shape %r for templates [%d, %d)" % (tuple(cols.shape), lo, hi))
+    if world == 1:
+        return cols.t().contiguous()
+    return all_gather_peak_columns(cols, num_templates, group)
+
+
+def c4_plant_plan(num_templates, template_len, num_bins, rx_len, seed=4):
+    """Where config C4's synthetic signals sit: template i is planted once, at delay d_i (evenly spread over the
+    delay axis with a seeded jitter, never overlapping a neighbour) with an on-grid frequency offset of k_i
+    bins, k_i in [-num_bins/2, num_bins/2).  Returns (delays int64[T], bins int32[T]); every rank derives the
+    same plan from the seed."""
+    rng = np.random.default_rng(seed)
+    S = rx_len - template_len + 1
+    pitch = S // num_templates
+    if pitch < 2 * template_len:
+        raise ValueError("rx too short to plant %d templates of %d samples apart" % (num_templates, template_len))
+    jitter = rng.integers(0, pitch - template_len, num_templates)
+    delays = pitch * np.arange(num_templates, dtype=np.int64) + jitter
+    bins = rng.integers(-num_bins // 2, num_bins // 2, num_templates).astype(np.int32)
+    return delays, bins

@@ -79,3 +79,78 @@ def test_all_gather_peak_table_gloo(world, num_templates):
     want = sharding.pack_peak_table(1000 + 7 * tids, tids % 5, (tids + 1) / 1024.0)
     for r in range(world):
         np.testing.assert_array_equal(got[r], want)  # identical on every rank, template order preserved
+
+
+# ---- config C4's step (sharding.sharded_peak_table) over gloo, with the oracle standing in for the GPU engine ----
+C4_MINI = dict(num_templates=6, template_len=64, num_bins=8, rx_len=2400)
+
+
+def _c4_mini_inputs():
+    rng = np.random.default_rng(40)
+    T, N, F, M = (C4_MINI[k] for k in ("num_templates", "template_len", "num_bins", "rx_len"))
+    delays, kbins = sharding.c4_plant_plan(T, N, F, M, seed=41)
+    tm = np.exp(1j * (np.pi / 4 + np.pi / 2 * rng.integers(0, 4, (T, N)))).astype(np.complex64)
+    rx = ((rng.standard_normal(M) + 1j * rng.standard_normal(M)) / np.sqrt(2)).astype(np.complex64)
+    for i in range(T):
+        rx[delays[i] : delays[i] + N] += (tm[i] * np.exp(2j * np.pi * kbins[i] * np.arange(N) / N)).astype(np.complex64)
+    return tm, rx, delays, kbins
+
+
+def _oracle_compute_local(tm, rx, bins):
+    """What a rank's engine reports for templates [lo, hi): the oracle's CAF, reduced to (delay, bin index, peak)."""
+    import torch
+
+    import oracle
+
+    def compute(lo, hi):
+        S = rx.size - tm.shape[1] + 1
+        cols = np.zeros((3, hi - lo), np.int32)
+        for j, t in enumerate(range(lo, hi)):
+            surf = oracle.caf_bins(tm[t], rx, bins, np.arange(S))
+            d, f = np.unravel_index(int(np.argmax(surf)), surf.shape)
+            cols[:, j] = (d, f, np.float32(surf[d, f]).view(np.int32))
+        return torch.from_numpy(cols)
+
+    return compute
+
+
+def _c4_worker(rank, world, port, q):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        tm, rx, _, _ = _c4_mini_inputs()
+        bins = np.arange(-C4_MINI["num_bins"] // 2, C4_MINI["num_bins"] // 2)
+        table = sharding.sharded_peak_table(tm.shape[0], _oracle_compute_local(tm, rx, bins))
+        q.put((rank, table.numpy().copy()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_c4_step_sharded_equals_single_process(world):
+    """bench.py --workload c4 calls sharding.sharded_peak_table; here the same function runs over gloo with the
+    oracle as the per-rank engine: the gathered table is identical on every rank, equals the one-process table
+    and recovers every planted (delay, bin).  (world 4 with 6 templates: uneven shards 2/2/1/1.)"""
+    import torch.multiprocessing as mp
+
+    tm, rx, delays, kbins = _c4_mini_inputs()
+    bins = np.arange(-C4_MINI["num_bins"] // 2, C4_MINI["num_bins"] // 2)
+    single = sharding.sharded_peak_table(tm.shape[0], _oracle_compute_local(tm, rx, bins)).numpy()
+    np.testing.assert_array_equal(single[:, 0], delays)
+    np.testing.assert_array_equal(bins[single[:, 1]], kbins)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_c4_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(world):
+        np.testing.assert_array_equal(got[r], single)
