@@ -1,0 +1,85 @@
+// Device-side complex helpers and the in-register inverse DFT butterflies shared by the LDS-resident FFT kernels
+// (caf_fused.hip: 16384-point hypothesis transform; caf_perdelay.hip: per-delay row transforms).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace caf {
+
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ float2 mulj(float2 a) { return make_float2(-a.y, a.x); }  // * (+j)
+// inverse 4-point DFT (kernel e^{+j 2 pi m n / 4}), in place
+__device__ __forceinline__ void idft4(float2& a0, float2& a1, float2& a2, float2& a3) {
+    const float2 s02 = cadd(a0, a2), d02 = csub(a0, a2);
+    const float2 s13 = cadd(a1, a3), d13 = mulj(csub(a1, a3));
+    a0 = cadd(s02, s13);
+    a1 = cadd(d02, d13);
+    a2 = csub(s02, s13);
+    a3 = csub(d02, d13);
+}
+
+// inverse 16-point DFT in registers: v[k] <- sum_m v[m] W^{mk}, W = e^{+j 2 pi / 16}
+__device__ __forceinline__ void idft16(float2 (&v)[16]) {
+    constexpr float C1 = 0.92387953251128674f;  // cos(pi/8)
+    constexpr float S1 = 0.38268343236508977f;  // sin(pi/8)
+    constexpr float R2 = 0.70710678118654752f;  // 1/sqrt(2)
+    // stage 1: for each m2 in 0..3, DFT4 over m1 of v[4 m1 + m2]  ->  v[4 n1 + m2] = u[m2][n1]
+#pragma unroll
+    for (int m2 = 0; m2 < 4; ++m2) idft4(v[m2], v[4 + m2], v[8 + m2], v[12 + m2]);
+    // internal twiddles W^{m2 n1}
+    {
+        const float2 w1 = make_float2(C1, S1), w3 = make_float2(S1, C1);
+        v[4 * 1 + 1] = cmul(v[4 * 1 + 1], w1);
+        v[4 * 2 + 1] = make_float2((v[4 * 2 + 1].x - v[4 * 2 + 1].y) * R2, (v[4 * 2 + 1].x + v[4 * 2 + 1].y) * R2);  // W^2
+        v[4 * 3 + 1] = cmul(v[4 * 3 + 1], w3);
+        v[4 * 1 + 2] = make_float2((v[4 * 1 + 2].x - v[4 * 1 + 2].y) * R2, (v[4 * 1 + 2].x + v[4 * 1 + 2].y) * R2);  // W^2
+        v[4 * 2 + 2] = mulj(v[4 * 2 + 2]);                                                                             // W^4
+        v[4 * 3 + 2] = make_float2((-v[4 * 3 + 2].x - v[4 * 3 + 2].y) * R2, (v[4 * 3 + 2].x - v[4 * 3 + 2].y) * R2);  // W^6
+        v[4 * 1 + 3] = cmul(v[4 * 1 + 3], w3);
+        v[4 * 2 + 3] = make_float2((-v[4 * 2 + 3].x - v[4 * 2 + 3].y) * R2, (v[4 * 2 + 3].x - v[4 * 2 + 3].y) * R2);  // W^6
+        v[4 * 3 + 3] = cmul(v[4 * 3 + 3], make_float2(-C1, -S1));                                                      // W^9
+    }
+    // stage 2: for each n1, DFT4 over m2 of v[4 n1 + m2] -> Y[n1 + 4 n2] at v[4 n1 + n2]
+#pragma unroll
+    for (int n1 = 0; n1 < 4; ++n1) idft4(v[4 * n1 + 0], v[4 * n1 + 1], v[4 * n1 + 2], v[4 * n1 + 3]);
+    // 4x4 transpose of register names so that v[k] = Y[k]
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = a + 1; b < 4; ++b) {
+            const float2 t = v[4 * a + b];
+            v[4 * a + b] = v[4 * b + a];
+            v[4 * b + a] = t;
+        }
+}
+
+// inverse 2-point and 8-point DFTs (kernel e^{+j 2 pi m n / R}), in place, natural order in and out
+__device__ __forceinline__ void idft2(float2& a0, float2& a1) {
+    const float2 s = cadd(a0, a1), d = csub(a0, a1);
+    a0 = s;
+    a1 = d;
+}
+__device__ __forceinline__ void idft8(float2 (&v)[8]) {
+    constexpr float R2 = 0.70710678118654752f;
+    // two 4-point transforms over the even / odd inputs, then the radix-2 combination with W8^k = e^{+j pi k / 4}
+    float2 e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
+    float2 o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
+    idft4(e0, e1, e2, e3);
+    idft4(o0, o1, o2, o3);
+    o1 = make_float2((o1.x - o1.y) * R2, (o1.x + o1.y) * R2);    // * W8^1
+    o2 = mulj(o2);                                                 // * W8^2
+    o3 = make_float2((-o3.x - o3.y) * R2, (o3.x - o3.y) * R2);   // * W8^3
+    v[0] = cadd(e0, o0);
+    v[4] = csub(e0, o0);
+    v[1] = cadd(e1, o1);
+    v[5] = csub(e1, o1);
+    v[2] = cadd(e2, o2);
+    v[6] = csub(e2, o2);
+    v[3] = cadd(e3, o3);
+    v[7] = csub(e3, o3);
+}
+
+}  // namespace caf

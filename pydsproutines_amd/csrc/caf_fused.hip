@@ -27,6 +27,7 @@
 #include <cstdlib>
 
 #include "caf_internal.h"
+#include "caf_fft_dev.h"
 
 namespace caf {
 
@@ -35,12 +36,6 @@ constexpr int F_ROW = 68;              // sub-row pitch (64 used)
 constexpr int F_N1 = 16 * F_ROW + 2;   // pitch between n1 planes (1090)
 constexpr int F_LDS_DATA = 16 * F_N1;  // complex elements
 
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
-    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
-}
-__device__ __forceinline__ float2 mulj(float2 a) { return make_float2(-a.y, a.x); }  // * (+j)
 // Global-memory accessors: uniform base + 32-bit BYTE offset lets the compiler pick the scalar-base (saddr)
 // addressing form instead of building a 64-bit address per access.  The explicit address-space-1 casts keep
 // the accesses global_* (not flat_*) even where the base pointer was rebuilt from scalar halves
@@ -68,51 +63,6 @@ __device__ __forceinline__ void gst1(float* base, uint32_t byteoff, float v) {
 __device__ __forceinline__ void gst1_wt(float* base, uint32_t byteoff, float v) {
     __hip_atomic_store(reinterpret_cast<CAF_AS1 float*>((CAF_AS1 char*)base + byteoff), v, __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// inverse 4-point DFT (kernel e^{+j 2 pi m n / 4}), in place
-__device__ __forceinline__ void idft4(float2& a0, float2& a1, float2& a2, float2& a3) {
-    const float2 s02 = cadd(a0, a2), d02 = csub(a0, a2);
-    const float2 s13 = cadd(a1, a3), d13 = mulj(csub(a1, a3));
-    a0 = cadd(s02, s13);
-    a1 = cadd(d02, d13);
-    a2 = csub(s02, s13);
-    a3 = csub(d02, d13);
-}
-
-// inverse 16-point DFT in registers: v[k] <- sum_m v[m] W^{mk}, W = e^{+j 2 pi / 16}
-__device__ __forceinline__ void idft16(float2 (&v)[16]) {
-    constexpr float C1 = 0.92387953251128674f;  // cos(pi/8)
-    constexpr float S1 = 0.38268343236508977f;  // sin(pi/8)
-    constexpr float R2 = 0.70710678118654752f;  // 1/sqrt(2)
-    // stage 1: for each m2 in 0..3, DFT4 over m1 of v[4 m1 + m2]  ->  v[4 n1 + m2] = u[m2][n1]
-#pragma unroll
-    for (int m2 = 0; m2 < 4; ++m2) idft4(v[m2], v[4 + m2], v[8 + m2], v[12 + m2]);
-    // internal twiddles W^{m2 n1}
-    {
-        const float2 w1 = make_float2(C1, S1), w3 = make_float2(S1, C1);
-        v[4 * 1 + 1] = cmul(v[4 * 1 + 1], w1);
-        v[4 * 2 + 1] = make_float2((v[4 * 2 + 1].x - v[4 * 2 + 1].y) * R2, (v[4 * 2 + 1].x + v[4 * 2 + 1].y) * R2);  // W^2
-        v[4 * 3 + 1] = cmul(v[4 * 3 + 1], w3);
-        v[4 * 1 + 2] = make_float2((v[4 * 1 + 2].x - v[4 * 1 + 2].y) * R2, (v[4 * 1 + 2].x + v[4 * 1 + 2].y) * R2);  // W^2
-        v[4 * 2 + 2] = mulj(v[4 * 2 + 2]);                                                                             // W^4
-        v[4 * 3 + 2] = make_float2((-v[4 * 3 + 2].x - v[4 * 3 + 2].y) * R2, (v[4 * 3 + 2].x - v[4 * 3 + 2].y) * R2);  // W^6
-        v[4 * 1 + 3] = cmul(v[4 * 1 + 3], w3);
-        v[4 * 2 + 3] = make_float2((-v[4 * 2 + 3].x - v[4 * 2 + 3].y) * R2, (v[4 * 2 + 3].x - v[4 * 2 + 3].y) * R2);  // W^6
-        v[4 * 3 + 3] = cmul(v[4 * 3 + 3], make_float2(-C1, -S1));                                                      // W^9
-    }
-    // stage 2: for each n1, DFT4 over m2 of v[4 n1 + m2] -> Y[n1 + 4 n2] at v[4 n1 + n2]
-#pragma unroll
-    for (int n1 = 0; n1 < 4; ++n1) idft4(v[4 * n1 + 0], v[4 * n1 + 1], v[4 * n1 + 2], v[4 * n1 + 3]);
-    // 4x4 transpose of register names so that v[k] = Y[k]
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = a + 1; b < 4; ++b) {
-            const float2 t = v[4 * a + b];
-            v[4 * a + b] = v[4 * b + a];
-            v[4 * b + a] = t;
-        }
 }
 
 // |y|^2 tiles: vt[blk_local][s_tile][h][64]  (s_tile = delay/64 inside the block)

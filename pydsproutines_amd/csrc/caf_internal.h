@@ -61,7 +61,7 @@ void scan_tiles(double* tile_sums, int64_t ntiles, hipStream_t st);
 // caf_rows.hip
 void launch_sliding_multiply(const float2* x, int32_t xlen, const float2* y, int64_t ylen, const double* prefix,
                              int64_t start, int64_t step, int64_t rows, double coef, int32_t zero_oor, float2* z,
-                             hipStream_t st);
+                             hipStream_t st, const double* d_coef = nullptr);  // d_coef: device scalar multiplied into coef
 void launch_rows_argmax(const float2* z, int64_t rows, int64_t len, int32_t use_normsq, float scale, uint32_t* argmax,
                         float* maxv, float* plane, hipStream_t st);
 void launch_magnsq(const void* x, int64_t n, int in_c128, void* out, int out_f64, hipStream_t st);
@@ -102,6 +102,13 @@ void launch_scale(float2* y, int64_t n, float scale, hipStream_t st);
 void launch_iq16_to_c64(const short* in, int64_t nsamp, float scale, float2* out, hipStream_t st);
 void launch_argmax3d_u32(const uint32_t* x, int64_t items, int32_t d1, int32_t d2, int32_t d3, uint32_t* argmax,
                          uint32_t* maxv, hipStream_t st);
+
+// caf_perdelay.hip: fused per-delay correlator (product -> LDS FFT -> |.|^2 -> argmax), power-of-two n in [64, 16384]
+bool perdelay_fused_ok(int32_t n);
+int launch_perdelay_fused(const float2* x, int32_t n, const float2* y, int64_t ylen, int64_t start, int64_t step,
+                          int64_t num, int32_t zero_oor, float* qf2, uint32_t* fidx, float* plane, float2* cplane,
+                          hipStream_t st);
+void launch_cutout_norm(const float2* x, int64_t n, double* out, hipStream_t st);
 
 // caf_fused.hip
 void launch_fused_caf(const float2* xb, const float2* hc, const int32_t* shifts, const float2* tw1,

@@ -3,6 +3,7 @@
 // gfx950 kernels of caf_rows.hip / caf_kernels.hip and batched rocFFT rows.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -120,17 +121,41 @@ int32_t caf_xcorr_perdelay(const float* d_cutout, int32_t n, const float* d_rx, 
     }
     if (num == 0) return CAF_OK;
     hipStream_t st = (hipStream_t)stream;
+    // Power-of-two cutouts up to 16384 samples: one fused kernel (product -> LDS FFT -> |.|^2 -> argmax; window energies
+    // and the cutout norm summed in the kernel): no product matrix, no prefix pass, no scratch, no synchronisation.
+    // CAF_PERDELAY_UNFUSED=1 keeps the three-kernel form below (A/B switch; it also serves every other length).
+    {
+        static const bool unfused = [] {
+            const char* e = getenv("CAF_PERDELAY_UNFUSED");
+            return e && atoi(e) != 0;
+        }();
+        if (!unfused && perdelay_fused_ok(n)) {
+            const int rc1 = launch_perdelay_fused((const float2*)d_cutout, n, (const float2*)d_rx, rx_len, start, step, num,
+                                                  zero_oor ? 1 : 0, d_qf2, (uint32_t*)d_fidx, d_caf, (float2*)d_ccaf, st);
+            if (rc1) return rc1;
+            CAF_HIP_TRY(hipGetLastError());
+            return CAF_OK;
+        }
+    }
     Scratch sc;
+    // energy prefix over the span of rx the delays touch (not the whole array: 128 delays of a 10^7-sample rx used
+    // to cost a full pass), indices shifted accordingly; only when every window lies inside rx (otherwise the
+    // out-of-range rules are stated against the whole array and the whole array is scanned)
+    const int64_t s_last = start + (num - 1) * step;
+    const int64_t span_lo = std::max<int64_t>(0, std::min(start, s_last));
+    const int64_t span_hi = std::min<int64_t>(rx_len, std::max(start, s_last) + n);
+    const bool clip = span_hi > span_lo && (span_lo > 0 || span_hi < rx_len) && span_lo == std::min(start, s_last) &&
+                      span_hi == std::max(start, s_last) + n;  // only when no window leaves rx
+    const float2* yv = (const float2*)d_rx + (clip ? span_lo : 0);
+    const int64_t ylen_v = clip ? span_hi - span_lo : rx_len;
+    const int64_t start_v = clip ? start - span_lo : start;
     double* prefix = nullptr;
-    int rc = energy_prefix((const float2*)d_rx, rx_len, sc, &prefix, st);
+    int rc = energy_prefix(yv, ylen_v, sc, &prefix, st);
     if (rc) return rc;
-    // ||cutout|| in float64 on the host (n is small compared with the work that follows)
-    std::vector<float> hc((size_t)n * 2);
-    CAF_HIP_TRY(hipMemcpyAsync(hc.data(), d_cutout, (size_t)n * 8, hipMemcpyDeviceToHost, st));
-    CAF_HIP_TRY(hipStreamSynchronize(st));
-    double e = 0.0;
-    for (size_t i = 0; i < hc.size(); ++i) e += (double)hc[i] * (double)hc[i];
-    const double cnorm = std::sqrt(e);
+    // ||cutout|| in float64 on the device (no host round trip)
+    double* d_cnorm = nullptr;
+    if ((rc = sc.get(&d_cnorm, 1))) return rc;
+    launch_cutout_norm((const float2*)d_cutout, n, d_cnorm, st);
     if (batch_rows <= 0) batch_rows = std::max<int64_t>(1, std::min<int64_t>(num, ((int64_t)1 << 25) / n));
     batch_rows = std::min(batch_rows, num);
     float2* rows = nullptr;
@@ -139,8 +164,8 @@ int32_t caf_xcorr_perdelay(const float* d_cutout, int32_t n, const float* d_rx, 
     for (int64_t r0 = 0; r0 < num; r0 += batch_rows) {
         const int64_t nr = std::min(batch_rows, num - r0);
         float2* buf = direct ? direct + r0 * n : rows;
-        launch_sliding_multiply((const float2*)d_cutout, n, (const float2*)d_rx, rx_len, prefix, start + r0 * step, step,
-                                nr, cnorm, zero_oor ? 1 : 0, buf, st);
+        launch_sliding_multiply((const float2*)d_cutout, n, yv, ylen_v, prefix, start_v + r0 * step, step, nr, 1.0,
+                                zero_oor ? 1 : 0, buf, st, d_cnorm);
         if ((rc = fft_rows(buf, buf, nr, n, false, st))) return rc;
         if (d_qf2 || d_fidx || d_caf)
             launch_rows_argmax(buf, nr, n, 1, 1.0f, (uint32_t*)(d_fidx ? d_fidx + r0 : nullptr), d_qf2 ? d_qf2 + r0 : nullptr,

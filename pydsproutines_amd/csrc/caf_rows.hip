@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void k_sliding_multiply(const float2* __restri
                                                           const float2* __restrict__ y, int64_t ylen,
                                                           const double* __restrict__ prefix, int64_t start,
                                                           int64_t step, double coef, int32_t zero_oor,
-                                                          float2* __restrict__ z) {
+                                                          float2* __restrict__ z, const double* __restrict__ d_coef) {
     const int64_t row = blockIdx.y;
     const int64_t s = start + row * step;
     const bool oor = (s < 0) || (s + xlen > ylen);
@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void k_sliding_multiply(const float2* __restri
         int64_t b = s + xlen;
         b = b < 0 ? 0 : (b > ylen ? ylen : b);
         const double e = prefix[b] - prefix[a];
-        inv = (float)(1.0 / (sqrt(e) * coef));
+        inv = (float)(1.0 / (sqrt(e) * (d_coef ? coef * *d_coef : coef)));
     }
     float2* zr = z + row * (int64_t)xlen;
     for (int t = blockIdx.x * 256 + threadIdx.x; t < xlen; t += gridDim.x * 256) {
@@ -1015,14 +1015,37 @@ __global__ __launch_bounds__(256) void k_colmax_sqrt(const float* __restrict__ q
 // ---------------------------------------------------------------------------------------
 static inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
 
+// ||x|| = sqrt(sum |x|^2) of a complex64 vector in float64, one workgroup (the cutout of the per-delay path:
+// replaces a blocking device-to-host copy + host loop)
+__global__ __launch_bounds__(1024) void k_cutout_norm(const float2* __restrict__ x, int64_t n, double* __restrict__ out) {
+    __shared__ double s[16];
+    double e = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        const float2 a = x[i];
+        e += (double)a.x * a.x + (double)a.y * a.y;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o, 64);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = e;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < 16; ++w) t += s[w];
+        *out = sqrt(t);
+    }
+}
+void launch_cutout_norm(const float2* x, int64_t n, double* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_cutout_norm, dim3(1), dim3(1024), 0, st, x, n, out);
+}
+
 void launch_sliding_multiply(const float2* x, int32_t xlen, const float2* y, int64_t ylen, const double* prefix,
                              int64_t start, int64_t step, int64_t rows, double coef, int32_t zero_oor, float2* z,
-                             hipStream_t st) {
+                             hipStream_t st, const double* d_coef) {
     const unsigned gx = std::min<unsigned>(cdiv(xlen, 256), 64);
     for (int64_t r0 = 0; r0 < rows; r0 += 65535) {
         const int64_t nr = std::min<int64_t>(65535, rows - r0);
         hipLaunchKernelGGL(k_sliding_multiply, dim3(gx, (unsigned)nr), dim3(256), 0, st, x, xlen, y, ylen, prefix,
-                           start + r0 * step, step, coef, zero_oor, z + r0 * (int64_t)xlen);
+                           start + r0 * step, step, coef, zero_oor, z + r0 * (int64_t)xlen, d_coef);
     }
 }
 

@@ -1,0 +1,116 @@
+"""GPU parity tests of the fused per-delay correlator (csrc/caf_perdelay.hip) behind caf_xcorr_perdelay:
+every power-of-two cutout length 64 ... 16384 against the oracle's fastXcorr branches B / C / C'
+(the reference's literal algorithm, xcorrRoutines.py:511-580), strided and descending delay runs, the
+out-of-range rules of both native twins (IppXcorrFFT.cpp:125-130 zero rows; multiplySlices.cu:147-163 zero
+padding), and agreement with the three-kernel form it replaces (CAF_PERDELAY_UNFUSED=1, separate process)."""
+
+import ctypes as ct
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle as O
+from conftest import REPO, cn
+
+pytestmark = pytest.mark.gpu
+
+
+def _perdelay(cut_conj, rx, start, step, num, zero_oor=False, caf=False, ccaf=False):
+    from pydsproutines_amd import _lib, asarray
+    from pydsproutines_amd.devarray import empty
+
+    lib = _lib.load()
+    n = cut_conj.size
+    d_cut, d_rx = asarray(cut_conj), asarray(rx)
+    qf2, idx = empty(num, np.float32), empty(num, np.int32)
+    pl = empty((num, n), np.float32) if caf else None
+    cp = empty((num, n), np.complex64) if ccaf else None
+    p = lambda a: ct.c_void_p(a.ptr) if a is not None else None  # noqa: E731
+    _lib.check(lib.caf_xcorr_perdelay(p(d_cut), n, p(d_rx), rx.size, int(start), int(step), int(num), 1 if zero_oor else 0,
+                                      p(qf2), p(idx), p(pl), p(cp), 0, None), "caf_xcorr_perdelay")
+    _lib.check(lib.caf_stream_sync(None))
+    return qf2.get(), idx.get(), (pl.get() if caf else None), (cp.get() if ccaf else None)
+
+
+@pytest.mark.parametrize("log2n", range(6, 15))
+def test_fused_perdelay_matches_oracle(log2n):
+    n = 1 << log2n
+    rng = np.random.default_rng(100 + log2n)
+    m = n + 700
+    rx = cn(rng, m)
+    d0, k0 = 123, (3 * n) // 8 + 1
+    cut = (rx[d0 : d0 + n] * np.exp(-2j * np.pi * k0 * np.arange(n) / n)).astype(np.complex64)  # planted at (d0, k0)
+    rx = (rx + 0.05 * cn(rng, m)).astype(np.complex64)
+    num = 600 if n <= 4096 else 150
+    shifts = np.arange(num)
+    q, fi, pl, cp = _perdelay(cut.conj(), rx, 0, 1, num, caf=True, ccaf=True)
+    ref_c = O.fastXcorr(cut, rx, freqsearch=True, outputCAF=True, shifts=shifts)                  # branch C
+    ref_cc = O.fastXcorr(cut, rx, freqsearch=True, outputCAF=True, shifts=shifts, absResult=False)  # branch C'
+    tol = 2e-5
+    assert np.max(np.abs(pl - ref_c)) <= tol
+    assert np.max(np.abs(cp - ref_cc)) <= 1e-4 * max(1.0, np.abs(ref_cc).max())
+    np.testing.assert_array_equal(q, pl.max(axis=1))              # row results == the plane it wrote
+    np.testing.assert_array_equal(fi, np.argmax(pl, axis=1))      # first index of the maximum
+    assert (int(np.argmax(q)), int(fi[np.argmax(q)])) == (d0, k0)
+    top2 = np.sort(ref_c, axis=1)[:, -2:]
+    clear = top2[:, 1] - top2[:, 0] > 4 * tol
+    np.testing.assert_array_equal(fi[clear], np.argmax(ref_c, axis=1)[clear])
+
+
+def test_fused_perdelay_strides_and_out_of_range_rules():
+    n = 256
+    rng = np.random.default_rng(7)
+    rx = cn(rng, 3000)
+    cut = cn(rng, n)
+    # strided ascending and descending runs
+    for start, step, num in ((5, 7, 300), (2700, -9, 280), (0, 1, 3000 - n + 1)):
+        q, fi, _, _ = _perdelay(cut.conj(), rx, start, step, num)
+        sh = start + step * np.arange(num)
+        rq, rf = O.fastXcorr(cut, rx, freqsearch=True, shifts=sh)
+        assert np.max(np.abs(q - rq)) <= 2e-5
+        assert np.mean(fi == rf) > 0.99
+    # CyIppXcorrFFT rule: windows that leave rx give (0, 0)
+    q, fi, pl, _ = _perdelay(cut.conj(), rx, -40, 1, 3000 - n + 90, zero_oor=True, caf=True)
+    inside = (np.arange(-40, 3000 - n + 50) >= 0) & (np.arange(-40, 3000 - n + 50) + n <= 3000)
+    assert np.all(q[~inside] == 0) and np.all(fi[~inside] == 0) and np.all(pl[~inside] == 0)
+    rq, rf = O.fastXcorr(cut, rx, freqsearch=True, shifts=np.arange(0, 3000 - n + 1))
+    assert np.max(np.abs(q[inside] - rq)) <= 2e-5
+    # an all-zero window: NaN plane, (0, 0) row result
+    rz = rx.copy()
+    rz[1000 : 1000 + n + 10] = 0
+    q, fi, pl, _ = _perdelay(cut.conj(), rz, 1000, 1, 8, caf=True)
+    assert np.all(q == 0) and np.all(fi == 0) and np.all(np.isnan(pl))
+
+
+def test_fused_equals_three_kernel_form():
+    """The same calls through the path it replaces (rocFFT rows), in a child process because the switch is read once."""
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests')
+from test_gpu_perdelay import _perdelay
+from conftest import cn
+rng = np.random.default_rng(5)
+out = {}
+for n in (64, 1024, 4096):
+    rx = cn(rng, n + 500); cut = cn(rng, n)
+    q, fi, pl, _ = _perdelay(cut.conj(), rx, 3, 2, 200, caf=True)
+    out['q%%d' %% n], out['f%%d' %% n], out['p%%d' %% n] = q, fi, pl
+np.savez(sys.argv[1], **out)
+""" % (REPO, REPO)
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as td:
+        res = {}
+        for tag, env in (("fused", {}), ("unfused", {"CAF_PERDELAY_UNFUSED": "1"})):
+            path = os.path.join(td, tag + ".npz")
+            subprocess.run([sys.executable, "-c", code, path], check=True, env={**os.environ, **env}, timeout=600)
+            res[tag] = dict(np.load(path))
+    for k in res["fused"]:
+        a, b = res["fused"][k], res["unfused"][k]
+        if k.startswith("f"):
+            assert np.mean(a == b) > 0.99, k
+        else:
+            assert np.max(np.abs(a - b)) <= 2e-6, k
