@@ -109,6 +109,22 @@ int launch_perdelay_fused(const float2* x, int32_t n, const float2* y, int64_t y
                           int64_t num, int32_t zero_oor, float* qf2, uint32_t* fidx, float* plane, float2* cplane,
                           hipStream_t st);
 void launch_cutout_norm(const float2* x, int64_t n, double* out, hipStream_t st);
+// e^{+j 2 pi q / 16384}, q < 16384: the twiddle table of the in-LDS transforms (caf_ldsfft.h), built once per device
+int lds_fft_twiddles(int device, const float2** out);
+
+// caf_firos.hip: overlap-save FIR (fused in-LDS form for <= 8192 taps; gather / scatter kernels for the rocFFT rows)
+int fir_os_fused_block(int32_t ntaps);
+int launch_fir_os_fused(const float2* x, int64_t n, const float* taps, int32_t ntaps, const float2* delay, int32_t dlen,
+                        int32_t dsr, int32_t phase, float2* out, int64_t nout, float2* ht, hipStream_t st);
+int launch_iq16_fir_os_fused(const int16_t* iq, int64_t n, float scale, const float* taps, int32_t ntaps, const int16_t* delay,
+                             int32_t dlen, int32_t dsr, int32_t phase, float2* out, int64_t nout, float2* ht, hipStream_t st);
+void launch_fos_gather(const float2* x, int64_t n, const float2* delay, int32_t dlen, int64_t b0, int64_t nb, int64_t L,
+                       int64_t B, int32_t ntaps, float2* rows, hipStream_t st);
+void launch_fos_gather_iq16(const int16_t* x, int64_t n, float scale, const int16_t* delay, int32_t dlen, int64_t b0,
+                            int64_t nb, int64_t L, int64_t B, int32_t ntaps, float2* rows, hipStream_t st);
+void launch_fos_taps_pad(const float* taps, int32_t ntaps, int64_t B, float2* row, hipStream_t st);
+void launch_fos_scatter(const float2* rows, int64_t b0, int64_t nb, int64_t L, int64_t B, int32_t ntaps, int32_t dsr,
+                        int32_t phase, float2* out, int64_t nout, hipStream_t st);
 
 // caf_fused.hip
 void launch_fused_caf(const float2* xb, const float2* hc, const int32_t* shifts, const float2* tw1,

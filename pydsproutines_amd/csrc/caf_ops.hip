@@ -96,6 +96,61 @@ int energy_prefix(const float2* x, int64_t n, Scratch& sc, double** prefix, hipS
     return CAF_OK;
 }
 
+// Overlap-save FIR (caf_firos.hip).  Direct form costs ntaps multiply-adds per KEPT output, overlap-save ~130 flops
+// per full-rate output: it wins once ntaps / dsr passes a few hundred, and it is the only form for tap sets longer
+// than the direct kernels' LDS windows.  CAF_FIR_OS_MIN_TAPS overrides the 256 (A/B switch; 0 = always).
+bool fir_use_overlap_save(int32_t ntaps, int32_t dsr, int32_t direct_limit) {
+    static const int min_taps = [] {
+        const char* e = getenv("CAF_FIR_OS_MIN_TAPS");
+        return e ? atoi(e) : 256;
+    }();
+    return ntaps > direct_limit || (int64_t)ntaps > (int64_t)min_taps * dsr;
+}
+
+// is_iq16: x / delay are interleaved int16 IQ pairs scaled by `scale`, else complex64
+int fir_overlap_save(const void* x, int64_t n, bool is_iq16, float scale, const float* taps, int32_t ntaps, const void* delay,
+                     int32_t dlen, int32_t dsr, int32_t phase, float2* out, int64_t nout, hipStream_t st) {
+    if (nout <= 0) return CAF_OK;
+    Scratch sc;
+    int rc;
+    if (const int fb = fir_os_fused_block(ntaps)) {
+        float2* ht = nullptr;
+        if ((rc = sc.get(&ht, fb))) return rc;
+        rc = is_iq16 ? launch_iq16_fir_os_fused((const int16_t*)x, n, scale, taps, ntaps, (const int16_t*)delay, dlen, dsr, phase,
+                                                out, nout, ht, st)
+                     : launch_fir_os_fused((const float2*)x, n, taps, ntaps, (const float2*)delay, dlen, dsr, phase, out, nout,
+                                           ht, st);
+        if (rc) return rc;
+    } else {
+        // long tap sets: rocFFT rows of B >= 4 ntaps points (>= 75 % new outputs per block)
+        int64_t B = 65536;
+        while (B < 4 * (int64_t)ntaps) B <<= 1;
+        CAF_REQUIRE(B <= ((int64_t)1 << 26), "overlap-save FIR: more than 2^24 taps");
+        const int64_t L = B - ntaps + 1;
+        const int64_t last = phase + (nout - 1) * (int64_t)dsr;
+        const int64_t nblk = last / L + 1;
+        const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(nblk, 65535), ((int64_t)1 << 25) / B));
+        float2 *rows = nullptr, *hrow = nullptr;
+        if ((rc = sc.get(&rows, chunk * B)) || (rc = sc.get(&hrow, B))) return rc;
+        launch_fos_taps_pad(taps, ntaps, B, hrow, st);
+        if ((rc = fft_rows(hrow, hrow, 1, B, false, st))) return rc;
+        for (int64_t b0 = 0; b0 < nblk; b0 += chunk) {
+            const int64_t nb = std::min(chunk, nblk - b0);
+            if (is_iq16)
+                launch_fos_gather_iq16((const int16_t*)x, n, scale, (const int16_t*)delay, dlen, b0, nb, L, B, ntaps, rows, st);
+            else
+                launch_fos_gather((const float2*)x, n, (const float2*)delay, dlen, b0, nb, L, B, ntaps, rows, st);
+            if ((rc = fft_rows(rows, rows, nb, B, false, st))) return rc;
+            launch_rows_mul_vec(rows, B, 0, hrow, B, rows, B, B, nb, 1.0f / (float)B, st);
+            if ((rc = fft_rows(rows, rows, nb, B, true, st))) return rc;
+            launch_fos_scatter(rows, b0, nb, L, B, ntaps, dsr, phase, out, nout, st);
+        }
+    }
+    CAF_HIP_TRY(hipStreamSynchronize(st));  // scratch is freed on return
+    CAF_HIP_TRY(hipGetLastError());
+    return CAF_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -322,9 +377,11 @@ int32_t caf_fir_lfilter(const float* d_x, int64_t n, const float* d_taps, int32_
                         int32_t delay_len, int32_t dsr, int32_t ds_phase, float* d_out, int64_t out_len, void* stream) {
     CAF_REQUIRE(d_x && d_taps && d_out && n >= 1 && num_taps >= 1, "caf_fir_lfilter: bad arguments");
     CAF_REQUIRE(dsr >= 1 && ds_phase >= 0 && ds_phase < dsr, "dsPhase must be between in the range [0,dsr-1].");
-    CAF_REQUIRE(num_taps <= 4096, "more than 4096 taps: use an overlap-save FIR (hypothesis engine) instead");
     CAF_REQUIRE(delay_len >= 0 && (delay_len == 0 || d_delay), "delay_len > 0 needs d_delay");
     CAF_REQUIRE(out_len >= 0 && out_len <= (n - ds_phase + dsr - 1) / dsr, "caf_fir_lfilter: out_len exceeds len(x[dsPhase::dsr])");
+    if (fir_use_overlap_save(num_taps, dsr, 4096))  // long tap sets: frequency-domain blocks (any length)
+        return fir_overlap_save(d_x, n, false, 1.0f, d_taps, num_taps, d_delay, delay_len, dsr, ds_phase, (float2*)d_out, out_len,
+                                (hipStream_t)stream);
     launch_fir((const float2*)d_x, n, d_taps, num_taps, (const float2*)d_delay, delay_len, dsr, ds_phase, (float2*)d_out,
                out_len, (hipStream_t)stream);
     CAF_HIP_TRY(hipGetLastError());
@@ -336,11 +393,14 @@ int32_t caf_iq16_fir_decimate(const int16_t* d_iq, int64_t num_samples, float sc
                               int64_t out_len, void* stream) {
     CAF_REQUIRE(d_iq && d_taps && d_out && num_samples >= 1 && num_taps >= 1, "caf_iq16_fir_decimate: bad arguments");
     CAF_REQUIRE(dsr >= 1 && ds_phase >= 0 && ds_phase < dsr, "dsPhase must be between in the range [0,dsr-1].");
-    CAF_REQUIRE(fir_decim_ok(num_taps, dsr), "caf_iq16_fir_decimate: at most 2048 taps and dsr <= 16");
     CAF_REQUIRE(delay_len >= 0 && (delay_len == 0 || d_delay), "delay_len > 0 needs d_delay");
     CAF_REQUIRE(((uintptr_t)d_iq & 3) == 0 && ((uintptr_t)d_delay & 3) == 0, "caf_iq16_fir_decimate: IQ pairs must be 4-byte aligned");
     CAF_REQUIRE(out_len >= 0 && out_len <= (num_samples - ds_phase + dsr - 1) / dsr,
                 "caf_iq16_fir_decimate: out_len exceeds len(x[dsPhase::dsr])");
+    // direct polyphase form: <= 2048 taps and dsr <= 16; anything else (and long tap sets) goes overlap-save
+    if (!fir_decim_ok(num_taps, dsr) || fir_use_overlap_save(num_taps, dsr, 2048))
+        return fir_overlap_save(d_iq, num_samples, true, scale, d_taps, num_taps, d_delay, delay_len, dsr, ds_phase,
+                                (float2*)d_out, out_len, (hipStream_t)stream);
     launch_iq16_fir(d_iq, num_samples, scale, d_taps, num_taps, d_delay, delay_len, dsr, ds_phase, (float2*)d_out, out_len,
                     (hipStream_t)stream);
     CAF_HIP_TRY(hipGetLastError());

@@ -122,8 +122,8 @@ class CupyKernelFilter:
         delay = self.delay if useInternalDelay else None
         if useInternalDelay and delay is None:
             raise TypeError("Delay has not been allocated. Re-initialize with memory argument.")
-        if d_taps.size > 4096:
-            raise MemoryError("Shared memory requested %d bytes exceeds maximum" % d_taps.nbytes)
+        # (no tap limit: beyond a few hundred taps per kept output libcaf switches to its overlap-save form, any length;
+        # the reference's kernel stops where the taps no longer fit its shared memory, cupyHelpers.py:50-77)
         _lib.check(_lib.load().caf_fir_lfilter(_p(d_x), d_x.size, _p(d_taps), d_taps.size, _p(delay),
                                                delay.size if delay is not None else 0, int(dsr), int(dsPhase),
                                                _p(d_out), outlength, None))

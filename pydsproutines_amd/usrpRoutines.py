@@ -40,8 +40,6 @@ class Iq16FrontEnd:
             raise ValueError("d_taps must be 1D.")
         if dsPhase >= dsr or dsPhase < 0:
             raise ValueError("dsPhase must be between in the range [0,dsr-1].")
-        if d_taps.size > 2048 or dsr > 16:
-            raise MemoryError("at most 2048 taps and dsr <= 16")
         self.d_taps, self.dsr, self.scale = d_taps, int(dsr), float(scale)
         self.phase = int(dsPhase)  # phase of the next chunk
         self.delay = None  # int16 (2 * (ntaps - 1),): the IQ pairs preceding the next chunk
