@@ -880,26 +880,41 @@ __global__ __launch_bounds__(256) void k_fir_poly(const TIn* __restrict__ x, int
 
 // upfirdn == scipy.signal.upfirdn(taps, x, up, down) per row; out[r][o] = sum_k taps[k] xu[o*down - k],
 // xu = x upsampled by `up` (zeros between samples).  Optional |.| output.
+// The taps that meet a sample of x for output o are k = k0, k0 + up, ... with k0 = (o down) mod up, and they meet
+// x[j0], x[j0 - 1], ... (j0 = (o down - k0) / up): one division per output, none per tap.
+// STAGE: the workgroup's input window x[jlo .. jhi] (256 consecutive outputs: (255 down + ntaps) / up + 2 samples)
+// is staged in LDS with coalesced loads (upfirdn.cu:68-182 does the same with its shared-memory window); without it
+// every tap re-reads x from global memory.
+template <bool STAGE>
 __global__ __launch_bounds__(256) void k_upfirdn(const float2* __restrict__ x, int64_t n, const float* __restrict__ taps,
-                                                 int32_t ntaps, int32_t up, int32_t down, int64_t nout,
+                                                 int32_t ntaps, int32_t up, int32_t down, int64_t nout, int32_t span,
                                                  float2* __restrict__ out, float* __restrict__ out_abs) {
     extern __shared__ float s_tp[];
+    float2* s_x = reinterpret_cast<float2*>(s_tp + ((ntaps + 1) & ~1));
     for (int t = threadIdx.x; t < ntaps; t += 256) s_tp[t] = taps[t];
-    __syncthreads();
     const int64_t row = blockIdx.y;
     const float2* xr = x + row * n;
-    const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t o0 = (int64_t)blockIdx.x * 256;
+    // first sample any output of the workgroup can touch: floor((o0 down - (ntaps - 1)) / up), clipped below
+    const int64_t plo = o0 * down - (ntaps - 1);
+    const int64_t jlo = plo >= 0 ? plo / up : -((-plo + up - 1) / up);
+    if (STAGE) {
+        for (int i = threadIdx.x; i < span; i += 256) {
+            const int64_t j = jlo + i;
+            s_x[i] = (j >= 0 && j < n) ? xr[j] : make_float2(0.f, 0.f);
+        }
+    }
+    __syncthreads();
+    const int64_t o = o0 + threadIdx.x;
     if (o >= nout) return;
     const int64_t pos = o * down;  // index into the upsampled stream
-    // taps index k must satisfy (pos - k) % up == 0 and 0 <= (pos-k)/up < n
-    int64_t k = pos % up;
+    const int k0 = (int)(pos % up);
+    int64_t j = (pos - k0) / up;
     float ar = 0.f, ai = 0.f;
-    for (; k < ntaps; k += up) {
-        const int64_t j = (pos - k) / up;
-        if (pos - k < 0) break;
+    for (int k = k0; k < ntaps && j >= 0; k += up, --j) {
         if (j < n) {
             const float c = s_tp[k];
-            const float2 v = xr[j];
+            const float2 v = STAGE ? s_x[j - jlo] : xr[j];
             ar += c * v.x;
             ai += c * v.y;
         }
@@ -1341,8 +1356,16 @@ void launch_iq16_fir(const int16_t* iq, int64_t n, float scale, const float* tap
 
 void launch_upfirdn(const float2* x, int64_t rows, int64_t n, const float* taps, int32_t ntaps, int32_t up, int32_t down,
                     int64_t nout, float2* out, float* out_abs, hipStream_t st) {
-    hipLaunchKernelGGL(k_upfirdn, dim3(cdiv(nout, 256), (unsigned)rows), dim3(256), (size_t)ntaps * sizeof(float), st, x,
-                       n, taps, ntaps, up, down, nout, out, out_abs);
+    // input window of 256 consecutive outputs; staged in LDS when it fits beside the taps (<= 64 KB)
+    const int64_t span = (255 * (int64_t)down + ntaps - 1) / up + 3;
+    const size_t tap_bytes = (size_t)((ntaps + 1) & ~1) * sizeof(float);
+    if (tap_bytes + (size_t)span * sizeof(float2) <= 64 * 1024)
+        hipLaunchKernelGGL(k_upfirdn<true>, dim3(cdiv(nout, 256), (unsigned)rows), dim3(256),
+                           tap_bytes + (size_t)span * sizeof(float2), st, x, n, taps, ntaps, up, down, nout, (int32_t)span, out,
+                           out_abs);
+    else
+        hipLaunchKernelGGL(k_upfirdn<false>, dim3(cdiv(nout, 256), (unsigned)rows), dim3(256), tap_bytes, st, x, n, taps,
+                           ntaps, up, down, nout, 0, out, out_abs);
 }
 
 void launch_rows_mul_vec(const float2* x, int64_t in_pitch, int64_t in_off, const float2* v, int64_t len, float2* y,

@@ -141,8 +141,7 @@ def test_iq16_frontend_validation():
         Iq16FrontEnd(taps, 4, 4)
     with pytest.raises(TypeError):
         Iq16FrontEnd(asarray(np.ones(8, np.float64)))
-    with pytest.raises(MemoryError):
-        Iq16FrontEnd(taps, 17, 0)
+    Iq16FrontEnd(taps, 17, 0)  # (round 2: any decimation factor / tap count -- the overlap-save form takes over)
     fe = Iq16FrontEnd(taps, 2)
     with pytest.raises(TypeError):
         fe.run(asarray(np.zeros(10, np.float32)))
