@@ -234,6 +234,32 @@ CAF_EXPORT int32_t caf_find_local_maxima(const float* d_x, int64_t n, float min_
  * indexing d_trace[d_idx] of a cupy caller after cupyFindLocalMaxima, cupyExtensions.py:651-686) */
 CAF_EXPORT int32_t caf_gather_b32(const void* d_x, int64_t xlen, const int32_t* d_index, int64_t n, void* d_out,
                                   void* stream);
+/* ---- config C5 in one call: coarse CAF -> top-k local maxima -> chirp-Z fine zoom ------------------------------
+ * Replaces the reference's two-stage workflow of a coarse xcorr followed by a CZT over a narrow span at the delays of
+ * interest (benchmarks/benchmark_czts.py:31-82 with pbIppCZT32fc.runMany; cztXcorr xcorrRoutines.py:413-457;
+ * pybinds/ippGroupXcorrCZT/GroupXcorrCZT.cpp:202-329).  Input: the per-delay trace of ONE template of a finished
+ * caf_plan_execute (d_row_max / d_row_arg offset to that template, num_shifts entries starting at shift_start).
+ * On the device: local maxima above min_height (peakfinding.cu:52 predicate) -> the k strongest (value descending,
+ * delay ascending) -> per peak the normalised product row rx[d:d+N] * conj(template) -> |CZT|^2 on the grid
+ * nu0 - span ... nu0 + span in steps of `step` (all in cycles per sample; nu0 = the peak's coarse frequency).
+ * Every output is a caller-allocated DEVICE array with k entries (NULL to skip); unused entries have delay -1.
+ * d_count[0] = peaks returned (<= k), or -1 when more than 2^20 local maxima exceed min_height (raise it). */
+typedef struct caf_zoom_outputs {
+    int32_t* d_count;              /* [1] */
+    int32_t* d_delay;              /* [k] absolute delay index */
+    int32_t* d_coarse_freq_index;  /* [k] hypothesis index of the coarse maximum at that delay */
+    float* d_coarse_qf2;           /* [k] */
+    int32_t* d_fine_index;         /* [k] argmax on the fine grid (first index) */
+    double* d_fine_freq;           /* [k] its frequency, cycles per sample: nu0 - span + index * step */
+    float* d_fine_qf2;             /* [k] */
+    float* d_planes;               /* [k][num_bins] fine |CZT|^2 (num_bins from caf_zoom_num_bins) */
+} caf_zoom_outputs;
+CAF_EXPORT int32_t caf_zoom_num_bins(double span, double step, int32_t* num_bins);
+CAF_EXPORT int32_t caf_zoom_czt(caf_plan plan, int32_t template_index, const float* d_rx, int64_t rx_len,
+                                const float* d_row_max, const int32_t* d_row_arg, int64_t shift_start, int64_t num_shifts,
+                                int32_t k, float min_height, double span, double step, const caf_zoom_outputs* out,
+                                void* stream);
+
 /* filter_smtaps* (filter.cu:9-181) == scipy.signal.lfilter(taps, 1, x)[ds_phase::dsr] with carried-in history */
 CAF_EXPORT int32_t caf_fir_lfilter(const float* d_x, int64_t n, const float* d_taps, int32_t num_taps,
                                    const float* d_delay, int32_t delay_len, int32_t dsr, int32_t ds_phase, float* d_out,

@@ -84,6 +84,19 @@ class CafOutputs(ct.Structure):
     ]
 
 
+class CafZoomOutputs(ct.Structure):
+    _fields_ = [
+        ("d_count", ct.c_void_p),
+        ("d_delay", ct.c_void_p),
+        ("d_coarse_freq_index", ct.c_void_p),
+        ("d_coarse_qf2", ct.c_void_p),
+        ("d_fine_index", ct.c_void_p),
+        ("d_fine_freq", ct.c_void_p),
+        ("d_fine_qf2", ct.c_void_p),
+        ("d_planes", ct.c_void_p),
+    ]
+
+
 _P = ct.c_void_p
 _I32 = ct.c_int32
 _I64 = ct.c_int64
@@ -137,6 +150,9 @@ _SIGNATURES = {
     "caf_mul_conj": [_P, _P, _I64, _P, _P],
     "caf_steer_dot": [_P, _P, _I64, _I64, ct.c_double, _P, _P],
     "caf_sum_planes_qf2": [_P, _I32, _I64, _I32, _P, _I32, _P, ct.c_double, _P, _P],
+    "caf_zoom_num_bins": [ct.c_double, ct.c_double, ct.POINTER(_I32)],
+    "caf_zoom_czt": [_P, _I32, _P, _I64, _P, _P, _I64, _I64, _I32, ct.c_float, ct.c_double, ct.c_double,
+                     ct.POINTER(CafZoomOutputs), _P],
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -112,6 +112,26 @@ void launch_cutout_norm(const float2* x, int64_t n, double* out, hipStream_t st)
 // e^{+j 2 pi q / 16384}, q < 16384: the twiddle table of the in-LDS transforms (caf_ldsfft.h), built once per device
 int lds_fft_twiddles(int device, const float2** out);
 
+// what caf_zoom_czt needs from a plan (caf_plan.hip)
+struct PlanZoomView {
+    int T, N, F, G, device;
+    const float2* d_uconj;  // [T][N] conj(u): product row = rx[d + n] * d_uconj[n]
+    const double* d_nu;     // [F] coarse frequency per hypothesis index, cycles per sample
+    const float* d_tscale;  // [T] 1 / ||template||^2
+};
+int plan_zoom_view(caf_plan p, PlanZoomView* v);
+// caf_zoom.hip
+void launch_zoom_topk(const float* trace, const int32_t* cand, const int32_t* cand_count, int32_t max_cand, int32_t k,
+                      float* vals_scratch, int32_t* sel, int32_t* sel_count, hipStream_t st);
+void launch_zoom_rows(const float2* rx, const float2* uconj, int32_t n, const float* tscale_t, const int32_t* row_arg,
+                      const double* nu, const float2* aa, const int32_t* sel, const int32_t* sel_count, int32_t k,
+                      int64_t shift_start, int32_t nfft, float2* rows, hipStream_t st);
+void launch_zoom_finish(const float* trace, const int32_t* row_arg, const double* nu, const int32_t* sel,
+                        const int32_t* sel_count, int32_t k, int64_t shift_start, double span, double step,
+                        const uint32_t* fine_arg, const float* fine_max, int32_t cand_overflow_cap, const int32_t* cand_count,
+                        int32_t* o_count, int32_t* o_delay, int32_t* o_cidx, float* o_cqf2, int32_t* o_fidx, double* o_ffreq,
+                        float* o_fqf2, hipStream_t st);
+
 // caf_firos.hip: overlap-save FIR (fused in-LDS form for <= 8192 taps; gather / scatter kernels for the rocFFT rows)
 int fir_os_fused_block(int32_t ntaps);
 int launch_fir_os_fused(const float2* x, int64_t n, const float* taps, int32_t ntaps, const float2* delay, int32_t dlen,

@@ -3,6 +3,7 @@
 // gfx950 kernels of caf_rows.hip / caf_kernels.hip and batched rocFFT rows.
 #include <algorithm>
 #include <cmath>
+#include <complex>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -153,6 +154,99 @@ int fir_overlap_save(const void* x, int64_t n, bool is_iq16, float scale, const 
     // own stream is synchronised, because the next user of the block may sit on another stream.
     if (st != nullptr) CAF_HIP_TRY(hipStreamSynchronize(st));
     CAF_HIP_TRY(hipGetLastError());
+    return CAF_OK;
+}
+
+// ---- chirp-Z constants of the zoom, computed like CZTCached / IppCZT32fc (spectralRoutines.py:239-267,
+// CZT.cpp:89-140): float64 on the host, stored as complex64; W exponent = step (the labelled grid IS the evaluated
+// grid), nfft = next 7-smooth length >= m + k - 1.  Cached per (device, m, span, step).
+typedef std::complex<double> cd;
+void host_fft(std::vector<cd>& a) {  // in-place forward DFT, length with prime factors <= 7 (recursive mixed radix)
+    const size_t n = a.size();
+    if (n <= 1) return;
+    size_t p = 0;
+    for (size_t q : {2, 3, 5, 7})
+        if (n % q == 0) {
+            p = q;
+            break;
+        }
+    if (!p) {  // (not reached for 7-smooth lengths) plain DFT
+        std::vector<cd> o(n);
+        for (size_t k = 0; k < n; ++k) {
+            cd acc = 0;
+            for (size_t j = 0; j < n; ++j) acc += a[j] * std::polar(1.0, -2.0 * M_PI * (double)((j * k) % n) / (double)n);
+            o[k] = acc;
+        }
+        a.swap(o);
+        return;
+    }
+    const size_t m = n / p;
+    std::vector<std::vector<cd>> sub(p, std::vector<cd>(m));
+    for (size_t j = 0; j < n; ++j) sub[j % p][j / p] = a[j];
+    for (auto& v : sub) host_fft(v);
+    for (size_t k = 0; k < n; ++k) {
+        cd acc = 0;
+        for (size_t r = 0; r < p; ++r) acc += sub[r][k % m] * std::polar(1.0, -2.0 * M_PI * (double)((r * k) % n) / (double)n);
+        a[k] = acc;
+    }
+}
+int64_t next_fast_len7(int64_t n) {
+    for (;; ++n) {
+        int64_t v = n;
+        for (int q : {2, 3, 5, 7})
+            while (v % q == 0) v /= q;
+        if (v == 1) return n;
+    }
+}
+struct ZoomCzt {
+    int nfft = 0, k = 0;
+    float2 *aa = nullptr, *fv = nullptr, *wws = nullptr;  // device, never freed (a handful of small arrays per process)
+};
+std::mutex g_zoom_mu;
+std::map<std::tuple<int, int, double, double>, ZoomCzt> g_zoom_czt;
+
+int zoom_num_bins(double span, double step) { return (int)std::floor(2.0 * span / step + 1.0 + 1e-9); }
+
+int zoom_constants(int dev, int m, double span, double step, ZoomCzt* out) {
+    std::lock_guard<std::mutex> lk(g_zoom_mu);
+    const auto key = std::make_tuple(dev, m, span, step);
+    auto it = g_zoom_czt.find(key);
+    if (it != g_zoom_czt.end()) {
+        *out = it->second;
+        return CAF_OK;
+    }
+    ZoomCzt z;
+    z.k = zoom_num_bins(span, step);
+    z.nfft = (int)next_fast_len7((int64_t)m + z.k - 1);
+    const int k = z.k, nfft = z.nfft;
+    const int lo = -m + 1, hi = std::max(k - 1, m - 1);
+    std::vector<cd> ww(hi - lo + 1);
+    for (int i = lo; i <= hi; ++i) {
+        double cyc = step * ((double)i * (double)i / 2.0);
+        cyc -= std::floor(cyc);
+        ww[i - lo] = std::polar(1.0, -2.0 * M_PI * cyc);
+    }
+    std::vector<cd> fv(nfft, cd(0, 0));
+    for (int i = 0; i < k - 1 + m; ++i) fv[i] = 1.0 / ww[i];
+    host_fft(fv);
+    std::vector<std::complex<float>> aa(m), fvf(nfft), wws(k);
+    for (int n = 0; n < m; ++n) {
+        double cyc = span * (double)n;  // exp(-2 pi j f1 n) with f1 = -span
+        cyc -= std::floor(cyc);
+        const cd v = std::polar(1.0, 2.0 * M_PI * cyc) * ww[m - 1 + n];
+        aa[n] = std::complex<float>((float)v.real(), (float)v.imag());
+    }
+    for (int i = 0; i < nfft; ++i) fvf[i] = std::complex<float>((float)fv[i].real(), (float)fv[i].imag());
+    for (int i = 0; i < k; ++i) wws[i] = std::complex<float>((float)ww[m - 1 + i].real(), (float)ww[m - 1 + i].imag());
+    CAF_HIP_TRY(hipMalloc((void**)&z.aa, (size_t)m * 8));
+    CAF_HIP_TRY(hipMalloc((void**)&z.fv, (size_t)nfft * 8));
+    CAF_HIP_TRY(hipMalloc((void**)&z.wws, (size_t)k * 8));
+    CAF_HIP_TRY(hipMemcpy(z.aa, aa.data(), (size_t)m * 8, hipMemcpyHostToDevice));
+    CAF_HIP_TRY(hipMemcpy(z.fv, fvf.data(), (size_t)nfft * 8, hipMemcpyHostToDevice));
+    CAF_HIP_TRY(hipMemcpy(z.wws, wws.data(), (size_t)k * 8, hipMemcpyHostToDevice));
+    if (g_zoom_czt.size() > 64) g_zoom_czt.clear();  // (leaks a few hundred KB at worst; bounded)
+    g_zoom_czt[key] = z;
+    *out = z;
     return CAF_OK;
 }
 
@@ -520,6 +614,65 @@ int32_t caf_sum_planes_qf2(const float* d_planes, int32_t num_planes, int64_t ro
     CAF_REQUIRE(ynormsq > 0.0, "caf_sum_planes_qf2: ynormsq must be positive");
     launch_sum_planes_qf2((const float2*)d_planes, rows * cols, cols, h_sel, num_sel, d_row_norm, ynormsq, d_out,
                           (hipStream_t)stream);
+    CAF_HIP_TRY(hipGetLastError());
+    return CAF_OK;
+}
+
+int32_t caf_zoom_num_bins(double span, double step, int32_t* num_bins) {
+    CAF_REQUIRE(num_bins && span > 0.0 && step > 0.0 && span / step < 1e6, "caf_zoom_num_bins: bad span/step");
+    *num_bins = zoom_num_bins(span, step);
+    return CAF_OK;
+}
+
+int32_t caf_zoom_czt(caf_plan plan, int32_t template_index, const float* d_rx, int64_t rx_len, const float* d_row_max,
+                     const int32_t* d_row_arg, int64_t shift_start, int64_t num_shifts, int32_t k, float min_height,
+                     double span, double step, const caf_zoom_outputs* out, void* stream) {
+    CAF_REQUIRE(plan && d_rx && d_row_max && d_row_arg && out, "caf_zoom_czt: NULL argument");
+    PlanZoomView v;
+    int rc = plan_zoom_view(plan, &v);
+    if (rc) return rc;
+    CAF_REQUIRE(template_index >= 0 && template_index < v.T, "caf_zoom_czt: template_index outside the plan");
+    CAF_REQUIRE(v.G == 1, "caf_zoom_czt: composite (multi-group) templates are not supported");
+    CAF_REQUIRE(k >= 1 && k <= 4096, "caf_zoom_czt: need 1 <= k <= 4096");
+    CAF_REQUIRE(span > 0.0 && step > 0.0 && span / step < 1e5, "caf_zoom_czt: bad span/step");
+    CAF_REQUIRE(shift_start >= 0 && num_shifts >= 1 && shift_start + num_shifts - 1 + v.N <= rx_len,
+                "caf_zoom_czt: delays run past the end of rx");
+    CAF_REQUIRE(num_shifts < ((int64_t)1 << 31), "caf_zoom_czt: trace too long");
+    int cur = -1;
+    CAF_HIP_TRY(hipGetDevice(&cur));
+    CAF_REQUIRE(cur == v.device, "caf_zoom_czt: the plan was created on another device than the current one");
+    hipStream_t st = (hipStream_t)stream;
+    ZoomCzt z;
+    if ((rc = zoom_constants(v.device, v.N, span, step, &z))) return rc;
+    Scratch sc;
+    const int32_t max_cand = (int32_t)std::min<int64_t>(num_shifts, (int64_t)1 << 20);
+    int32_t *tiles = nullptr, *cand = nullptr, *cnt = nullptr, *sel = nullptr, *selcnt = nullptr;
+    float *vals = nullptr, *fmax = nullptr;
+    uint32_t* farg = nullptr;
+    float2 *rows = nullptr, *zk = nullptr;
+    if ((rc = sc.get(&tiles, local_maxima_scratch_ints(num_shifts))) || (rc = sc.get(&cand, max_cand)) ||
+        (rc = sc.get(&cnt, 1)) || (rc = sc.get(&sel, k)) || (rc = sc.get(&selcnt, 1)) || (rc = sc.get(&vals, max_cand)) ||
+        (rc = sc.get(&fmax, k)) || (rc = sc.get(&farg, k)) || (rc = sc.get(&rows, (int64_t)k * z.nfft)) ||
+        (rc = sc.get(&zk, (int64_t)k * z.k)))
+        return rc;
+    // 1. local maxima above min_height (peakfinding.cu:52 predicate), ascending index order, count on the device
+    launch_find_local_maxima(d_row_max, num_shifts, min_height, tiles, max_cand, cand, cnt, st);
+    // 2. the k strongest: value descending, index ascending
+    launch_zoom_topk(d_row_max, cand, cnt, max_cand, k, vals, sel, selcnt, st);
+    // 3. all product rows in one launch, already rotated, pre-chirped and padded
+    launch_zoom_rows((const float2*)d_rx, v.d_uconj + (int64_t)template_index * v.N, v.N, v.d_tscale + template_index, d_row_arg,
+                     v.d_nu, z.aa, sel, selcnt, k, shift_start, z.nfft, rows, st);
+    // 4. one batched Bluestein transform
+    if ((rc = fft_rows(rows, rows, k, z.nfft, false, st))) return rc;
+    launch_rows_mul_vec(rows, z.nfft, 0, z.fv, z.nfft, rows, z.nfft, z.nfft, k, 1.0f, st);
+    if ((rc = fft_rows(rows, rows, k, z.nfft, true, st))) return rc;
+    launch_rows_mul_vec(rows, z.nfft, v.N - 1, z.wws, z.k, zk, z.k, z.k, k, 1.0f / (float)z.nfft, st);
+    // 5. |.|^2, fine argmax (first index), optional planes
+    launch_rows_argmax(zk, k, z.k, 1, 1.0f, farg, fmax, out->d_planes, st);
+    launch_zoom_finish(d_row_max, d_row_arg, v.d_nu, sel, selcnt, k, shift_start, span, step, farg, fmax, max_cand, cnt,
+                       out->d_count, out->d_delay, out->d_coarse_freq_index, out->d_coarse_qf2, out->d_fine_index,
+                       out->d_fine_freq, out->d_fine_qf2, st);
+    if (st != nullptr) CAF_HIP_TRY(hipStreamSynchronize(st));  // scratch: see fir_overlap_save
     CAF_HIP_TRY(hipGetLastError());
     return CAF_OK;
 }

@@ -90,6 +90,8 @@ struct caf_plan_t {
     float* d_vt = nullptr;
     float2* d_tw1 = nullptr;
     float2* d_tw23 = nullptr;
+    float2* d_uconj = nullptr;  // conj(u) per template in the time domain (T x N): product rows of the zoom (caf_zoom_czt)
+    double* d_nu = nullptr;     // coarse frequency of hypothesis f in cycles per sample (F)
     FftPlan fwd, inv;
     hipStream_t s_aux = nullptr;  // sliding-energy pass beside gather + forward FFTs
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -162,7 +164,7 @@ struct caf_plan_t {
         s_aux = nullptr;
         ev_fork = ev_join = nullptr;
         void* ptrs[] = {d_hc,  d_shifts, d_tscale, d_gstart,  d_glen, d_tile_sums, d_prefix, d_inv_e,
-                        d_xb,  d_pbuf,   d_partial, d_vt,     d_params, d_pq};  // (d_tw1 / d_tw23 are shared, per device)
+                        d_xb,  d_pbuf,   d_partial, d_vt,     d_params, d_pq,     d_uconj, d_nu};  // (d_tw1 / d_tw23 are shared, per device)
         for (void* p : ptrs)
             if (p) (void)pool_free(p);
     }
@@ -209,6 +211,21 @@ static int ilog2_ceil(int64_t v) {
     while (((int64_t)1 << l) < v) ++l;
     return l;
 }
+
+namespace caf {
+int plan_zoom_view(caf_plan p, PlanZoomView* v) {
+    CAF_REQUIRE(p && v, "NULL plan");
+    v->T = p->T;
+    v->N = p->N;
+    v->F = p->F;
+    v->G = p->G;
+    v->device = p->device;
+    v->d_uconj = p->d_uconj;
+    v->d_nu = p->d_nu;
+    v->d_tscale = p->d_tscale;
+    return CAF_OK;
+}
+}  // namespace caf
 
 extern "C" {
 
@@ -533,6 +550,17 @@ static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
     if (!shifts.empty())
         CAF_HIP_TRY(hipMemcpy(p->d_shifts, shifts.data(), shifts.size() * 4, hipMemcpyHostToDevice));
     CAF_HIP_TRY(hipMemcpy(p->d_tscale, tscale.data(), (size_t)T * 4, hipMemcpyHostToDevice));
+    {   // what the zoom needs beside the coarse result: the time-domain multiplier of a product row,
+        // rx[d + n] * conj(u[n]), and the frequency each hypothesis index stands for
+        std::vector<std::complex<float>> uc((size_t)T * N);
+        for (size_t i = 0; i < uc.size(); ++i) uc[i] = d->auto_conj ? std::conj(tm[i]) : tm[i];
+        std::vector<double> nu(F);
+        for (int f = 0; f < F; ++f)
+            nu[f] = d->freq_mode == CAF_FREQ_BINS ? (double)d->h_bins[f] / (double)d->grid : d->h_freqs_norm[f];
+        if ((rc = p->alloc(&p->d_uconj, (int64_t)T * N)) || (rc = p->alloc(&p->d_nu, F))) return rc;
+        CAF_HIP_TRY(hipMemcpy(p->d_uconj, uc.data(), uc.size() * 8, hipMemcpyHostToDevice));
+        CAF_HIP_TRY(hipMemcpy(p->d_nu, nu.data(), nu.size() * 8, hipMemcpyHostToDevice));
+    }
     CAF_HIP_TRY(hipMemcpy(p->d_gstart, gs.data(), gs.size() * 4, hipMemcpyHostToDevice));
     CAF_HIP_TRY(hipMemcpy(p->d_glen, gl.data(), gl.size() * 4, hipMemcpyHostToDevice));
 

@@ -3,14 +3,13 @@
 Replaces the reference's two-stage workflow -- a coarse xcorr, then ``cztXcorr`` /
 ``pbIppGroupXcorrCZT`` over a narrow frequency span at the delays of interest
 (xcorrRoutines.py:413-457, benchmarks/benchmark_czts.py:31-82,
-benchmarks/benchmark_groupXcorrs.py:37-72) -- with device kernels end to end:
+benchmarks/benchmark_groupXcorrs.py:37-72) -- with ONE libcaf call, ``caf_zoom_czt`` (include/caf.h):
 
-  coarse per-delay trace (CAFPlan) -> local maxima (peakfinding.cu:52 predicate, ``caf_find_local_maxima``)
-  -> top-k (value descending, index ascending) -> normalised product row per peak
-  (``caf_sliding_multiply_normalised``) -> Bluestein CZT on a fine grid (``caf_czt_run_many``)
-  -> |.|^2 -> refined (frequency, QF^2).
+  coarse per-delay trace of a finished CAFPlan.run -> local maxima (peakfinding.cu:52 predicate) -> top-k on the
+  device (value descending, delay ascending) -> all normalised product rows in one launch -> one batched
+  Bluestein CZT on the fine grid -> |.|^2 -> refined (frequency, QF^2).
 
-Only the tiny peak list (<= maxNumPeaks indices) is ordered on the host.
+This module is a thin caller: it allocates the k-row result table, makes the call and reads the table back.
 """
 
 import ctypes as ct
@@ -18,14 +17,81 @@ import ctypes as ct
 import numpy as np
 
 from . import _lib
-from .cupyExtensions import (
+from .devarray import DeviceArray, asarray, empty, requireDeviceArray
+
+
+def zoom_num_bins(span, step):
+    """Number of fine-grid bins of a zoom over -span ... +span in steps of ``step`` (any common unit)."""
+    nb = ct.c_int32()
+    _lib.check(_lib.load().caf_zoom_num_bins(float(span), float(step), ct.byref(nb)), "caf_zoom_num_bins")
+    return nb.value
+
+
+def zoom_czt(plan, d_rx, plan_result, k=8, min_height=0.0, span=None, step=None, template=0, shift_start=0,
+             planes=False):
+    """``caf_zoom_czt`` on the trace of ``template`` in ``plan_result`` (a CAFPlan.run(..., rows=True) result of
+    ``plan`` over ``d_rx``).  ``span`` / ``step`` are in cycles per sample.  Returns a dict of host arrays with one
+    entry per peak found, best first: delay, coarse_index, coarse_qf2, fine_index, fine_freq (cycles per sample),
+    fine_qf2 (+ planes (npeaks, nbins) float32 if requested)."""
+    requireDeviceArray(d_rx)
+    if plan_result.row_max is None or plan_result.row_arg is None:
+        raise ValueError("the coarse result needs per-delay rows (run the plan with rows=True)")
+    T, S = plan_result.row_max.shape
+    if not (0 <= template < T):
+        raise ValueError("template index outside the coarse result")
+    k = int(k)
+    nb = zoom_num_bins(span, step)
+    cnt = empty(1, np.int32)
+    dly, cidx, fidx = empty(k, np.int32), empty(k, np.int32), empty(k, np.int32)
+    cq, fq = empty(k, np.float32), empty(k, np.float32)
+    ff = empty(k, np.float64)
+    pl = empty((k, nb), np.float32) if planes else None
+    o = _lib.CafZoomOutputs(cnt.ptr, dly.ptr, cidx.ptr, cq.ptr, fidx.ptr, ff.ptr, fq.ptr, pl.ptr if planes else None)
+    _lib.check(
+        _lib.load().caf_zoom_czt(plan._h, int(template), ct.c_void_p(d_rx.ptr), d_rx.size,
+                                 ct.c_void_p(plan_result.row_max.ptr + 4 * S * template),
+                                 ct.c_void_p(plan_result.row_arg.ptr + 4 * S * template), int(shift_start), S, k,
+                                 float(min_height), float(span), float(step), ct.byref(o), None),
+        "caf_zoom_czt",
+    )
+    n = int(cnt.get()[0])
+    if n < 0:
+        raise ValueError("more than 2^20 local maxima above min_height=%g; raise min_height" % min_height)
+    res = {"delay": dly.get()[:n].astype(np.int64), "coarse_index": cidx.get()[:n], "coarse_qf2": cq.get()[:n],
+           "fine_index": fidx.get()[:n], "fine_freq": ff.get()[:n], "fine_qf2": fq.get()[:n]}
+    if planes:
+        res["planes"] = pl.get()[:n]
+    return res
+
+
+def caf_with_zoom(plan, d_rx, plan_result, bins, grid, fs, k=8, min_height=None, span_bins=1.0, step_bins=1.0 / 64,
+                  template=0):
+    """Config-5 pipeline on an existing coarse result (``plan.run(d_rx, rows=True)``; on-grid bins ``bins``/``grid``).
+
+    Returns a list of dicts (delay, coarse_bin, coarse_qf2, fine_freq [Hz], fine_qf2), best first."""
+    if min_height is None:
+        min_height = 0.25 * float(plan_result.peak_val.get()[template]) if plan_result.peak_val is not None else 0.0
+    r = zoom_czt(plan, d_rx, plan_result, k=k, min_height=min_height, span=span_bins / float(grid),
+                 step=step_bins / float(grid), template=template)
+    cb = np.asarray(bins)[r["coarse_index"]]
+    return [
+        {"delay": int(d), "coarse_bin": int(b), "coarse_qf2": float(v), "fine_freq": float(f) * fs, "fine_qf2": float(q)}
+        for d, b, v, f, q in zip(r["delay"], cb, r["coarse_qf2"], r["fine_freq"], r["fine_qf2"])
+    ]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The same pipeline spelled out with the kernel-level wrappers (local maxima -> host ordering of the candidates ->
+# one product row per peak -> batched CZT).  NOT used by caf_with_zoom any more; kept because the tests cross-check
+# caf_zoom_czt's device top-k and batched rows against this independent chain.
+# ------------------------------------------------------------------------------------------------------------------
+from .cupyExtensions import (  # noqa: E402
     cupyArgmaxAbsRows_complex64,
     cupyComplexMagnSq,
     cupyFindLocalMaxima,
     multiplySlidesNormalised,
 )
-from .devarray import DeviceArray, asarray, empty, requireDeviceArray
-from .spectralRoutines import CZTCachedGPU
+from .spectralRoutines import CZTCachedGPU  # noqa: E402
 
 
 def gather(d_x, d_idx, n=None):
@@ -102,25 +168,4 @@ def czt_zoom(cutout, d_rx, delays, coarse_freqs, fs, span, step):
     return fine_f, fine_q, [pl[i] for i in range(npk)]
 
 
-def caf_with_zoom(cutout, d_rx, plan_result, bins, grid, fs, k=8, min_height=None, span_bins=1.0, step_bins=1.0 / 64):
-    """Config-5 pipeline on an existing coarse result (``CAFPlan.run(..., rows=True)`` of ONE template).
-
-    Returns a list of dicts (delay, coarse_bin, coarse_qf2, fine_freq, fine_qf2), best first."""
-    trace = plan_result.row_max[0]
-    args = plan_result.row_arg[0]
-    if min_height is None:
-        min_height = 0.25 * float(plan_result.peak_val.get()[0]) if plan_result.peak_val is not None else 0.0
-    delays, vals = topk_local_maxima(trace, k, min_height)
-    if delays.size == 0:
-        return []
-    a = gather(args, asarray(delays.astype(np.int32)))
-    cbins = np.asarray(bins)[a]
-    bin_hz = fs / float(grid)
-    ff, fq, _ = czt_zoom(cutout, d_rx, delays, cbins * bin_hz, fs, span_bins * bin_hz, step_bins * bin_hz)
-    return [
-        {"delay": int(d), "coarse_bin": int(b), "coarse_qf2": float(v), "fine_freq": float(f), "fine_qf2": float(q)}
-        for d, b, v, f, q in zip(delays, cbins, vals, ff, fq)
-    ]
-
-
-__all__ = ["topk_local_maxima", "czt_zoom", "caf_with_zoom", "DeviceArray"]
+__all__ = ["zoom_num_bins", "zoom_czt", "caf_with_zoom", "gather", "topk_local_maxima", "czt_zoom", "DeviceArray"]

@@ -36,7 +36,7 @@ for it in range(3):
     res = plan.run(d_rx, surface=False, rows=True, peak=True)
     sync()
     t1 = time.perf_counter()
-    out = caf_with_zoom(t, d_rx, res, bins, N, fs, k=8, span_bins=1.0, step_bins=1.0 / 64)
+    out = caf_with_zoom(plan, d_rx, res, bins, N, fs, k=8, span_bins=1.0, step_bins=1.0 / 64)
     t2 = time.perf_counter()
     print("coarse CAF %.2f ms, top-k + zoom %.2f ms" % ((t1 - t0) * 1e3, (t2 - t1) * 1e3), flush=True)
 found = sorted((o["delay"], round(o["fine_freq"], 3)) for o in out)

@@ -222,7 +222,7 @@ def test_c5_full_size_zoom(c2):
     from pydsproutines_amd.zoom import caf_with_zoom
 
     fs = float(N)  # bins are 1 Hz wide
-    out = caf_with_zoom(c2["t"], c2["d_rx"], c2["res"], c2["bins"], N, fs, k=3, span_bins=1.0, step_bins=1.0 / 32)
+    out = caf_with_zoom(c2["plan"], c2["d_rx"], c2["res"], c2["bins"], N, fs, k=3, span_bins=1.0, step_bins=1.0 / 32)
     # (default threshold: a quarter of the global peak -- only the planted signal stands above it)
     assert len(out) == 1 and out[0]["delay"] == D0 and out[0]["coarse_bin"] == K0
     assert out[0]["coarse_qf2"] == float(c2["res"].peak_val.get()[0])
@@ -231,7 +231,7 @@ def test_c5_full_size_zoom(c2):
     assert abs(ref[0].max() - out[0]["fine_qf2"]) <= 1e-4
     assert abs(fr[int(np.argmax(ref[0]))] - out[0]["fine_freq"]) <= 1e-9
     # a lower threshold admits noise maxima: still best first, the planted one on top
-    more = caf_with_zoom(c2["t"], c2["d_rx"], c2["res"], c2["bins"], N, fs, k=3, min_height=0.0045, span_bins=1.0,
+    more = caf_with_zoom(c2["plan"], c2["d_rx"], c2["res"], c2["bins"], N, fs, k=3, min_height=0.0045, span_bins=1.0,
                          step_bins=1.0 / 8)
     assert len(more) == 3 and more[0]["delay"] == D0
     assert more[0]["coarse_qf2"] >= more[1]["coarse_qf2"] >= more[2]["coarse_qf2"] > 0.0045

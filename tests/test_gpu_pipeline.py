@@ -54,7 +54,7 @@ def test_iq_file_to_refined_peaks(tmp_path):
     d_rx = asarray(rx)
     plan = CAFPlan(t, max_rx_len=rx.size, bins=bins, grid=n)
     res = plan.run(d_rx, surface=True, rows=True, peak=True)
-    out = caf_with_zoom(t, d_rx, res, bins, n, fs, k=2, span_bins=1.0, step_bins=1.0 / 32)
+    out = caf_with_zoom(plan, d_rx, res, bins, n, fs, k=2, span_bins=1.0, step_bins=1.0 / 32)
     # the FIR delays the signal by (64 - 1) / 2 input samples ~ 16 decimated samples
     gd = int(round((taps.size - 1) / 2 / dsr))
     for o, (d, f, _) in zip(sorted(out, key=lambda o: o["delay"]), planted):
