@@ -234,6 +234,26 @@ CAF_EXPORT int32_t caf_find_local_maxima(const float* d_x, int64_t n, float min_
  * indexing d_trace[d_idx] of a cupy caller after cupyFindLocalMaxima, cupyExtensions.py:651-686) */
 CAF_EXPORT int32_t caf_gather_b32(const void* d_x, int64_t xlen, const int32_t* d_index, int64_t n, void* d_out,
                                   void* stream);
+/* ---- multi-GPU step --------------------------------------------------------------------------------
+ * One process per GPU; templates are block-sharded over the ranks, rx is replicated, and the only exchange of the
+ * path is the all-gather of the per-template peak rows over RCCL / xGMI.  Rank 0 obtains a 128-byte id and hands it
+ * to the other ranks through any host channel (MPI, a file, torch.distributed's store); every rank then creates the
+ * communicator with its GPU current.  d_local = this rank's rows as [3][rows_per_rank] int32 (delays, frequency
+ * indices, float32 peak values as bits: the three d_peak_* arrays of caf_outputs laid end to end, shards padded to
+ * the largest); d_table = [world][3][rows_per_rank], identical on every rank.  The reference has no multi-GPU code;
+ * its nearest analogue is the thread-strided split of cython_ext/CyIppXcorrFFT/IppXcorrFFT.cpp:117. */
+typedef struct caf_comm_t* caf_comm;
+CAF_EXPORT int32_t caf_comm_unique_id(void* id128);
+CAF_EXPORT int32_t caf_comm_create(caf_comm* comm, int32_t world_size, int32_t rank, const void* id128);
+CAF_EXPORT int32_t caf_comm_destroy(caf_comm comm);
+CAF_EXPORT int32_t caf_peak_table_allgather(caf_comm comm, const int32_t* d_local, int32_t rows_per_rank,
+                                            int32_t* d_table, void* stream);
+
+/* d_out[i] = (double) d_x[d_index ? d_index[i] : i] (0 outside [0, xlen)): float32 per-delay traces into the float64
+ * device arrays the reference's GPU entry points return (GroupXcorrFFT.xcorrGPU xc = cp.zeros(shifts.size),
+ * xcorrRoutines.py:1198-1203; cp_fastXcorr's d_result, :95-101) with no host round trip */
+CAF_EXPORT int32_t caf_gather_f32_f64(const float* d_x, int64_t xlen, const int32_t* d_index, int64_t n, double* d_out,
+                                      void* stream);
 /* ---- config C5 in one call: coarse CAF -> top-k local maxima -> chirp-Z fine zoom ------------------------------
  * Replaces the reference's two-stage workflow of a coarse xcorr followed by a CZT over a narrow span at the delays of
  * interest (benchmarks/benchmark_czts.py:31-82 with pbIppCZT32fc.runMany; cztXcorr xcorrRoutines.py:413-457;

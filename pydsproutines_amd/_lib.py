@@ -138,6 +138,7 @@ _SIGNATURES = {
     "caf_copy_groups": [_P, _P, _P, _P, _P, _I32, _P],
     "caf_find_local_maxima": [_P, _I64, ct.c_float, _I32, _P, _P, _P],
     "caf_gather_b32": [_P, _I64, _P, _I64, _P, _P],
+    "caf_gather_f32_f64": [_P, _I64, _P, _I64, _P, _P],
     "caf_fir_lfilter": [_P, _I64, _P, _I32, _P, _I32, _I32, _I32, _P, _I64, _P],
     "caf_upfirdn": [_P, _I64, _I64, _P, _I32, _I32, _I32, _P, _P, _I64, _P],
     "caf_czt_run_many": [_P, _I64, _I32, _I32, _I32, _P, _P, _P, _P, _P],
@@ -150,6 +151,10 @@ _SIGNATURES = {
     "caf_mul_conj": [_P, _P, _I64, _P, _P],
     "caf_steer_dot": [_P, _P, _I64, _I64, ct.c_double, _P, _P],
     "caf_sum_planes_qf2": [_P, _I32, _I64, _I32, _P, _I32, _P, ct.c_double, _P, _P],
+    "caf_comm_unique_id": [_P],
+    "caf_comm_create": [ct.POINTER(_P), _I32, _I32, _P],
+    "caf_comm_destroy": [_P],
+    "caf_peak_table_allgather": [_P, _P, _I32, _P, _P],
     "caf_zoom_num_bins": [ct.c_double, ct.c_double, ct.POINTER(_I32)],
     "caf_zoom_czt": [_P, _I32, _P, _I64, _P, _P, _I64, _I64, _I32, ct.c_float, ct.c_double, ct.c_double,
                      ct.POINTER(CafZoomOutputs), _P],

@@ -86,6 +86,7 @@ int64_t local_maxima_scratch_ints(int64_t n);
 void launch_find_local_maxima(const float* x, int64_t n, float min_height, int32_t* tile_scratch, int32_t max_out,
                               int32_t* idx, int32_t* count, hipStream_t st);
 void launch_gather_b32(const void* x, int64_t xlen, const int32_t* idx, int64_t n, void* out, hipStream_t st);
+void launch_gather_f32_f64(const float* x, int64_t xlen, const int32_t* idx, int64_t n, double* out, hipStream_t st);
 void launch_fir(const float2* x, int64_t n, const float* taps, int32_t ntaps, const float2* delay, int32_t dlen,
                 int32_t dsr, int32_t phase, float2* out, int64_t nout, hipStream_t st);
 bool fir_decim_ok(int32_t ntaps, int32_t dsr);

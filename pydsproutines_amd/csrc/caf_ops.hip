@@ -472,6 +472,13 @@ int32_t caf_gather_b32(const void* d_x, int64_t xlen, const int32_t* d_index, in
     return CAF_OK;
 }
 
+int32_t caf_gather_f32_f64(const float* d_x, int64_t xlen, const int32_t* d_index, int64_t n, double* d_out, void* stream) {
+    CAF_REQUIRE(d_x && d_out && xlen >= 1 && n >= 0, "caf_gather_f32_f64: bad arguments");
+    launch_gather_f32_f64(d_x, xlen, d_index, n, d_out, (hipStream_t)stream);
+    CAF_HIP_TRY(hipGetLastError());
+    return CAF_OK;
+}
+
 int32_t caf_fir_lfilter(const float* d_x, int64_t n, const float* d_taps, int32_t num_taps, const float* d_delay,
                         int32_t delay_len, int32_t dsr, int32_t ds_phase, float* d_out, int64_t out_len, void* stream) {
     CAF_REQUIRE(d_x && d_taps && d_out && n >= 1 && num_taps >= 1, "caf_fir_lfilter: bad arguments");

@@ -614,6 +614,17 @@ __global__ __launch_bounds__(256) void k_gather_b32(const uint32_t* __restrict__
     out[i] = (j >= 0 && j < xlen) ? x[j] : 0u;
 }
 
+// out[i] = (double) x[idx ? idx[i] : i]: float32 traces into the float64 device arrays the reference's GPU entry
+// points return (xc = cp.zeros(shifts.size), xcorrRoutines.py:1198-1203) without a host round trip
+__global__ __launch_bounds__(256) void k_gather_f32_f64(const float* __restrict__ x, int64_t xlen,
+                                                        const int32_t* __restrict__ idx, int64_t n,
+                                                        double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t j = idx ? (int64_t)idx[i] : i;
+    out[i] = (j >= 0 && j < xlen) ? (double)x[j] : 0.0;
+}
+
 // ---------------------------------------------------------------------------------------
 // FIR == scipy.signal.lfilter(taps, 1, x) on complex64 with real float32 taps, optional carried-in
 // history (`delay` = the dlen samples preceding x) and decimation out[k] = y[k*dsr + phase].
@@ -1290,6 +1301,10 @@ void launch_gather_b32(const void* x, int64_t xlen, const int32_t* idx, int64_t 
     if (n > 0)
         hipLaunchKernelGGL(k_gather_b32, dim3(cdiv(n, 256)), dim3(256), 0, st, (const uint32_t*)x, xlen, idx, n,
                            (uint32_t*)out);
+}
+
+void launch_gather_f32_f64(const float* x, int64_t xlen, const int32_t* idx, int64_t n, double* out, hipStream_t st) {
+    if (n > 0) hipLaunchKernelGGL(k_gather_f32_f64, dim3(cdiv(n, 256)), dim3(256), 0, st, x, xlen, idx, n, out);
 }
 
 int moving_tile_max_window() { return MAT_MAXL; }

@@ -31,7 +31,7 @@ from .cupyExtensions import (  # noqa: F401  (re-exported like `from cupyExtensi
     multiplySlidesNormalised,
     multiTemplateSlidingDotProduct,
 )
-from .devarray import DeviceArray, asarray, empty, requireDeviceArray, requireDtype
+from .devarray import DeviceArray, asarray, empty, requireDeviceArray, requireDtype, zeros
 from .filterRoutines import cupyMovingAverage  # noqa: F401
 from .signalCreationRoutines import makeFreq
 from .spectralRoutines import CZTCached, CZTCachedGPU, next_fast_len  # noqa: F401
@@ -66,8 +66,9 @@ def _runs(shifts):
     return out
 
 
-def _perdelay(d_cut, n, d_rx, rx_len, start, step, num, zero_oor, want_qf2, want_idx, want_caf, want_ccaf):
-    """One caf_xcorr_perdelay call; returns host arrays."""
+def _perdelay(d_cut, n, d_rx, rx_len, start, step, num, zero_oor, want_qf2, want_idx, want_caf, want_ccaf,
+              device_out=False):
+    """One caf_xcorr_perdelay call; returns host arrays (DeviceArrays with ``device_out``)."""
     lib = _lib.load()
     qf2 = empty(num, np.float32) if want_qf2 else None
     idx = empty(num, np.int32) if want_idx else None
@@ -79,6 +80,8 @@ def _perdelay(d_cut, n, d_rx, rx_len, start, step, num, zero_oor, want_qf2, want
                                p(qf2), p(idx), p(caf), p(ccaf), 0, None),
         "caf_xcorr_perdelay",
     )
+    if device_out:
+        return qf2, idx, caf, ccaf
     g = lambda a: a.get() if a is not None else None  # noqa: E731
     return g(qf2), g(idx), g(caf), g(ccaf)
 
@@ -87,6 +90,38 @@ def _engine_range(shifts):
     s = np.asarray(shifts, dtype=np.int64)
     lo, hi = int(s.min()), int(s.max())
     return lo, hi - lo + 1, s - lo
+
+
+def _dev_index(rel, n):
+    """None when ``rel`` selects 0..n-1 in order (no gather needed), else the int32 index array on the device."""
+    rel = np.asarray(rel)
+    if rel.size == n and (n == 0 or (rel[0] == 0 and rel[-1] == n - 1 and np.all(np.diff(rel) == 1))):
+        return None
+    return asarray(rel.astype(np.int32))
+
+
+def _take_f64(d_f32, rel, out=None):
+    """float64 device array of d_f32[rel] (d_f32: 1-D float32 DeviceArray), on the device."""
+    rel = np.asarray(rel)
+    out = empty(rel.size, np.float64) if out is None else out
+    d_idx = _dev_index(rel, d_f32.size)
+    _lib.check(_lib.load().caf_gather_f32_f64(ct.c_void_p(d_f32.ptr), d_f32.size, ct.c_void_p(d_idx.ptr) if d_idx is not None
+                                              else None, rel.size, ct.c_void_p(out.ptr), None), "caf_gather_f32_f64")
+    return out
+
+
+def _take_u32(d_i32, rel, out=None):
+    """uint32 device array of d_i32[rel] (non-negative int32 values: same bits), on the device."""
+    rel = np.asarray(rel)
+    out = empty(rel.size, np.uint32) if out is None else out
+    d_idx = _dev_index(rel, d_i32.size)
+    lib = _lib.load()
+    if d_idx is None:
+        _lib.check(lib.caf_d2d(ct.c_void_p(out.ptr), ct.c_void_p(d_i32.ptr), 4 * rel.size, None), "caf_d2d")
+    else:
+        _lib.check(lib.caf_gather_b32(ct.c_void_p(d_i32.ptr), d_i32.size, ct.c_void_p(d_idx.ptr), rel.size,
+                                      ct.c_void_p(out.ptr), None), "caf_gather_b32")
+    return out
 
 
 # ------------------------------------------------------------------------------------------
@@ -208,10 +243,10 @@ class _GroupEngine:
         return self._plan
 
     def _run(self, rx, shifts, **kw):
-        rx = np.asarray(rx)
-        plan = self._get_plan(len(rx))
+        d_rx = rx if isinstance(rx, DeviceArray) else asarray(_c64(np.asarray(rx)))  # device input stays where it is
+        plan = self._get_plan(d_rx.size)
         lo, cnt, rel = _engine_range(shifts)
-        res = plan.run(asarray(_c64(rx)), shift_start=lo, num_shifts=cnt, **kw)
+        res = plan.run(d_rx, shift_start=lo, num_shifts=cnt, **kw)
         return res, rel
 
 
@@ -309,13 +344,16 @@ class GroupXcorrFFT(_GroupEngine):
     def _default_shifts(self, n):
         return np.arange(n - (self.starts[-1] + self.fftlen) + 1)
 
-    def xcorr(self, rx, shifts=None, flattenToTime=True):
-        rx = rx.get() if isinstance(rx, DeviceArray) else np.asarray(rx)
+    def _shifts_for(self, rx, shifts):
         if shifts is None:
-            shifts = self._default_shifts(len(rx))
-        else:
-            shifts = np.asarray(shifts)
-            assert shifts[-1] + self.starts[-1] + self.fftlen < rx.size
+            return self._default_shifts(rx.size)
+        shifts = np.asarray(shifts)
+        assert shifts[-1] + self.starts[-1] + self.fftlen < rx.size
+        return shifts
+
+    def xcorr(self, rx, shifts=None, flattenToTime=True):
+        rx = rx if isinstance(rx, DeviceArray) else np.asarray(rx)
+        shifts = self._shifts_for(rx, shifts)
         if flattenToTime:
             res, rel = self._run(rx, shifts + self._first, rows=True, peak=False)
             return res.row_max.get()[0][rel].astype(np.float64), res.row_arg.get()[0][rel].astype(np.uint32)
@@ -326,11 +364,20 @@ class GroupXcorrFFT(_GroupEngine):
         return self.xcorr(rx, shifts, flattenToTime=False)
 
     def xcorrGPU(self, rx, shifts=None, flattenToTime=True):
+        """ref: xcorrRoutines.py:1191-1262: device rx in, device results out -- (float64[S], uint32[S]) or
+        float64[S, fftlen] -- and nothing crosses PCIe but the shift list."""
         requireDeviceArray(rx)
-        out = self.xcorr(rx, shifts, flattenToTime)
+        shifts = self._shifts_for(rx, shifts)
         if flattenToTime:
-            return asarray(out[0]), asarray(out[1])
-        return asarray(out)
+            res, rel = self._run(rx, shifts + self._first, rows=True, peak=False)
+            return _take_f64(res.row_max[0], rel), _take_u32(res.row_arg[0], rel)
+        res, rel = self._run(rx, shifts + self._first, surface=True, rows=False, peak=False)
+        S, F = res.surface.shape[1], res.surface.shape[2]
+        # rows rel of the (S, F) float32 surface as float64: flat element indices (identity when rel is 0..S-1)
+        rel = np.asarray(rel)
+        contiguous = rel.size == S and _dev_index(rel, S) is None
+        flat = np.arange(S * F) if contiguous else (rel[:, None] * F + np.arange(F)[None, :]).reshape(-1)
+        return _take_f64(res.surface.reshape(S * F), flat).reshape(rel.size, F)
 
 
 # ------------------------------------------------------------------------------------------
@@ -407,14 +454,23 @@ def cp_fastXcorr(cutout, rx, freqsearch=True, outputCAF=False, shifts=None, absR
         return None
     shifts = np.asarray(shifts)
     d_cut = asarray(_c64(cutout).conj())
+    if not copyToCpu:
+        # results stay on the device (float64 / uint32 like the reference's d_result / d_freqlist): every run of
+        # shifts writes its slice of the two output arrays
+        d_out, d_fidx = empty(len(shifts), np.float64), empty(len(shifts), np.uint32)
+        for off, start, step, count in _runs(shifts):
+            q, fi, _, _ = _perdelay(d_cut, n, d_rx, d_rx.size, start, step, count, False, True, True, False, False,
+                                    device_out=True)
+            ident = np.arange(count)
+            _take_f64(q, ident, out=d_out[off : off + count])
+            _take_u32(fi, ident, out=d_fidx[off : off + count])
+        return d_out, d_fidx
     out = np.zeros(len(shifts), np.float64)
     fidx = np.zeros(len(shifts), np.uint32)
     for off, start, step, count in _runs(shifts):
         q, fi, _, _ = _perdelay(d_cut, n, d_rx, d_rx.size, start, step, count, False, True, True, False, False)
         out[off : off + count], fidx[off : off + count] = q, fi.astype(np.uint32)
-    if copyToCpu:
-        return out, fidx
-    return asarray(out), asarray(fidx)
+    return out, fidx
 
 
 def cp_fastXcorr_v2(cutout, rx, startIdx=0, idxlen=None, THREADS_PER_BLOCK=32, numSlidesPerBlk=None, cztObj=None,
@@ -757,20 +813,41 @@ class GroupXcorrCZT_Permutations:
             c._d_wws = asarray((c._ww64[c.m - 1 : c.m + c.k - 1] * ph).astype(np.complex64))
             czts.append(c)
         k = czts[0].k
-        # sliding energy of rx once: E[d] = sum |rx[d : d+L]|^2 (causal moving sum, so E[d] = msum[d + L - 1])
-        msum = cupyMovingAverage(cupyComplexMagnSq(d_rx, np.float32), L, sumInstead=True).get().astype(np.float64)
-        self._rxgroupNormSq = np.stack([msum[shifts + int(self.groupStarts[g]) + L - 1] for g in range(G)])
-        self.d_rxgroupNormSq = asarray(self._rxgroupNormSq.astype(np.float32))
+        # sliding energy of rx once, on the device: E[d] = sum |rx[d : d+L]|^2 (causal moving sum, so
+        # E[d] = msum[d + L - 1]); the (G, S) energies of the wanted shifts are gathered there too -- only the
+        # per-group start indices (S int32 each) are uploaded, nothing of rx's length comes back
+        d_msum = cupyMovingAverage(cupyComplexMagnSq(d_rx, np.float32), L, sumInstead=True)
+        lib = _lib.load()
+        self.d_rxgroupNormSq = empty((G, S), np.float32)
+        d_starts = []
+        for g in range(G):
+            d_starts.append(asarray((shifts + int(self.groupStarts[g])).astype(np.int32)))
+            d_e = asarray((shifts + int(self.groupStarts[g]) + L - 1).astype(np.int32))
+            _lib.check(lib.caf_gather_b32(ct.c_void_p(d_msum.ptr), d_msum.size, ct.c_void_p(d_e.ptr), S,
+                                          ct.c_void_p(self.d_rxgroupNormSq[g].ptr), None), "caf_gather_b32")
+        self._rxgroupNormSq_host = None  # (G, S) float64 host copy, read back on first use
         self.d_xcTemplates = empty((T, S, k), np.complex64)
         d_len = asarray(np.full(S, L, np.int32))
+        d_row0 = zeros(S, np.int32)  # every slice multiplies row 0 of the one-template view passed below
+        d_mul = empty((S, L), np.complex64)
         for t in range(T):
             g = int(self.ygroupIdxs[t])
-            d_starts = asarray((shifts + int(self.groupStarts[g])).astype(np.int32))
-            d_rowidx = asarray(np.full(S, t, np.int32))
-            d_mul = multiplySlicesOptimistically(d_rx, self._d_ygroups, d_starts, d_len, d_rowidx)
+            # multiplySlicesOptimistically (cupyExtensions.py:405-488) without its per-call host check of the slice
+            # lengths: they are all L by construction
+            _lib.check(lib.caf_multiply_slices_indexed_rows(ct.c_void_p(d_rx.ptr), d_rx.size,
+                                                            ct.c_void_p(self._d_ygroups[t].ptr), 1, L,
+                                                            ct.c_void_p(d_starts[g].ptr), ct.c_void_p(d_len.ptr),
+                                                            ct.c_void_p(d_row0.ptr), L, S, ct.c_void_p(d_mul.ptr), None),
+                       "caf_multiply_slices_indexed_rows")
             czts[g].runMany(d_mul, out=self.d_xcTemplates[t])
         self._shape = (S, k)
         return cztFreq
+
+    @property
+    def _rxgroupNormSq(self):
+        if self._rxgroupNormSq_host is None:
+            self._rxgroupNormSq_host = self.d_rxgroupNormSq.get().astype(np.float64)
+        return self._rxgroupNormSq_host
 
     def _check_shifts(self, n, shifts):
         if shifts is None:

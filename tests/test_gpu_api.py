@@ -185,6 +185,60 @@ def test_groupxcorr_family(golden):
         CyGroupXcorrFFT(g["yg"], g["st2"].astype(np.int32), int(fs), 64)
 
 
+def test_device_signatures_stay_on_the_device(golden, monkeypatch):
+    """GroupXcorrFFT.xcorrGPU, cp_fastXcorr(copyToCpu=False) and GroupXcorrCZT_Permutations.xcorrGPU take device arrays
+    and hand back device arrays (xcorrRoutines.py:1191-1262, :95-101, :1264-1690): results equal the host-signature
+    calls, dtypes are the reference's, and nothing of rx's size is copied to the host on the way (every DeviceArray.get
+    during the calls is counted)."""
+    from pydsproutines_amd import asarray
+    from pydsproutines_amd.devarray import DeviceArray
+    from pydsproutines_amd.xcorrRoutines import GroupXcorrCZT_Permutations, GroupXcorrFFT, cp_fastXcorr
+
+    pulled = []
+    real_get = DeviceArray.get
+    monkeypatch.setattr(DeviceArray, "get", lambda self: (pulled.append(self.nbytes), real_get(self))[1])
+
+    g = golden("groupxcorr_small")
+    fs, fftlen = float(g["fs"][0]), int(g["fftlen"][0])
+    of = GroupXcorrFFT(g["yg"], g["st2"], fs, fftlen=fftlen)
+    d_rx2 = asarray(g["rx2"].astype(np.complex64))
+    want_x, want_f = of.xcorr(g["rx2"], g["sh2"])
+    want_full = of.xcorr(g["rx2"], g["sh2"], flattenToTime=False)
+    pulled.clear()
+    dx, df = of.xcorrGPU(d_rx2, g["sh2"])
+    dfull = of.xcorrGPU(d_rx2, g["sh2"], flattenToTime=False)
+    sub = g["sh2"][::3]  # a strided selection goes through the device gather
+    dxs, dfs = of.xcorrGPU(d_rx2, sub)
+    assert pulled == []                                   # nothing came back during the device calls
+    assert isinstance(dx, DeviceArray) and dx.dtype == np.float64 and df.dtype == np.uint32 and dfull.dtype == np.float64
+    np.testing.assert_array_equal(dx.get(), want_x)
+    np.testing.assert_array_equal(df.get(), want_f)
+    np.testing.assert_array_equal(dfull.get(), want_full)
+    np.testing.assert_array_equal(dxs.get(), want_x[::3])
+    np.testing.assert_array_equal(dfs.get(), want_f[::3])
+
+    rng = np.random.default_rng(3)
+    rx = cn(rng, 5000)
+    cut = rx[700:956].copy()
+    sh = np.concatenate((np.arange(600, 800), np.arange(900, 1500, 5)))
+    hq, hf = cp_fastXcorr(cut, asarray(rx), shifts=sh)
+    pulled.clear()
+    dq, dfi = cp_fastXcorr(cut, asarray(rx), shifts=sh, copyToCpu=False)
+    assert pulled == []
+    assert dq.dtype == np.float64 and dfi.dtype == np.uint32
+    np.testing.assert_array_equal(dq.get(), hq)
+    np.testing.assert_array_equal(dfi.get(), hf)
+    assert int(sh[np.argmax(hq)]) == 700
+
+    p = golden("perm_small")
+    f1, f2, bw = (float(v) for v in p["f1f2bw"])
+    obj = GroupXcorrCZT_Permutations(p["ygroups"], p["ygroupIdxs"], p["groupStarts"], f1, f2, bw, float(p["fs"][0]))
+    d_prx = asarray(p["rx"].astype(np.complex64))
+    pulled.clear()
+    obj.xcorrGPU(d_prx, p["shifts"])
+    assert max(pulled, default=0) <= 4 * p["shifts"].size   # at most shift-sized bookkeeping, never an rx-sized array
+
+
 def test_kat1_groupxcorrczt_and_pybind_twin(golden):
     from pydsproutines_amd.xcorrRoutines import GroupXcorrCZT, pbIppGroupXcorrCZT
 
@@ -729,3 +783,25 @@ def test_argmax3d_uint32():
         cupyArgmax3d_uint32(asarray(x.astype(np.int32)))
     with pytest.raises(ValueError):
         cupyArgmax3d_uint32(asarray(x[0]))
+
+
+def test_c_abi_peak_table_allgather_world_of_one():
+    """The RCCL all-gather of the peak table behind the C-ABI (caf_comm_*): on the one GPU of this box a world of one
+    rank -- communicator from a unique id, gather == copy of the [3][rows] block.  (Two or more ranks need as many
+    GPUs: not runnable here; the Python path of the same exchange is covered over gloo in test_sharding_gloo.py.)"""
+    import ctypes as ct
+
+    from pydsproutines_amd import _lib, asarray
+    from pydsproutines_amd.devarray import empty
+
+    lib = _lib.load()
+    uid = (ct.c_ubyte * 128)()
+    _lib.check(lib.caf_comm_unique_id(uid), "caf_comm_unique_id")
+    comm = ct.c_void_p()
+    _lib.check(lib.caf_comm_create(ct.byref(comm), 1, 0, uid), "caf_comm_create")
+    rows = np.stack((np.arange(5) * 1000, np.arange(5) - 2, np.linspace(0.1, 0.9, 5).astype(np.float32).view(np.int32))).astype(np.int32)
+    d_loc, d_tab = asarray(rows), empty((1, 3, 5), np.int32)
+    _lib.check(lib.caf_peak_table_allgather(comm, ct.c_void_p(d_loc.ptr), 5, ct.c_void_p(d_tab.ptr), None))
+    _lib.check(lib.caf_stream_sync(None))
+    np.testing.assert_array_equal(d_tab.get()[0], rows)
+    _lib.check(lib.caf_comm_destroy(comm))
