@@ -63,6 +63,10 @@ CAF_EXPORT int32_t caf_h2d(void* d_dst, const void* h_src, int64_t bytes, void* 
 CAF_EXPORT int32_t caf_d2h(void* h_dst, const void* d_src, int64_t bytes, void* stream);
 CAF_EXPORT int32_t caf_d2d(void* d_dst, const void* d_src, int64_t bytes, void* stream);
 CAF_EXPORT int32_t caf_stream_sync(void* stream);
+/* a non-blocking HIP stream of the current device for the `stream` arguments below (cupy.cuda.Stream(non_blocking=True)
+ * of a cupy caller); NULL = the default stream everywhere */
+CAF_EXPORT int32_t caf_stream_create(void** stream);
+CAF_EXPORT int32_t caf_stream_destroy(void* stream);
 
 /* ---- the hypothesis engine (frequency-domain overlap-save CAF) -----------------------
  *
@@ -155,6 +159,10 @@ typedef struct caf_outputs {
 CAF_EXPORT int32_t caf_plan_execute(caf_plan plan, const float* d_rx, int64_t rx_len, int64_t shift_start,
                                     int64_t num_shifts, const caf_outputs* out, void* stream);
 
+/* Diagnostic of the one-launch (persistent) engine: marks[0..1] = the watchdog words of the work-queue block. Both
+ * are 0 unless a tile item waited ~10 s for its block to be published -- which the protocol rules out (the launch
+ * then traps) -- so a non-zero value after a successful run means a broken hand-off.  Synchronises the device. */
+CAF_EXPORT int32_t caf_plan_watchdog(caf_plan plan, int32_t* marks);
 /* Per-kernel device timing with HIP events recorded on the execute stream (used by bench.py
  * for the roofline figure).  enable=1 starts collecting; get() synchronises the recorded events
  * and returns accumulated milliseconds and launch counts since enable, per stage:

@@ -117,11 +117,14 @@ _SIGNATURES = {
     "caf_d2h": [_P, _P, _I64, _P],
     "caf_d2d": [_P, _P, _I64, _P],
     "caf_stream_sync": [_P],
+    "caf_stream_create": [ct.POINTER(_P)],
+    "caf_stream_destroy": [_P],
     "caf_plan_create": [ct.POINTER(_P), ct.POINTER(CafPlanDesc)],
     "caf_plan_destroy": [_P],
     "caf_plan_info": [_P, ct.POINTER(_I32), ct.POINTER(_I32), ct.POINTER(_I32), ct.POINTER(_I64)],
     "caf_plan_engine": [_P, ct.POINTER(_I32)],
     "caf_plan_execute": [_P, _P, _I64, _I64, _I64, ct.POINTER(CafOutputs), _P],
+    "caf_plan_watchdog": [_P, ct.POINTER(_I32)],
     "caf_plan_profile": [_P, _I32],
     "caf_plan_profile_get": [_P, ct.POINTER(ct.c_double), ct.POINTER(_I64)],
     "caf_plan_execute_host": [_P, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P],

@@ -183,6 +183,12 @@ class CAFPlan:
         return {"surface": surf, "row_max": rmax, "row_arg": rarg, "peak_val": pv, "peak_delay": pd, "peak_freq": pf}
 
     # ------------------------------------------------------------------------------------
+    def watchdog(self):
+        """(mark, fft_next) of the persistent engine's polling watchdog: (0, 0) unless its hand-off protocol broke."""
+        m = (ct.c_int32 * 2)()
+        _lib.check(_lib.load().caf_plan_watchdog(self._h, m), "caf_plan_watchdog")
+        return int(m[0]), int(m[1])
+
     def profile(self, enable=True):
         _lib.check(_lib.load().caf_plan_profile(self._h, 1 if enable else 0))
 

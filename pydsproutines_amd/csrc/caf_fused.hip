@@ -536,6 +536,30 @@ __device__ __forceinline__ Tp* uniform_ptr(Tp* p) {
 // all 128 VGPRs; allocated together with the other role it reloads spilled values every hypothesis), and the
 // arguments live in device memory (PersistParams), read with scalar loads at the start of each item.
 // ----------------------------------------------------------------------------------------
+// What the publish / consume pair below relies on (measured on gfx950 / ROCm 7.2: MI355X_MICROARCH.md, "Workgroup
+// dispatch, XCD placement & inter-workgroup visibility", valid forms + the table of measured hand-offs; NOT
+// guarantees of the HSA memory model -- which is why tests/test_gpu_persistent_protocol.py runs the residency
+// matrix in every suite run):
+//   producer (persistent_fft_item):
+//     P1 every |y|^2 / (value, hypothesis) store of the item is an sc1 (write-through) store: the bytes leave the
+//        XCD's L2 towards memory instead of staying dirty in it (gst1_wt / __hip_atomic_store relaxed, agent scope);
+//     P2 each storing wave executes s_waitcnt vmcnt(0) after its stores (the workgroup-scope release fence lowers
+//        to exactly that): vmcnt is decremented for an sc1 store only when the write has been acknowledged by the
+//        memory side, so after the wait the wave's bytes are visible to every XCD;
+//     P3 the workgroup barrier that follows orders ALL waves' waits before the one lane that signals;
+//     P4 that lane's agent-scope atomic add on done[block] executes at the memory side (not in an L2), after P3.
+//   consumer (pq_wait_block + the tile roles):
+//     C1 the poll is a relaxed agent-scope atomic load (sc1: served from memory, never from this CU's L1 or a stale
+//        L2 line) issued by wave 0 as SCALAR control flow: the branch that leaves the loop is resolved before any
+//        instruction after it issues (in-order issue per wave), so no tile load can be issued ahead of the poll;
+//     C2 the other waves start the item only after the workgroup barrier wave 0 joins after its poll (s_cmd hand-off);
+//     C3 every load of the handed-off bytes is a buffer_load ... sc1 to registers (CAF_AUX_SC1): it bypasses the CU's
+//        L1 and is not served from an L2 line older than the write-through, because P1's stores dropped / updated
+//        the line on their way through.
+// This is the guide's row "ONE lane of each storing workgroup signals with an agent-scope atomic add; consumer polls
+// with an sc1 load; workgroup barrier between poll and loads; hipMalloc memory; one workgroup per CU; stores
+// 4-byte sc1; loads 4- or 16-byte sc1".  An agent-scope release fence per item (buffer_wbl2) would make the
+// hand-off model-conformant and was measured at +30 % per FFT item (it writes back the L2 shared by 32 CUs).
 constexpr int PQ_FFT_NEXT = 0, PQ_TR_NEXT = 1, PQ_DONE = 4;  // int32 slots of the queue block
 constexpr int PQ_TILES = 16;  // a tile item = 16 delay tiles of one block, one per wave (~2 MB of HBM traffic at F = 256)
 #define CAF_AS4 __attribute__((address_space(4)))
@@ -862,18 +886,26 @@ __device__ __attribute__((noinline)) void reduce_wave_nosurf(const PersistParams
         const int64_t g0 = (int64_t)z * ngroups + (int64_t)t * gpt;
         const __amdgpu_buffer_rsrc_t rv = buf_of(uniform_ptr(P->vmax + g0 * tiles_per_blk * 64), group_bytes * (uint32_t)gpt);
         const __amdgpu_buffer_rsrc_t ri = buf_of(uniform_ptr(P->imax + g0 * tiles_per_blk * 64), group_bytes * (uint32_t)gpt);
-        float bv = -1.f;
+        // Across the groups the rule of the surface paths applies: the maximum of the NORMALISED float32 values, first
+        // hypothesis on ties (groups come in increasing hypothesis order).  Inside a group the FFT role compared raw
+        // |y|^2 (it does not have the delay's normalisation at hand), so the two modes can name different hypotheses
+        // only when two hypotheses of ONE group are within a float32 ulp of each other -- and both then hold the
+        // reported maximum.
+        const float gn = ie * P->tscale[t];
+        float bv = -1.f, bx = -1.f;
         int32_t bh = 0;
         for (int g = 0; g < gpt; ++g) {
             const int voff = (tile * 64 + lane) * 4;
             const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, voff, g * (int)group_bytes, CAF_AUX_SC1));
             const int32_t hh = __builtin_amdgcn_raw_buffer_load_b32(ri, voff, g * (int)group_bytes, CAF_AUX_SC1);
-            if (v > bv) {
+            const float xg = v * gn;
+            if (v >= 0.f && (xg > bx || bv < 0.f)) {
+                bx = xg;
                 bv = v;
                 bh = hh;
             }
         }
-        const float x = bv * (ie * P->tscale[t]);
+        const float x = bv * gn;
         const int32_t f = bh - t * nfreq;
         float best = -1.f;
         int32_t bdel = 0x7fffffff, bfrq = 0;

@@ -302,6 +302,17 @@ int32_t caf_stream_sync(void* stream) {
     CAF_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     return CAF_OK;
 }
+int32_t caf_stream_create(void** stream) {
+    CAF_REQUIRE(stream, "caf_stream_create: NULL");
+    hipStream_t s = nullptr;
+    CAF_HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = (void*)s;
+    return CAF_OK;
+}
+int32_t caf_stream_destroy(void* stream) {
+    if (stream) CAF_HIP_TRY(hipStreamDestroy((hipStream_t)stream));
+    return CAF_OK;
+}
 
 int32_t caf_plan_destroy(caf_plan plan) {
     if (!plan) return CAF_OK;
@@ -611,6 +622,16 @@ int32_t caf_plan_info(caf_plan plan, int32_t* block, int32_t* step, int32_t* blo
 int32_t caf_plan_engine(caf_plan plan, int32_t* engine) {
     CAF_REQUIRE(plan && engine, "NULL argument");
     *engine = plan->persistent ? CAF_ENGINE_PERSISTENT : plan->fused ? CAF_ENGINE_FUSED : CAF_ENGINE_ROCFFT;
+    return CAF_OK;
+}
+
+int32_t caf_plan_watchdog(caf_plan plan, int32_t* marks) {
+    CAF_REQUIRE(plan && marks, "NULL argument");
+    marks[0] = marks[1] = 0;
+    if (!plan->persistent || !plan->d_pq) return CAF_OK;
+    plan->drain();
+    CAF_HIP_TRY(hipDeviceSynchronize());
+    CAF_HIP_TRY(hipMemcpy(marks, plan->d_pq + 2, 2 * sizeof(int32_t), hipMemcpyDeviceToHost));
     return CAF_OK;
 }
 
