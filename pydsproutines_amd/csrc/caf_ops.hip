@@ -308,13 +308,18 @@ int32_t caf_xcorr_perdelay(const float* d_cutout, int32_t n, const float* d_rx, 
     if (rc) return rc;
     // ||cutout|| in float64 on the device (no host round trip)
     double* d_cnorm = nullptr;
-    if ((rc = sc.get(&d_cnorm, 1))) return rc;
+    if ((rc = sc.get(&d_cnorm, cutout_norm_scratch_doubles()))) return rc;
     launch_cutout_norm((const float2*)d_cutout, n, d_cnorm, st);
-    if (batch_rows <= 0) batch_rows = std::max<int64_t>(1, std::min<int64_t>(num, ((int64_t)1 << 25) / n));
+    // rows per batch: up to 2^28 product elements (2 GiB of the 288) in flight, so that even 1e7-sample cutouts go
+    // through rocFFT and the argmax a few dozen rows at a time
+    if (batch_rows <= 0) batch_rows = std::max<int64_t>(1, std::min<int64_t>(num, ((int64_t)1 << 28) / n));
     batch_rows = std::min(batch_rows, num);
     float2* rows = nullptr;
     float2* direct = (float2*)d_ccaf;  // when the complex plane is wanted, build it in place
     if (!direct && (rc = sc.get(&rows, batch_rows * n))) return rc;
+    unsigned long long* part = nullptr;  // long rows: chunked argmax
+    if (const int ch = rows_argmax_chunks(batch_rows, n))
+        if ((rc = sc.get(&part, batch_rows * ch))) return rc;
     for (int64_t r0 = 0; r0 < num; r0 += batch_rows) {
         const int64_t nr = std::min(batch_rows, num - r0);
         float2* buf = direct ? direct + r0 * n : rows;
@@ -323,7 +328,7 @@ int32_t caf_xcorr_perdelay(const float* d_cutout, int32_t n, const float* d_rx, 
         if ((rc = fft_rows(buf, buf, nr, n, false, st))) return rc;
         if (d_qf2 || d_fidx || d_caf)
             launch_rows_argmax(buf, nr, n, 1, 1.0f, (uint32_t*)(d_fidx ? d_fidx + r0 : nullptr), d_qf2 ? d_qf2 + r0 : nullptr,
-                               d_caf ? d_caf + r0 * n : nullptr, st);
+                               d_caf ? d_caf + r0 * n : nullptr, st, part);
     }
     CAF_HIP_TRY(hipStreamSynchronize(st));  // scratch is freed on return
     CAF_HIP_TRY(hipGetLastError());
@@ -394,9 +399,17 @@ int32_t caf_argmax_abs_rows(const float* d_x, int64_t rows, int64_t len, uint32_
                             int32_t use_normsq, void* stream) {
     CAF_REQUIRE(d_x && d_argmax && rows >= 0 && len >= 1, "caf_argmax_abs_rows: bad arguments");
     hipStream_t st = (hipStream_t)stream;
+    Scratch sc;
+    unsigned long long* part = nullptr;
+    const int ch = rows > 0 ? rows_argmax_chunks(rows, len) : 0;
+    if (ch) {
+        const int rc = sc.get(&part, rows * ch);
+        if (rc) return rc;
+    }
     for (int64_t r0 = 0; r0 < rows; r0 += ((int64_t)1 << 30))
         launch_rows_argmax((const float2*)d_x + r0 * len, std::min<int64_t>(rows - r0, (int64_t)1 << 30), len, use_normsq,
-                           1.0f, d_argmax + r0, d_max ? d_max + r0 : nullptr, nullptr, st);
+                           1.0f, d_argmax + r0, d_max ? d_max + r0 : nullptr, nullptr, st, part ? part + r0 * ch : nullptr);
+    if (ch && st != nullptr) CAF_HIP_TRY(hipStreamSynchronize(st));  // (scratch: stream-ordered on the default stream)
     CAF_HIP_TRY(hipGetLastError());
     return CAF_OK;
 }

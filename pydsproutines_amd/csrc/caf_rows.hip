@@ -15,6 +15,33 @@
 
 namespace caf {
 
+// sum |x|^2 of a complex64 vector in float64 as NORM_PARTS partial sums (fixed assignment of elements to workgroups
+// and a fixed summation order: the result does not depend on scheduling); the consumer adds the partials up.
+// Replaces a blocking device-to-host copy + host loop in front of the per-delay path.
+constexpr int NORM_PARTS = 128;
+__global__ __launch_bounds__(256) void k_cutout_sumsq(const float2* __restrict__ x, int64_t n, double* __restrict__ parts) {
+    __shared__ double s[4];
+    double e = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)NORM_PARTS * 256) {
+        const float2 a = x[i];
+        e += (double)a.x * a.x + (double)a.y * a.y;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o, 64);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = e;
+    __syncthreads();
+    if (threadIdx.x == 0) parts[blockIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
+}
+__device__ __forceinline__ double norm_from_parts(const double* __restrict__ parts) {
+    double t = 0.0;
+    for (int i = 0; i < NORM_PARTS; ++i) t += parts[i];
+    return sqrt(t);
+}
+int cutout_norm_scratch_doubles() { return NORM_PARTS; }
+void launch_cutout_norm(const float2* x, int64_t n, double* parts, hipStream_t st) {
+    hipLaunchKernelGGL(k_cutout_sumsq, dim3(NORM_PARTS), dim3(256), 0, st, x, n, parts);
+}
+
 // ---------------------------------------------------------------------------------------
 // z[i][t] = x[t] * y[s_i + t] / (sqrt(E_i) * coef),  s_i = start + i*step,
 // E_i = sum_t |y[s_i + t]|^2 from the f64 prefix array (samples past the end of y read as 0).
@@ -36,7 +63,7 @@ __global__ __launch_bounds__(256) void k_sliding_multiply(const float2* __restri
         int64_t b = s + xlen;
         b = b < 0 ? 0 : (b > ylen ? ylen : b);
         const double e = prefix[b] - prefix[a];
-        inv = (float)(1.0 / (sqrt(e) * (d_coef ? coef * *d_coef : coef)));
+        inv = (float)(1.0 / (sqrt(e) * (d_coef ? coef * norm_from_parts(d_coef) : coef)));
     }
     float2* zr = z + row * (int64_t)xlen;
     for (int t = blockIdx.x * 256 + threadIdx.x; t < xlen; t += gridDim.x * 256) {
@@ -103,6 +130,55 @@ __global__ __launch_bounds__(256) void k_rows_argmax(const float2* __restrict__ 
         if (argmax) argmax[row] = bi;
         if (maxv) maxv[row] = use_normsq ? bv : sqrtf(bv);
     }
+}
+
+// Rows too long for one workgroup each (cp_fastXcorr at N = 1e7: three workgroups scanning 1e7 elements took 17 ms per
+// launch): the row is cut into chunks, one workgroup per (chunk, row) leaves a packed key
+//   (float bits of the maximum) << 32 | (0xFFFFFFFF - index)      (values >= 0: the bits order like the floats; 0 = none)
+// and a second small kernel takes the largest key per row: same result as k_rows_argmax (first index on ties).
+__global__ __launch_bounds__(256) void k_rows_argmax_part(const float2* __restrict__ z, int64_t len, int64_t chunk, float scale,
+                                                          unsigned long long* __restrict__ part, float* __restrict__ plane) {
+    __shared__ unsigned long long s_k[4];
+    const int64_t row = blockIdx.y, c = blockIdx.x;
+    const float2* zr = z + row * len;
+    const int64_t lo = c * chunk, hi = min(len, lo + chunk);
+    float bv = -1.f;
+    uint32_t bi = 0;
+    for (int64_t t = lo + threadIdx.x; t < hi; t += 256) {
+        const float2 a = zr[t];
+        const float v = (a.x * a.x + a.y * a.y) * scale;
+        if (plane) plane[row * len + t] = v;
+        if (v > bv) {
+            bv = v;
+            bi = (uint32_t)t;
+        }
+    }
+    unsigned long long key = bv < 0.f ? 0ull : (((unsigned long long)__float_as_uint(bv)) << 32) | (0xFFFFFFFFu - bi);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long ok = __shfl_xor(key, o, 64);
+        key = ok > key ? ok : key;
+    }
+    if ((threadIdx.x & 63) == 0) s_k[threadIdx.x >> 6] = key;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) key = s_k[w] > key ? s_k[w] : key;
+        part[row * gridDim.x + c] = key;
+    }
+}
+__global__ __launch_bounds__(64) void k_rows_argmax_fin(const unsigned long long* __restrict__ part, int32_t chunks,
+                                                        int64_t rows, int32_t use_normsq, uint32_t* __restrict__ argmax,
+                                                        float* __restrict__ maxv) {
+    const int64_t row = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (row >= rows) return;
+    unsigned long long key = 0ull;
+    for (int c = 0; c < chunks; ++c) {
+        const unsigned long long k = part[row * chunks + c];
+        key = k > key ? k : key;
+    }
+    const float bv = key ? __uint_as_float((uint32_t)(key >> 32)) : 0.f;  // empty / all-NaN row: (0, 0)
+    if (argmax) argmax[row] = key ? 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull) : 0u;
+    if (maxv) maxv[row] = use_normsq ? bv : sqrtf(bv);
 }
 
 // multiArgmax3d_uint32 (argmax.cu:11-81): per item, argmax over the last three dimensions of a
@@ -1041,29 +1117,6 @@ __global__ __launch_bounds__(256) void k_colmax_sqrt(const float* __restrict__ q
 // ---------------------------------------------------------------------------------------
 static inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
 
-// ||x|| = sqrt(sum |x|^2) of a complex64 vector in float64, one workgroup (the cutout of the per-delay path:
-// replaces a blocking device-to-host copy + host loop)
-__global__ __launch_bounds__(1024) void k_cutout_norm(const float2* __restrict__ x, int64_t n, double* __restrict__ out) {
-    __shared__ double s[16];
-    double e = 0.0;
-    for (int64_t i = threadIdx.x; i < n; i += 1024) {
-        const float2 a = x[i];
-        e += (double)a.x * a.x + (double)a.y * a.y;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o, 64);
-    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = e;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = 0.0;
-        for (int w = 0; w < 16; ++w) t += s[w];
-        *out = sqrt(t);
-    }
-}
-void launch_cutout_norm(const float2* x, int64_t n, double* out, hipStream_t st) {
-    hipLaunchKernelGGL(k_cutout_norm, dim3(1), dim3(1024), 0, st, x, n, out);
-}
-
 void launch_sliding_multiply(const float2* x, int32_t xlen, const float2* y, int64_t ylen, const double* prefix,
                              int64_t start, int64_t step, int64_t rows, double coef, int32_t zero_oor, float2* z,
                              hipStream_t st, const double* d_coef) {
@@ -1075,9 +1128,24 @@ void launch_sliding_multiply(const float2* x, int32_t xlen, const float2* y, int
     }
 }
 
+int rows_argmax_chunks(int64_t rows, int64_t len) {
+    // one workgroup per row is fine while there are enough rows to fill the chip or the rows are short
+    if (len <= 131072 || rows >= 2048) return 0;
+    return (int)std::min<int64_t>(1024, (len + 32767) / 32768);
+}
+
 void launch_rows_argmax(const float2* z, int64_t rows, int64_t len, int32_t use_normsq, float scale, uint32_t* argmax,
-                        float* maxv, float* plane, hipStream_t st) {
+                        float* maxv, float* plane, hipStream_t st, unsigned long long* part) {
     if (rows <= 0) return;
+    const int chunks = part ? rows_argmax_chunks(rows, len) : 0;
+    if (chunks > 1) {
+        const int64_t chunk = ((len + chunks - 1) / chunks + 255) / 256 * 256;
+        hipLaunchKernelGGL(k_rows_argmax_part, dim3((unsigned)chunks, (unsigned)rows), dim3(256), 0, st, z, len, chunk, scale, part,
+                           plane);
+        hipLaunchKernelGGL(k_rows_argmax_fin, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, st, part, chunks, rows, use_normsq,
+                           argmax, maxv);
+        return;
+    }
     hipLaunchKernelGGL(k_rows_argmax, dim3((unsigned)rows), dim3(256), 0, st, z, len, use_normsq, scale, argmax, maxv,
                        plane);
 }

@@ -1,0 +1,252 @@
+#!/usr/bin/env python3
+"""Workloads for the per-kernel roofline evidence (scripts/gpu_profile_kernels.sh runs every workload under
+rocprofv3 three times: kernel trace, FETCH_SIZE, WRITE_SIZE).
+
+    python3 scripts/profile_workloads.py <workload> [manifest.json]
+
+Each workload exercises a few hand-written kernels at ONE shape (the BASELINE configs and the reference's own
+benchmark shapes) and declares, per kernel, the ALGORITHMIC bytes (SURVEY 8d's per-unit figure x the units one launch
+processes) and/or flops of one launch; scripts/summarize_kernels.py divides them by the traced durations.
+`list` prints the workload names."""
+import json
+import sys
+
+import numpy as np
+
+sys.path.insert(0, ".")
+sys.path.insert(0, "tests")
+from conftest import cn, qpsk  # noqa: E402
+from pydsproutines_amd import CAFPlan, _lib, asarray  # noqa: E402
+from pydsproutines_amd.devarray import empty  # noqa: E402
+
+N, M = 4096, 1 << 24
+S = M - N + 1
+rng = np.random.default_rng(8)
+lib = _lib.load()
+
+
+def sync():
+    _lib.check(lib.caf_stream_sync(None))
+
+
+def c2_inputs():
+    t = qpsk(rng, N)
+    rx = cn(rng, M)
+    rx[5_000_000 : 5_000_000 + N] += (t * np.exp(2j * np.pi * 37 * np.arange(N) / N)).astype(np.complex64)
+    return t, asarray(rx)
+
+
+def caf(engine, surface, T=1, F=256, reps=2, rows=True):
+    t, d_rx = c2_inputs()
+    tm = t if T == 1 else np.stack([qpsk(rng, N) for _ in range(T)])
+    bins = np.arange(-F // 2, F // 2) if F > 1 else [0]
+    plan = CAFPlan(tm, max_rx_len=M, bins=bins, grid=N, engine=engine)
+    res = None
+    for _ in range(reps):
+        res = plan.run(d_rx, surface=surface, rows=rows, peak=True, out=res)
+    sync()
+    B, step, nb = plan.block, plan.step, plan.blocks_per_batch
+    nblk = -(-S // step)
+    tiles = -(-step // 64)
+    cells = float(T) * F * S
+    fft_flops = nblk * T * F * (5.0 * B * np.log2(B) + 6.0 * B + 3.0 * step)
+    man = []
+    if plan.engine_used == "persistent":
+        if surface:
+            alg = nblk * (tiles * 64 * T * F * 4.0 + 8.0 * B * (T * F / 64.0 + 1)) + cells * 8.0 + T * S * 12.0
+        elif F >= 64:
+            gpt = -(-F // 64)
+            alg = nblk * (tiles * 64 * T * gpt * 8.0 * 2 + 8.0 * B * (T * F / 64.0 + 1)) + T * S * 12.0
+        else:  # F == 1 streaming tile role: tiles written + read, traces written
+            alg = nblk * (tiles * 64 * T * F * 4.0 * 2 + 8.0 * B * (T * F / 64.0 + 1)) + T * S * 8.0
+        man.append(("k_caf_persistent", "one-launch engine, T=%d F=%d %s" % (T, F, "surface" if surface else "no surface"),
+                    alg, fft_flops, reps))
+    elif plan.engine_used == "fused":
+        man.append(("k_fused_caf", "multiply + LDS IFFT + |.|^2 tiles", nblk * (tiles * 64 * T * F * 4.0 + 8.0 * B * (T * F / 64.0 + 1)),
+                    fft_flops, reps))
+        man.append(("k_transpose_norm_argmax", "tiles -> surface + argmax", cells * (4.0 + (4.0 if surface else 0.0)) + T * S * 12.0, 0.0, reps))
+    else:
+        Bc = plan.block
+        man.append(("k_spectral_mul", "X * conj(H_h) for all hypotheses (8(1+2/F) B per point)", nblk * 8.0 * Bc * (T * F + 2), 0.0, reps))
+        man.append(("k_magsq_norm_argmax", "|.|^2 + normalise + argmax (8 B read + 4 B write per cell)", cells * (8.0 + (4.0 if surface else 0.0)) + T * S * 12.0, 0.0, reps))
+    man.append(("k_power_tile_sums|k_prefix_write|k_scan_tile_sums", "f64 energy prefix of |rx|^2 (8 B read + 8 B written per sample)", M * 16.0, 0.0, reps))
+    man.append(("k_inv_energy", "1 / window energy (16 B read + 4 B written per delay)", S * 20.0, 0.0, reps))
+    man.append(("k_gather_blocks", "overlap-save blocks (8 B read + 8 B written per block point)", nblk * B * 16.0, 0.0, reps))
+    plan.close()
+    return man
+
+
+def w_c2_surface():
+    return caf("persistent", True)
+
+
+def w_c2_nosurface():
+    return caf("persistent", False)
+
+
+def w_c2_fused():
+    return caf("fused", True)
+
+
+def w_c2_rocfft():
+    return caf("rocfft", True, reps=1)
+
+
+def w_c3():
+    return caf("persistent", False, T=64, F=1)
+
+
+def w_c4_share():
+    return caf("persistent", False, T=64, F=512, reps=1, rows=False)
+
+
+def w_c5_zoom():
+    from pydsproutines_amd.zoom import caf_with_zoom
+
+    t, d_rx = c2_inputs()
+    bins = np.arange(-128, 128)
+    plan = CAFPlan(t, max_rx_len=M, bins=bins, grid=N)
+    res = plan.run(d_rx, surface=False, rows=True, peak=True)
+    for _ in range(3):
+        out = caf_with_zoom(plan, d_rx, res, bins, N, float(N), k=8, min_height=0.004, span_bins=1.0, step_bins=1.0 / 64)
+    assert len(out) == 8
+    nfft = 4320
+    return [("k_local_max", "local maxima of the 2^24-delay trace (4 B read per delay, all three kernels)", S * 4.0 * 2, 0.0, 3),
+            ("k_zoom_topk", "device top-k of the candidates", 0.0, 0.0, 3),
+            ("k_zoom_rows", "8 product rows, rotated + pre-chirped + padded (8 B read x2, 8 B written)", 8 * (N * 16.0 + nfft * 8.0), 0.0, 3),
+            ("k_rows_mul_vec", "CZT spectral / output chirp multiplies (16 B per element)", 8 * nfft * 16.0 + 8 * 129 * 16.0, 0.0, 3)]
+
+
+def perdelay(n, num, label):
+    rx = cn(rng, n + num)
+    d_rx, d_cut = asarray(rx), asarray(rx[500 : 500 + n].conj().copy())
+    q, fi = empty(num, np.float32), empty(num, np.int32)
+    import ctypes as ct
+
+    for _ in range(2):
+        _lib.check(lib.caf_xcorr_perdelay(ct.c_void_p(d_cut.ptr), n, ct.c_void_p(d_rx.ptr), rx.size, 0, 1, num, 0,
+                                          ct.c_void_p(q.ptr), ct.c_void_p(fi.ptr), None, None, 0, None))
+    sync()
+    return n, num
+
+
+def w_perdelay_fused_4096():
+    n, num = perdelay(4096, 1_000_000, "fused")
+    return [("k_perdelay_fused", "product -> LDS FFT -> |.|^2 -> argmax, N=4096 x 1e6 delays; bytes = the 8 B product elements the "
+             "unfused form writes (SURVEY 8d slidingMultiplyNormalised), which this kernel never materialises", num * n * 8.0,
+             num * 5.0 * n * np.log2(n), 2)]
+
+
+def w_perdelay_fused_256():
+    n, num = perdelay(256, 1_000_000, "fused")
+    return [("k_perdelay_fused", "N=256 x 1e6 delays (same accounting)", num * n * 8.0, num * 5.0 * n * np.log2(n), 2)]
+
+
+def w_perdelay_rows_1000():
+    n, num = perdelay(1000, 100_000, "rows")
+    return [("k_sliding_multiply", "normalised product rows, N=1000 x 1e5 (8 B written per element)", num * n * 8.0, 0.0, 2),
+            ("k_rows_argmax", "|.|^2 + first argmax per row (8 B read per element)", num * n * 8.0, 0.0, 2)]
+
+
+def w_cp_fastxcorr_1e7():
+    from pydsproutines_amd.xcorrRoutines import cp_fastXcorr
+
+    n = 10_000_000
+    rx = cn(rng, n + 1000)
+    cut = rx[300 : 300 + n].copy()
+    d_rx = asarray(rx)
+    sh = np.arange(236, 364)
+    cp_fastXcorr(cut, d_rx, shifts=sh)
+    cp_fastXcorr(cut, d_rx, shifts=sh)
+    sync()
+    return [("k_sliding_multiply", "128 product rows of 1e7 samples (8 B written per element)", 128 * n * 8.0, 0.0, 2),
+            ("k_rows_argmax", "128 rows of 1e7 (8 B read per element)", 128 * n * 8.0, 0.0, 2)]
+
+
+def w_kernels_misc():
+    import ctypes as ct
+
+    from pydsproutines_amd.cupyExtensions import cupyComplexMagnSq, cupyFindLocalMaxima, multiTemplateSlidingDotProduct
+    from pydsproutines_amd.filterRoutines import CupyKernelFilter, cupyMovingAverage
+    from pydsproutines_amd.usrpRoutines import Iq16FrontEnd, iq16_to_complex64
+
+    man = []
+    n = 1 << 24
+    x = cn(rng, n)
+    d_x = asarray(x)
+    for _ in range(3):
+        cupyComplexMagnSq(d_x, np.float32)
+    man.append(("k_magnsq", "complex |.|^2 c64 -> f32 (12 B per element)", n * 12.0, 0.0, 4))
+    d_p = cupyComplexMagnSq(d_x, np.float32)
+    for _ in range(3):
+        cupyMovingAverage(d_p, 100)
+    man.append(("k_moving_tile", "moving average L=100 (4 B read + 4 B written per sample)", n * 8.0, 0.0, 3))
+    d_t = asarray(cn(rng, 20 * 100).reshape(20, 100))
+    for _ in range(2):
+        multiTemplateSlidingDotProduct(d_x[: 10_000_100], d_t, 0, 10_000_000)
+    man.append(("k_multi_template_dot", "20 templates x 100 over 1e7 slides (8 B read + 8 B written per slide; 2*20*100*8 flop per slide)",
+                10_000_000 * 16.0, 10_000_000 * 20 * 100 * 8.0, 2))
+    f = CupyKernelFilter()
+    d_tp = asarray((rng.standard_normal(1024) / 32).astype(np.float32))
+    for _ in range(3):
+        f.filter_smtaps(d_x, d_tp)
+    man.append(("k_fir_os", "overlap-save FIR, 1024 taps, fused 4096-point blocks (8 B read + 8 B written per output)", n * 16.0,
+                n / 3073.0 * 2 * 5 * 4096 * 12, 3))
+    iq = rng.integers(-2000, 2000, 2 * n).astype(np.int16)
+    d_iq = asarray(iq)
+    for _ in range(3):
+        iq16_to_complex64(d_iq, 1.0 / 2048)
+    man.append(("k_iq16_to_c64", "int16 IQ -> complex64 (4 B read + 8 B written per sample)", n * 12.0, 0.0, 3))
+    fe = Iq16FrontEnd(asarray((rng.standard_normal(64) / 8).astype(np.float32)), dsr=4, scale=1.0 / 2048)
+    for _ in range(3):
+        fe.reset()
+        fe.run(d_iq)
+    man.append(("k_fir_poly", "int16 IQ -> 64-tap FIR -> /4 (4 B read per input + 8 B written per output)", n * 4.0 + n / 4 * 8.0, n / 4 * 64 * 4.0, 3))
+    d_m = asarray(cn(rng, 64 * (1 << 18)).reshape(64, 1 << 18))
+    d_tp = asarray((rng.standard_normal(128) / 11).astype(np.float32))
+    for _ in range(3):
+        out = f.upfirdn_sm(d_m, d_tp, 5, 2)
+    man.append(("k_upfirdn", "upfirdn 64 x 2^18, 128 taps, up 5 down 2 (8 B read per input + 8 B written per output)",
+                d_m.size * 8.0 + out.size * 8.0, 0.0, 3))
+    for _ in range(3):
+        cupyFindLocalMaxima(d_p, 3.0)
+    man.append(("k_local_max", "local maxima of a 2^24 float trace (4 B read per sample x 2 passes)", n * 8.0, 0.0, 3))
+    sync()
+    return man
+
+
+def w_fir_direct():
+    """Direct-form FIR kernels (the dispatch would use the overlap-save form from 96 taps on: pinned by the A/B switch,
+    which is read once per process)."""
+    import os
+
+    os.environ["CAF_FIR_OS_MIN_TAPS"] = "1000000"
+    from pydsproutines_amd.filterRoutines import CupyKernelFilter
+
+    n = 1 << 24
+    d_x = asarray(cn(rng, n))
+    f = CupyKernelFilter()
+    man = []
+    for taps in (64, 128):
+        d_tp = asarray((rng.standard_normal(taps) / np.sqrt(taps)).astype(np.float32))
+        for _ in range(3):
+            f.filter_smtaps(d_x, d_tp)
+    man.append(("k_fir_fast", "direct FIR, 64 and 128 taps, 2^24 samples (16 B per sample; 4 flop per tap)", n * 16.0 * 2,
+                n * (64 + 128) * 4.0, 3))
+    sync()
+    return man
+
+
+WORKLOADS = {k[2:]: v for k, v in list(globals().items()) if k.startswith("w_")}
+
+if __name__ == "__main__":
+    if len(sys.argv) < 2 or sys.argv[1] == "list":
+        print(" ".join(WORKLOADS))
+        sys.exit(0)
+    name = sys.argv[1]
+    man = WORKLOADS[name]()
+    sync()
+    out = [{"kernel": k, "what": w, "alg_bytes_per_call": b, "alg_flops_per_call": fl, "calls": c} for k, w, b, fl, c in man]
+    if len(sys.argv) > 2:
+        json.dump({"workload": name, "kernels": out}, open(sys.argv[2], "w"), indent=1)
+    print("workload %s done: %d kernels declared" % (name, len(out)))

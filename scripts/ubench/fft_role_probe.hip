@@ -114,17 +114,30 @@ __global__ __launch_bounds__(1024) void k_probe(const float2* __restrict__ xb, c
         }
         __builtin_amdgcn_wave_barrier();
         float2 hn[16];
+        auto hload = [&](int a) {
+            const uint32_t e = (uint32_t)(((1024 * a + tid - sh_cur) & (FB - 1)) + lz);
+            if (FLAGS & 16384) {
+                const uint64_t u = __builtin_nontemporal_load(reinterpret_cast<const CAF_AS1 uint64_t*>((const CAF_AS1 char*)hrow_cur + (e << 3)));
+                float2 r;
+                __builtin_memcpy(&r, &u, 8);
+                hn[a] = r;
+            } else {
+                hn[a] = ld2(hrow_cur, e);
+            }
+        };
         if (FLAGS & 4096) {
-            // doubled table (no wrap): one per-thread offset for all 16 loads, the 1024 a part in the scalar base
             const uint32_t off = (uint32_t)(((tid - sh_cur) & (FB - 1)) + lz);
 #pragma unroll
             for (int a = 0; a < 16; ++a) hn[a] = ld2(hrow_cur + 1024 * a, off);
-        } else if (!(FLAGS & 2)) {
-#pragma unroll
-            for (int a = 0; a < 16; ++a) hn[a] = ld2(hrow_cur, (uint32_t)(((1024 * a + tid - sh_cur) & (FB - 1)) + lz));
-        } else {
+        } else if (FLAGS & 2) {
 #pragma unroll
             for (int a = 0; a < 16; ++a) hn[a] = make_float2(w.x + a, w.y);
+        } else if (FLAGS & 32768) {
+#pragma unroll
+            for (int a = 0; a < 8; ++a) hload(a);
+        } else if (!(FLAGS & 8192)) {
+#pragma unroll
+            for (int a = 0; a < 16; ++a) hload(a);
         }
         {
             const int base = (tid >> 6) * F_N1 + ((tid >> 2) & 15) * F_ROW + (tid & 3);
@@ -139,6 +152,14 @@ __global__ __launch_bounds__(1024) void k_probe(const float2* __restrict__ xb, c
 #pragma unroll
                 for (int n3 = 0; n3 < 16; ++n3) s_d[base + 4 * n3] = v[n3];
             }
+        }
+        if (FLAGS & 8192) {
+#pragma unroll
+            for (int a = 0; a < 16; ++a) hload(a);
+        }
+        if (FLAGS & 32768) {
+#pragma unroll
+            for (int a = 8; a < 16; ++a) hload(a);
         }
         bar(3);
         {
@@ -430,8 +451,10 @@ int main() {
 #define AB(F, WHAT)                                              \
     run<0>("full loop", xb, hc, sh, tw1, tw23, vt, nblk);       \
     run<F>(WHAT, xb, hc, sh, tw1, tw23, vt, nblk);
-    AB(4096, "row loads from a doubled table (one offset, scalar bases)")
-    AB(4096, "row loads from a doubled table (again)")
+    AB(8192, "row loads issued after pass 3")
+    AB(32768, "row loads: 8 before pass 3, 8 after")
+    AB(16384, "row loads nontemporal")
+    AB(8192, "row loads issued after pass 3 (again)")
     AB(1, "- global |y|^2 stores")
     AB(2, "- template-spectrum row loads")
     AB(3, "- stores - row loads")
