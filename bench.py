@@ -82,6 +82,47 @@ def cpu_baseline(rx_host, tmpl_host, bins, budget_s=12.0):
     }
 
 
+def _libcaf_source_hash():
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    for p in sorted(glob.glob(os.path.join(ROOT, "pydsproutines_amd", "csrc", "*"))):
+        if p.endswith((".hip", ".h", "Makefile")):
+            h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(engine, surface_on, dom, args):
+    """HBM bytes per launch of the dominant kernel from the PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, separate rocprofv3
+    runs) of scripts/gpu_profile_kernels.sh, as summarised in profiles/<round>/kernels_summary.json -- but only when that
+    summary was taken from EXACTLY these kernel sources (hash of csrc/) and this configuration; otherwise null, never a
+    stale constant.  bench.py cannot collect counters on itself: rocprofv3 has to own the process."""
+    if args.log2_block or args.blocks_per_batch:
+        return None, None
+    wl = {("persistent", True): "c2_surface", ("persistent", False): "c2_nosurface", ("fused", True): "c2_fused",
+          ("rocfft", True): "c2_rocfft"}.get((engine, surface_on))
+    want = {"spectral_conj_multiply": {"persistent": "k_caf_persistent", "fused": "k_fused_caf", "rocfft": "k_spectral_mul"},
+            "magsq_norm_argmax": {"fused": "k_transpose_norm_argmax", "rocfft": "k_magsq_norm_argmax"}}[dom].get(engine)
+    if not wl or not want:
+        return None, None
+    import glob
+
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "kernels_summary.json")), reverse=True):
+        try:
+            js = json.load(open(path))
+            if js.get("libcaf_source_hash") != _libcaf_source_hash():
+                continue
+            for k in js["workloads"][wl]["kernels"]:
+                if k["kernel"] == want and k["dispatches"] > 0:
+                    per_launch = (k["fetch_bytes_per_call_x2"] + k["write_bytes_per_call"]) * k["calls"] / k["dispatches"]
+                    if per_launch > 0:
+                        return per_launch, os.path.relpath(path, ROOT)
+        except Exception:
+            continue
+    return None, None
+
+
 def _host_cores():
     # threads actually usable: the scheduler affinity, capped at the 16-core share a one-GPU box gives
     # (os.cpu_count() reports all 256 host threads there); BENCH_CPU_WORKERS overrides
@@ -468,17 +509,7 @@ def main():
             st[name] = {"avg_ms": ms / max(n, 1), "launches": n}
         stage_total = {k: v["avg_ms"] * v["launches"] / args.steps for k, v in st.items()}
         dom = max(("spectral_conj_multiply", "magsq_norm_argmax"), key=lambda k: stage_total[k])
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                for entry in tj.get("entries", []):
-                    if entry.get("config") == {"engine": plan.engine_used, "block": B, "blocks_per_batch": nb,
-                                               "surface": surface_on}:
-                        traffic = entry.get(dom)
-            except Exception:
-                traffic = None
+        traffic, traffic_src = measured_traffic(plan.engine_used, surface_on, dom, args)
         combined_bytes = (st["spectral_conj_multiply"]["alg_bytes_per_launch"] + st["magsq_norm_argmax"]["alg_bytes_per_launch"])
         combined_ms = st["spectral_conj_multiply"]["avg_ms"] + st["magsq_norm_argmax"]["avg_ms"]
         out = {
@@ -516,7 +547,7 @@ def main():
                 {
                     "kernel": st[dom].get("kernel", dom), "bound": "hbm", "achieved": st[dom]["achieved_GBs"],
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": st[dom]["achieved_GBs"] / HBM_PEAK_GBS,
-                    "traffic": traffic, "avg_launch_ms": st[dom]["avg_ms"],
+                    "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": st[dom]["avg_ms"],
                     "alg_bytes_per_launch": st[dom]["alg_bytes_per_launch"],
                     **({"also_TFLOPs": st[dom]["achieved_TFLOPs"], "also_frac_f32_peak": st[dom]["achieved_TFLOPs"] / 157.3,
                         "note": "one launch overlaps the ALU/LDS-bound FFT role (priced in also_TFLOPs against the "
