@@ -24,6 +24,7 @@
 // 512-thread / two-butterfly variant is kept as an A/B switch (measured 20 % slower).
 // The same hypothesis loop (fused_item) also runs inside k_caf_persistent (end of this file), which
 // overlaps it with the transpose stage on other CUs in a single work-queue launch.
+#include <algorithm>
 #include <cstdlib>
 
 #include "caf_internal.h"
@@ -313,6 +314,193 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
                                        __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
+    }
+}
+
+// ----------------------------------------------------------------------------------------
+// Templates of 8193 .. 16384 samples: 32768-point blocks as TWO chained 16384-point transforms in the same LDS image.
+//   y[n] = sum_m P[m] W^{mn},  W = e^{+j 2 pi / 32768},  m = 2 m' + c:
+//   y[n'] = E[n'] + W^{n'} O[n'],   y[n' + 16384] = E[n'] - W^{n'} O[n'],   E / O = IFFT_16384 of the even / odd samples
+// The block spectra and the template-spectrum rows arrive PARITY-MAJOR ([c][16384] per row: k_parity_major below), so a
+// half-transform reads exactly what fused_item reads for a 16384-point block -- contiguous, and with the (even) shift
+// of an on-grid hypothesis halved.  E's sixteen outputs per thread wait in registers while O runs through the same
+// four passes; both transforms leave a thread the same sixteen positions n' = n1 + 16 n2 + 256 n3 + 4096 n4, so the
+// radix-2 combination is register-local and nothing but |y|^2 leaves the CU.
+// Registers (128): the block spectrum cannot stay resident (two parities = 64); instead the inputs of the O half are
+// fetched before pass 3 of the E half (E's outputs do not exist yet), and the inputs of the next E half are fetched
+// inside pass 4 of the O half, four positions at a time, as the combination frees E's registers.
+// Tiles: n -> tile n >> 6 as before (up to 384 tiles for N = 8193).  Write-through stores (MODE 1) or plain (0).
+template <int MODE>
+__device__ __forceinline__ void fused_item2(float2* __restrict__ s_d, const float2* __restrict__ s_tw2,
+                                            const float2* __restrict__ s_tw3, const float2* __restrict__ xb,  // [blocks][2][16384]
+                                            const float2* __restrict__ hc,       // [T][2][16384] or [T*F][2][16384]
+                                            const int32_t* __restrict__ shifts, const float2* __restrict__ tw1,
+                                            int32_t table_mode, int32_t nfreq, int32_t nhyp, int blk, int h0, int h1,
+                                            int32_t tiles_per_blk, float* __restrict__ vt) {
+    constexpr int FB2 = 2 * FB;
+    const int tid = threadIdx.x;
+    const float2 w = ld2(tw1, (uint32_t)(1024 + tid));  // pass-1 twiddle base e^{+j 2 pi m2 / 16384}
+    const float2* xp = xb + (int64_t)blk * FB2;
+    float* vt_blk = vt + (int64_t)blk * tiles_per_blk * nhyp * 64;
+    // combination twiddle base e^{+j 2 pi nb / 32768}, nb = n1 + 16 n2 + 256 q (the thread's pass-4 position, < 1024)
+    const int n1o = tid & 15, n2o = (tid >> 4) & 15, qo = tid >> 8;
+    float2 wb;
+    {
+        double sn, cs;
+        sincos(2.0 * M_PI * (double)(n1o + 16 * n2o + 256 * qo) / 32768.0, &sn, &cs);
+        wb = make_float2((float)cs, (float)sn);
+    }
+    const float2* hrow_cur;
+    int sh_cur;  // shift in parity-major elements (= half the 32768-point shift)
+    auto row_of = [&](int h) {
+        if (table_mode) {
+            hrow_cur = hc + (int64_t)h * FB2;
+            sh_cur = 0;
+        } else {
+            const int t = h / nfreq;
+            sh_cur = *((const CAF_AS1 int32_t*)shifts + (h - t * nfreq)) >> 1;
+            hrow_cur = hc + (int64_t)t * FB2;
+        }
+    };
+    float2 xn[16], hn[16];  // inputs of the NEXT half-transform
+    row_of(h0);
+#pragma unroll
+    for (int a = 0; a < 16; ++a) {
+        xn[a] = ld2(xp, (uint32_t)(1024 * a + tid));
+        hn[a] = ld2(hrow_cur, (uint32_t)((1024 * a + tid - sh_cur) & (FB - 1)));
+    }
+    float2 e[16];  // E's outputs (register 4 i + n4 <-> n3 = q + 4 i, n4)
+
+    for (int h = h0; h < h1; ++h) {
+        int64_t hoff = (int64_t)h * 64;
+        asm volatile("" : "+s"(hoff));
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            int lz = 0;
+            asm volatile("" : "+v"(lz));
+            // ---- pass 1 (as fused_item): product, DFT16 over a, twiddle, write ----
+            {
+                float2 v1[16];
+#pragma unroll
+                for (int a = 0; a < 16; ++a) v1[a] = cmul(xn[a], hn[a]);
+                idft16(v1);
+                float2 p = w;
+                asm volatile("" : "+v"(p.x), "+v"(p.y));
+                const float2 wj = p;
+                v1[1] = cmul(v1[1], p);
+#pragma unroll
+                for (int n1 = 2; n1 < 16; ++n1) {
+                    p = cmul(p, wj);
+                    v1[n1] = cmul(v1[n1], p);
+                }
+                __syncthreads();  // the previous half-transform's pass-4 reads are done
+                const int off = (tid >> 6) * F_ROW + (tid & 63);
+#pragma unroll
+                for (int n1 = 0; n1 < 16; ++n1) s_d[n1 * F_N1 + off] = v1[n1];
+            }
+            __syncthreads();
+            // ---- pass 2 ----
+            {
+                float2 v[16];
+                const int base = (tid >> 6) * F_N1 + (tid & 63);
+#pragma unroll
+                for (int b = 0; b < 16; ++b) v[b] = s_d[base + b * F_ROW];
+                idft16(v);
+#pragma unroll
+                for (int n2 = 1; n2 < 16; ++n2) v[n2] = cmul(v[n2], s_tw2[n2 * 64 + (tid & 63) + lz]);
+#pragma unroll
+                for (int n2 = 0; n2 < 16; ++n2) s_d[base + n2 * F_ROW] = v[n2];
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (c == 0) {
+                // inputs of the O half of this hypothesis: issued here, covered by pass 3 and pass 4
+#pragma unroll
+                for (int a = 0; a < 16; ++a) {
+                    xn[a] = ld2(xp, (uint32_t)(FB + 1024 * a + tid + lz));
+                    hn[a] = ld2(hrow_cur, (uint32_t)(FB + ((1024 * a + tid - sh_cur) & (FB - 1)) + lz));
+                }
+            } else {
+                row_of(h + 1 < h1 ? h + 1 : h);  // (the loads of the next E half follow inside pass 4)
+            }
+            // ---- pass 3 ----
+            {
+                float2 v[16];
+                const int base = (tid >> 6) * F_N1 + ((tid >> 2) & 15) * F_ROW + (tid & 3);
+#pragma unroll
+                for (int cc = 0; cc < 16; ++cc) v[cc] = s_d[base + 4 * cc];
+                idft16(v);
+#pragma unroll
+                for (int n3 = 1; n3 < 16; ++n3) v[n3] = cmul(v[n3], s_tw3[n3 * 4 + (tid & 3) + lz]);
+#pragma unroll
+                for (int n3 = 0; n3 < 16; ++n3) s_d[base + 4 * n3] = v[n3];
+            }
+            __syncthreads();
+            // ---- pass 4: DFT4 over d; the E half keeps its outputs, the O half combines and stores ----
+            const int base = n1o * F_N1 + n2o * F_ROW;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int n3 = qo + 4 * i;
+                int lzi = 0;
+                asm volatile("" : "+v"(lzi));
+                const float4 lo = *reinterpret_cast<const float4*>(&s_d[base + 4 * n3 + lzi]);
+                const float4 hi = *reinterpret_cast<const float4*>(&s_d[base + 4 * n3 + 2 + lzi]);
+                float2 a0 = make_float2(lo.x, lo.y), a1 = make_float2(lo.z, lo.w);
+                float2 a2 = make_float2(hi.x, hi.y), a3 = make_float2(hi.z, hi.w);
+                idft4(a0, a1, a2, a3);
+                const float2 y[4] = {a0, a1, a2, a3};
+                if (c == 0) {
+#pragma unroll
+                    for (int n4 = 0; n4 < 4; ++n4) e[4 * i + n4] = y[n4];
+                } else {
+#pragma unroll
+                    for (int n4 = 0; n4 < 4; ++n4) {
+                        // W^{n'} = wb * e^{j 2 pi (i + 4 n4) / 32}  (n' = nb + 1024 i + 4096 n4)
+                        const int k = i + 4 * n4;
+                        const float ck = (float)__builtin_cos(2.0 * M_PI * k / 32.0), sk = (float)__builtin_sin(2.0 * M_PI * k / 32.0);
+                        const float2 wn = cmul(wb, make_float2(ck, sk));
+                        const float2 t = cmul(y[n4], wn);
+                        const float2 ylo = cadd(e[4 * i + n4], t), yhi = csub(e[4 * i + n4], t);
+                        const int tile_u = 16 * i + 64 * n4;
+                        const int tile_t = (n2o >> 2) + 4 * qo;
+                        float* pu = vt_blk + (int64_t)tile_u * nhyp * 64 + hoff;
+                        const uint32_t voff = ((uint32_t)tile_t * (uint32_t)nhyp * 64u + (uint32_t)(n1o + 16 * (n2o & 3))) << 2;
+                        const uint32_t voff_hi = voff + (((uint32_t)256 * (uint32_t)nhyp * 64u) << 2);  // n + 16384: tile + 256
+                        const float vlo = ylo.x * ylo.x + ylo.y * ylo.y, vhi = yhi.x * yhi.x + yhi.y * yhi.y;
+                        if (tile_u + tile_t < tiles_per_blk) {
+                            if (MODE == 1) gst1_wt(pu, voff, vlo); else gst1(pu, voff, vlo);
+                        }
+                        if (256 + tile_u + tile_t < tiles_per_blk) {
+                            if (MODE == 1) gst1_wt(pu, voff_hi, vhi); else gst1(pu, voff_hi, vhi);
+                        }
+                    }
+                    // four positions of the next E half's inputs, into the registers the combination just freed
+#pragma unroll
+                    for (int a = 4 * i; a < 4 * i + 4; ++a) {
+                        xn[a] = ld2(xp, (uint32_t)(1024 * a + tid + lzi));
+                        hn[a] = ld2(hrow_cur, (uint32_t)(((1024 * a + tid - sh_cur) & (FB - 1)) + lzi));
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+}
+
+// rows of B = 2 * half complex samples -> parity-major: out[r][c][m'] = in[r][2 m' + c]
+__global__ __launch_bounds__(256) void k_parity_major(const float2* __restrict__ in, float2* __restrict__ out, int32_t half) {
+    const float2* ir = in + (int64_t)blockIdx.y * 2 * half;
+    float2* orow = out + (int64_t)blockIdx.y * 2 * half;
+    for (int m = blockIdx.x * 256 + threadIdx.x; m < half; m += gridDim.x * 256) {
+        const float4 v = *reinterpret_cast<const float4*>(&ir[2 * m]);
+        orow[m] = make_float2(v.x, v.y);
+        orow[half + m] = make_float2(v.z, v.w);
+    }
+}
+void launch_parity_major(const float2* in, float2* out, int64_t rows, int32_t half, hipStream_t st) {
+    for (int64_t r0 = 0; r0 < rows; r0 += 65535) {
+        const int64_t nr = std::min<int64_t>(65535, rows - r0);
+        hipLaunchKernelGGL(k_parity_major, dim3(16, (unsigned)nr), dim3(256), 0, st, in + r0 * 2 * half, out + r0 * 2 * half, half);
     }
 }
 
@@ -1061,6 +1249,25 @@ __device__ __attribute__((noinline)) void persistent_fft_item(lds_float2* s_d, c
         __hip_atomic_fetch_add(&params_of(pp)->pq[PQ_DONE + blk], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// FFT role for 32768-point blocks (templates of 8193 .. 16384 samples): fused_item2, same publish sequence
+__device__ __attribute__((noinline)) void persistent_fft_item2(lds_float2* s_d, const lds_float2* s_tw2, const lds_float2* s_tw3,
+                                                               const PersistParams* pp_in, int item_in) {
+    const PersistParams* pp = uniform_ptr(pp_in);
+    const int item = __builtin_amdgcn_readfirstlane(item_in);
+    const CAF_AS4 PersistParams* P = params_of(pp);
+    const int ngroups = P->ngroups, hyp_per_wg = P->hyp_per_wg, nhyp = P->nhyp;
+    const int blk = item / ngroups;
+    const int grp = item - blk * ngroups;
+    const int h0 = grp * hyp_per_wg;
+    const int h1 = min(h0 + hyp_per_wg, nhyp);
+    fused_item2<1>((float2*)s_d, (const float2*)s_tw2, (const float2*)s_tw3, P->xb, P->hc, P->shifts, P->tw1, P->table_mode,
+                   P->nfreq, nhyp, blk, h0, h1, P->tiles_per_blk, P->vt);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (threadIdx.x == 0)
+        __hip_atomic_fetch_add(&params_of(pp)->pq[PQ_DONE + blk], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <bool STATS>
 __global__ __launch_bounds__(1024) void k_caf_persistent(const PersistParams* __restrict__ pp) {
     static_assert(16 * TW_LDS * 4 <= F_LDS_DATA * 8, "transposer patches must fit the FFT image");
@@ -1156,7 +1363,9 @@ __global__ __launch_bounds__(1024) void k_caf_persistent(const PersistParams* __
             break;
         }
         if (kind == 1) {
-            if (__builtin_amdgcn_readfirstlane(params_of(pp)->nosurf))
+            if (__builtin_amdgcn_readfirstlane(params_of(pp)->block_log2) == 15)
+                persistent_fft_item2((lds_float2*)s_d, (const lds_float2*)s_tw2, (const lds_float2*)s_tw3, pp, item);
+            else if (__builtin_amdgcn_readfirstlane(params_of(pp)->nosurf))
                 persistent_fft_item<true>((lds_float2*)s_d, (const lds_float2*)s_tw2, (const lds_float2*)s_tw3, pp, item);
             else
                 persistent_fft_item<false>((lds_float2*)s_d, (const lds_float2*)s_tw2, (const lds_float2*)s_tw3, pp, item);

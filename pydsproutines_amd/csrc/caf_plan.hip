@@ -80,6 +80,7 @@ struct caf_plan_t {
     double* d_prefix = nullptr;
     float* d_inv_e = nullptr;
     float2* d_xb = nullptr;
+    float2* d_xb2 = nullptr;  // 32768-point blocks: the block spectra parity-major (fused_item2)
     float2* d_pbuf = nullptr;
     PeakRec* d_partial = nullptr;
     bool fused = false;
@@ -164,7 +165,7 @@ struct caf_plan_t {
         s_aux = nullptr;
         ev_fork = ev_join = nullptr;
         void* ptrs[] = {d_hc,  d_shifts, d_tscale, d_gstart,  d_glen, d_tile_sums, d_prefix, d_inv_e,
-                        d_xb,  d_pbuf,   d_partial, d_vt,     d_params, d_pq,     d_uconj, d_nu};  // (d_tw1 / d_tw23 are shared, per device)
+                        d_xb,  d_pbuf,   d_partial, d_vt,     d_params, d_pq,     d_uconj, d_nu,    d_xb2};  // (d_tw1 / d_tw23 are shared, per device)
         for (void* p : ptrs)
             if (p) (void)pool_free(p);
     }
@@ -355,10 +356,15 @@ static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
     // engine: the fused LDS-resident kernel works on 16384-point blocks
     CAF_REQUIRE(d->engine >= CAF_ENGINE_AUTO && d->engine <= CAF_ENGINE_PERSISTENT && d->reserved == 0,
                 "bad engine field");
-    const bool fused_ok = N <= 8192 && (d->freq_mode != CAF_FREQ_BINS || (d->grid >= 1 && 16384 % d->grid == 0)) &&
-                          (d->log2_block == 0 || d->log2_block == 14);
-    CAF_REQUIRE((d->engine != CAF_ENGINE_FUSED && d->engine != CAF_ENGINE_PERSISTENT) || fused_ok,
-                "fused engines need template_len <= 8192, grid | 16384 and log2_block 0 or 14");
+    // the LDS-resident engines: 16384-point blocks for templates up to 8192 samples, 32768-point blocks (two chained
+    // 16384-point transforms per hypothesis, persistent engine only) up to 16384
+    const int fused_lb = N <= 8192 ? 14 : 15;
+    const bool fused_ok = N <= 16384 && (d->freq_mode != CAF_FREQ_BINS || (d->grid >= 1 && 16384 % d->grid == 0)) &&
+                          (d->log2_block == 0 || d->log2_block == fused_lb);
+    CAF_REQUIRE(d->engine != CAF_ENGINE_PERSISTENT || fused_ok,
+                "the persistent engine needs template_len <= 16384, grid | 16384 and log2_block 0, 14 (<= 8192 samples) or 15");
+    CAF_REQUIRE(d->engine != CAF_ENGINE_FUSED || (fused_ok && N <= 8192),
+                "the two-launch fused engine needs template_len <= 8192, grid | 16384 and log2_block 0 or 14");
     p->fused = (d->engine == CAF_ENGINE_FUSED) || (d->engine == CAF_ENGINE_PERSISTENT) ||
                (d->engine == CAF_ENGINE_AUTO && fused_ok);
     // one launch for both stages whenever the fused FFT applies: its tile role handles any F (steps of 32
@@ -366,10 +372,10 @@ static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
     // form on every measured shape (C2 1.15x, C4 share 1.25x, C3 with 64 templates and no frequency scan ~10x)
     p->persistent = d->engine == CAF_ENGINE_PERSISTENT || (d->engine == CAF_ENGINE_AUTO && fused_ok);
     if (const char* e = getenv("CAF_PERSISTENT"))  // A/B switch for AUTO plans
-        if (d->engine == CAF_ENGINE_AUTO && fused_ok) p->persistent = atoi(e) != 0;
+        if (d->engine == CAF_ENGINE_AUTO && fused_ok && N <= 8192) p->persistent = atoi(e) != 0;
 
     // block size: B = 2^k, B >= 2N (>= 50 % valid outputs); default 16 N clipped to [2^12, 2^18]
-    int lb = p->fused ? 14 : d->log2_block;
+    int lb = p->fused ? fused_lb : d->log2_block;
     const int lmin = ilog2_ceil(2 * (int64_t)N);
     if (lb <= 0) {
         lb = std::min(std::max(ilog2_ceil(16 * (int64_t)N), 12), 18);
@@ -449,7 +455,7 @@ static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
     // as many blocks per launch (config C4's 512 templates x 512 bins on one GPU: 32 blocks instead of 1; fewer,
     // longer launches = fewer drain tails where the last blocks' reductions run on a handful of CUs).
     p->nb_nosurf = nb;
-    if (p->persistent && F >= p->hyp_per_wg) {
+    if (p->persistent && p->B == 16384 && F >= p->hyp_per_wg) {
         const int64_t gpt = (F + p->hyp_per_wg - 1) / p->hyp_per_wg;
         if (2 * gpt <= F) {
             const int64_t cap = (int64_t)nb * F / (2 * gpt);  // nb_nosurf * 2 * T * gpt <= nb * T * F pairs
@@ -471,6 +477,7 @@ static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
     // (~32 MiB of spectra per forward launch: 256 blocks of 16384, 64 blocks of 65536, ...)
     p->fwd_chunk = (int)std::min<int64_t>(std::max<int64_t>(1, ((int64_t)1 << 22) / B), p->max_blocks);
     if ((rc = p->alloc(&p->d_xb, (p->max_blocks + p->fwd_chunk) * B))) return rc;
+    if (p->fused && p->B == 32768 && (rc = p->alloc(&p->d_xb2, (p->max_blocks + p->fwd_chunk) * B))) return rc;
     if (p->fused) {
         if ((rc = p->alloc(&p->d_vt, (int64_t)nb * p->tiles_per_blk * T * F * 64))) return rc;
         if ((rc = fused_twiddles(p->device, &p->d_tw1, &p->d_tw23))) return rc;  // per device, shared by all plans
@@ -552,6 +559,17 @@ static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
         rc = fft_plan_acquire(&tmp, false, (size_t)B, (size_t)nspec, (size_t)B);
         if (rc == CAF_OK) rc = tmp.exec(p->d_hc, nullptr, nullptr);
         if (rc == CAF_OK) launch_conj_scale(p->d_hc, nspec * B, 1.0f / (float)B, nullptr);
+        if (rc == CAF_OK && p->fused && B == 32768) {
+            // the 32768-point engine reads its template-spectrum rows parity-major (even samples, then odd samples)
+            float2* tmp = nullptr;
+            rc = pool_alloc((void**)&tmp, nspec * (int64_t)B * 8);
+            if (rc == CAF_OK) {
+                launch_parity_major(p->d_hc, tmp, nspec, B / 2, nullptr);
+                if (hipMemcpyAsync(p->d_hc, tmp, (size_t)nspec * B * 8, hipMemcpyDeviceToDevice, nullptr) != hipSuccess) rc = CAF_ERR_HIP;
+                (void)hipStreamSynchronize(nullptr);
+                (void)pool_free(tmp);
+            }
+        }
         hipError_t e = hipStreamSynchronize(nullptr);
         fft_plan_release(&tmp);
         free_tmp();
@@ -698,6 +716,8 @@ int32_t caf_plan_execute(caf_plan p, const float* d_rx, int64_t rx_len, int64_t 
         p->stage_end(st);
         if (rc) return rc;
     }
+    if (p->fused && p->B == 32768)  // block spectra parity-major for the two chained half-transforms
+        launch_parity_major(p->d_xb, p->d_xb2, nfwd * p->fwd_chunk, p->B / 2, st);
     if (p->s_aux) CAF_HIP_TRY(hipStreamWaitEvent(st, p->ev_join, 0));
     if (p->fused) {
         CAF_REQUIRE(!out->d_cqf, "the fused engine has no complex-QF output (create the plan with CAF_ENGINE_ROCFFT)");
@@ -709,7 +729,7 @@ int32_t caf_plan_execute(caf_plan p, const float* d_rx, int64_t rx_len, int64_t 
         int ns_gpt = 0;
         {
             const char* e = getenv("CAF_PERSIST_NOSURF");  // A/B switch, default on
-            if (p->persistent && !out->d_surface && F >= p->hyp_per_wg && (!e || atoi(e))) {
+            if (p->persistent && p->B == 16384 && !out->d_surface && F >= p->hyp_per_wg && (!e || atoi(e))) {
                 const int gpt = (F + p->hyp_per_wg - 1) / p->hyp_per_wg;
                 // the two pair arrays must fit the tile buffer they replace (true for >= 2 hypotheses per group)
                 if (2 * (int64_t)T * gpt <= (int64_t)T * F) ns_gpt = gpt;
@@ -720,7 +740,7 @@ int32_t caf_plan_execute(caf_plan p, const float* d_rx, int64_t rx_len, int64_t 
             const int32_t nbk = (int32_t)std::min<int64_t>(nb_launch, nblk - b0);
             PersistParams h;
             std::memset(&h, 0, sizeof(h));
-            h.xb = p->d_xb + b0 * (int64_t)p->B;
+            h.xb = (p->B == 32768 ? p->d_xb2 : p->d_xb) + b0 * (int64_t)p->B;
             h.hc = p->d_hc;
             h.shifts = p->d_shifts;
             h.tw1 = p->d_tw1;
@@ -732,6 +752,7 @@ int32_t caf_plan_execute(caf_plan p, const float* d_rx, int64_t rx_len, int64_t 
             h.hyp_per_wg = p->hyp_per_wg;
             h.nblk = nbk;
             h.tiles_per_blk = p->tiles_per_blk;
+            h.block_log2 = p->B == 32768 ? 15 : 14;
             h.ntmpl = T;
             h.step = p->step;
             h.blk0 = (int32_t)b0;

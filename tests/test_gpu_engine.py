@@ -266,7 +266,7 @@ def test_engines_agree_with_oracle(engine, golden):
         with pytest.raises(ValueError):
             plan3.run(asarray(rxg), cqf=True)  # complex QF is a rocFFT-engine output
         with pytest.raises(ValueError):
-            CAFPlan(np.ones(9000, np.complex64), max_rx_len=40000, bins=[0], grid=16384, engine=engine)
+            CAFPlan(np.ones(17000, np.complex64), max_rx_len=40000, bins=[0], grid=16384, engine=engine)
 
     # 2 templates x 128 bins (whole 128-hypothesis chunks: the full-tile path of the transposers), 3 blocks,
     # run twice on different data through the same plan: the second result must not see the first one's tiles
@@ -316,24 +316,26 @@ def test_engines_agree_with_oracle(engine, golden):
     assert np.all(r7.peak_delay.get()[1:20] == d6[1:20])
 
 
-@pytest.mark.parametrize("n", [4095, 8191, 8192, 8193])
-def test_template_lengths_around_the_fused_limit(n):
-    """The LDS-resident engines take templates up to 8192 samples (16384-point blocks, >= 50 % valid delays);
+@pytest.mark.parametrize("n", [4095, 8191, 8192, 8193, 12000, 16384, 16385])
+def test_template_lengths_around_the_fused_limits(n):
+    """The LDS-resident engines: 16384-point blocks for templates up to 8192 samples (persistent and two-launch fused,
+    bit-identical), 32768-point blocks as two chained 16384-point transforms up to 16384 samples (persistent only);
     longer ones go to the rocfft engine automatically and are refused by an explicit fused / persistent request."""
     from pydsproutines_amd import CAFPlan, asarray
     from test_gpu_engine_fuzz import _oracle_rows
 
     rng = np.random.default_rng(n)
-    m = 40_000
+    m = 90_000 if n > 8192 else 40_000
     t = qpsk(rng, n)
     rx = cn(rng, m)
     d0, bins = 12_345, np.arange(-4, 4)
-    grid = 1 << int(np.ceil(np.log2(n)))
+    grid = min(16384, 1 << int(np.ceil(np.log2(n))))
     rx[d0 : d0 + n] += (t * np.exp(2j * np.pi * 3 * np.arange(n) / grid)).astype(np.complex64)
     d_rx = asarray(rx)
-    rows = np.array([0, 1, d0 - 1, d0, d0 + 1, m - n])
+    rows = np.array([0, 1, d0 - 1, d0, d0 + 1, 16383, 16384, 16385, 24575, 24576, 32767, 32768, m - n])
+    rows = rows[rows <= m - n]
     ref = _oracle_rows(t, rx, bins / grid, rows)
-    engines = ("persistent", "fused", "rocfft") if n <= 8192 else ("rocfft",)
+    engines = ("persistent", "fused", "rocfft") if n <= 8192 else ("persistent", "rocfft") if n <= 16384 else ("rocfft",)
     surf = {}
     for engine in engines:
         plan = CAFPlan(t, max_rx_len=m, bins=bins, grid=grid, engine=engine)
@@ -341,12 +343,24 @@ def test_template_lengths_around_the_fused_limit(n):
         surf[engine] = res.surface.get()[0]
         np.testing.assert_allclose(surf[engine][rows], ref, atol=1e-4 * ref.max())
         assert (int(res.peak_delay.get()[0]), int(bins[res.peak_freq.get()[0]])) == (d0, 3)
+        # row results == the surface it wrote; peak-only run agrees
+        np.testing.assert_array_equal(res.row_max.get()[0], surf[engine].max(axis=1))
+        np.testing.assert_array_equal(res.row_arg.get()[0], np.argmax(surf[engine], axis=1))
+        r2 = plan.run(d_rx, surface=False)
+        np.testing.assert_array_equal(r2.row_max.get()[0], surf[engine].max(axis=1))
         plan.close()
     if n <= 8192:
         np.testing.assert_array_equal(surf["persistent"], surf["fused"])
         auto = CAFPlan(t, max_rx_len=m, bins=bins, grid=grid)
         assert auto.engine_used == "persistent" and auto.block == 16384
         auto.close()
+    elif n <= 16384:
+        assert np.max(np.abs(surf["persistent"] - surf["rocfft"])) <= 2e-6 * max(1.0, surf["rocfft"].max())  # two engines
+        auto = CAFPlan(t, max_rx_len=m, bins=bins, grid=grid)
+        assert auto.engine_used == "persistent" and auto.block == 32768 and auto.step == 32768 - n + 1
+        auto.close()
+        with pytest.raises(ValueError):
+            CAFPlan(t, max_rx_len=m, bins=bins, grid=grid, engine="fused")
     else:
         auto = CAFPlan(t, max_rx_len=m, bins=bins, grid=grid)
         assert auto.engine_used == "rocfft"
@@ -354,3 +368,31 @@ def test_template_lengths_around_the_fused_limit(n):
         for engine in ("persistent", "fused"):
             with pytest.raises(ValueError):
                 CAFPlan(t, max_rx_len=m, bins=bins, grid=grid, engine=engine)
+
+
+def test_long_template_explicit_frequencies_and_many_hypotheses():
+    """32768-point blocks with an explicit frequency table (off-grid hypotheses, table mode) and more hypotheses than
+    one work item takes, several templates: against the rocfft engine and the oracle."""
+    from pydsproutines_amd import CAFPlan, asarray
+    from test_gpu_engine_fuzz import _oracle_rows
+
+    rng = np.random.default_rng(5)
+    n, m = 10_000, 120_000
+    tm = np.stack([qpsk(rng, n) for _ in range(2)])
+    rx = cn(rng, m)
+    freqs = np.linspace(-3.3e-4, 3.1e-4, 150)
+    truth = [(20_000, 17), (77_777, 140)]
+    for i, (d, f) in enumerate(truth):
+        rx[d : d + n] += (tm[i] * np.exp(2j * np.pi * freqs[f] * np.arange(n))).astype(np.complex64)
+    d_rx = asarray(rx)
+    p = CAFPlan(tm, max_rx_len=m, freqs_norm=freqs)
+    assert p.engine_used == "persistent" and p.block == 32768
+    r = p.run(d_rx, surface=True)
+    q = CAFPlan(tm, max_rx_len=m, freqs_norm=freqs, engine="rocfft").run(d_rx, surface=True)
+    a, b = r.surface.get(), q.surface.get()
+    assert np.max(np.abs(a - b)) <= 3e-6 * max(1.0, b.max())
+    for i, (d, f) in enumerate(truth):
+        assert (int(r.peak_delay.get()[i]), int(r.peak_freq.get()[i])) == (d, f)
+        rows = np.array([d - 1, d, d + 1, 50_000])
+        ref = _oracle_rows(tm[i], rx, freqs, rows)
+        np.testing.assert_allclose(a[i][rows], ref, atol=1e-4 * ref.max())
