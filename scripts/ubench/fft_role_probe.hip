@@ -206,6 +206,221 @@ __global__ __launch_bounds__(1024) void k_probe(const float2* __restrict__ xb, c
 }
 
 
+// ---- Variant 3: the same loop with hand-packed complex arithmetic (v_pk_add/mul/fma_f32 on (re, im) register pairs,
+// op_sel / neg modifiers instead of moves): packed instructions issue in ~4.2 cycles for two lanes of work where the
+// scalar forms take 2.4-2.9 each (pk_rate.hip).
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f pk_addj(v2f a, v2f b) {  // a + j b
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ v2f pk_subj(v2f a, v2f b) {  // a - j b
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ v2f pk_cmul(v2f a, v2f b) {
+    v2f t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
+    return r;
+}
+__device__ __forceinline__ v2f pk_cmul_s(v2f a, v2f b) {  // b uniform (SGPR pair)
+    v2f t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "s"(b));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "s"(b), "v"(t));
+    return r;
+}
+__device__ __forceinline__ void pk_idft4(v2f& a0, v2f& a1, v2f& a2, v2f& a3) {
+    const v2f s02 = a0 + a2, d02 = a0 - a2, s13 = a1 + a3, e13 = a1 - a3;
+    a0 = s02 + s13;
+    a1 = pk_addj(d02, e13);
+    a2 = s02 - s13;
+    a3 = pk_subj(d02, e13);
+}
+__device__ __forceinline__ void pk_idft16(v2f (&v)[16]) {
+    constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R2 = 0.70710678118654752f;
+#pragma unroll
+    for (int m2 = 0; m2 < 4; ++m2) pk_idft4(v[m2], v[4 + m2], v[8 + m2], v[12 + m2]);
+    const v2f w1 = {C1, S1}, w2 = {R2, R2}, w3 = {S1, C1}, w6 = {-R2, R2}, w9 = {-C1, -S1}, zero = {0.f, 0.f};
+    v[5] = pk_cmul_s(v[5], w1);
+    v[9] = pk_cmul_s(v[9], w2);
+    v[13] = pk_cmul_s(v[13], w3);
+    v[6] = pk_cmul_s(v[6], w2);
+    v[10] = pk_addj(zero, v[10]);
+    v[14] = pk_cmul_s(v[14], w6);
+    v[7] = pk_cmul_s(v[7], w3);
+    v[11] = pk_cmul_s(v[11], w6);
+    v[15] = pk_cmul_s(v[15], w9);
+#pragma unroll
+    for (int n1 = 0; n1 < 4; ++n1) pk_idft4(v[4 * n1 + 0], v[4 * n1 + 1], v[4 * n1 + 2], v[4 * n1 + 3]);
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = a + 1; b < 4; ++b) {
+            const v2f t = v[4 * a + b];
+            v[4 * a + b] = v[4 * b + a];
+            v[4 * b + a] = t;
+        }
+}
+__device__ __forceinline__ v2f ldv(const float2* base, uint32_t elem) {
+    const float2 f = ld2(base, elem);
+    return (v2f){f.x, f.y};
+}
+
+template <int FLAGS>
+__global__ __launch_bounds__(1024) void k_probe_pk(const float2* __restrict__ xb, const float2* __restrict__ hc,
+                                                   const int32_t* __restrict__ shifts, const float2* __restrict__ tw1,
+                                                   const float2* __restrict__ tw23, int32_t nfreq, int32_t nhyp,
+                                                   int32_t hyp_per_wg, int32_t nblk, int32_t tiles_per_blk,
+                                                   float* __restrict__ vt) {
+    __shared__ __attribute__((aligned(16))) v2f s_d[F_LDS_DATA];
+    __shared__ v2f s_tw2[16 * 64];
+    __shared__ v2f s_tw3[16 * 4];
+    const int tid = threadIdx.x;
+    const int ngroups = (nhyp + hyp_per_wg - 1) / hyp_per_wg;
+    const int lin = blockIdx.x;
+    const int q = lin >> 3;
+    const int blk = (q / ngroups) * 8 + (lin & 7);
+    const int grp = q - (q / ngroups) * ngroups;
+    if (blk >= nblk) return;
+    const int h0 = grp * hyp_per_wg;
+    const int h1 = min(h0 + hyp_per_wg, nhyp);
+    s_tw2[tid] = ldv(tw23, tid);
+    if (tid < 64) s_tw3[tid] = ldv(tw23, 1024 + tid);
+    const bool nosync = FLAGS & 4;
+    const v2f w = ldv(tw1, (uint32_t)(1024 + tid));
+    const float2* xp = xb + (int64_t)blk * FB;
+    float* vt_blk = vt + (int64_t)blk * tiles_per_blk * nhyp * 64;
+    const float2* hrow_cur;
+    int sh_cur;
+    auto row_of = [&](int h) {
+        const int t = h / nfreq;
+        sh_cur = *((const CAF_AS1 int32_t*)shifts + (h - t * nfreq));
+        hrow_cur = hc + (int64_t)t * FB;
+    };
+    v2f pr[16], xr[16];
+#pragma unroll
+    for (int a = 0; a < 16; ++a) xr[a] = ldv(xp, (uint32_t)(1024 * a + tid));
+    row_of(h0);
+#pragma unroll
+    for (int a = 0; a < 16; ++a) pr[a] = pk_cmul(xr[a], ldv(hrow_cur, (uint32_t)((1024 * a + tid - sh_cur) & (FB - 1))));
+    float acc = 0.f;
+    __syncthreads();
+    for (int h = h0; h < h1; ++h) {
+        const bool more = h + 1 < h1;
+        int64_t hoff = (int64_t)h * 64;
+        asm volatile("" : "+s"(hoff));
+        int lz = 0;
+        asm volatile("" : "+v"(lz));
+        v2f v1[16];
+#pragma unroll
+        for (int a = 0; a < 16; ++a) v1[a] = pr[a];
+        pk_idft16(v1);
+        {
+            v2f p = w;
+            asm volatile("" : "+v"(p));
+            const v2f wj = p;
+            v1[1] = pk_cmul(v1[1], p);
+#pragma unroll
+            for (int n1 = 2; n1 < 16; ++n1) {
+                p = pk_cmul(p, wj);
+                v1[n1] = pk_cmul(v1[n1], p);
+            }
+        }
+        if (nosync) __builtin_amdgcn_wave_barrier(); else __syncthreads();
+        if (!(FLAGS & 32)) {
+            const int off = (tid >> 6) * F_ROW + (tid & 63);
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) s_d[n1 * F_N1 + off] = v1[n1];
+        }
+        if (nosync) __builtin_amdgcn_wave_barrier(); else __syncthreads();
+        row_of(more ? h + 1 : h);
+        v2f v[16];
+        {
+            const int base = (tid >> 6) * F_N1 + (tid & 63);
+            if (!(FLAGS & 32)) {
+#pragma unroll
+                for (int b = 0; b < 16; ++b) v[b] = s_d[base + b * F_ROW];
+            } else {
+#pragma unroll
+                for (int b = 0; b < 16; ++b) v[b] = v1[b];
+            }
+            pk_idft16(v);
+#pragma unroll
+            for (int n2 = 1; n2 < 16; ++n2) v[n2] = pk_cmul(v[n2], (FLAGS & 8) ? w : s_tw2[n2 * 64 + (tid & 63) + lz]);
+            if (!(FLAGS & 32)) {
+#pragma unroll
+                for (int n2 = 0; n2 < 16; ++n2) s_d[base + n2 * F_ROW] = v[n2];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        v2f hn[16];
+        if (!(FLAGS & 2)) {
+#pragma unroll
+            for (int a = 0; a < 16; ++a) hn[a] = ldv(hrow_cur, (uint32_t)(((1024 * a + tid - sh_cur) & (FB - 1)) + lz));
+        } else {
+#pragma unroll
+            for (int a = 0; a < 16; ++a) hn[a] = (v2f){w.x + a, w.y};
+        }
+        {
+            const int base = (tid >> 6) * F_N1 + ((tid >> 2) & 15) * F_ROW + (tid & 3);
+            if (!(FLAGS & 32)) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) v[c] = s_d[base + 4 * c];
+            }
+            pk_idft16(v);
+#pragma unroll
+            for (int n3 = 1; n3 < 16; ++n3) v[n3] = pk_cmul(v[n3], (FLAGS & 8) ? w : s_tw3[n3 * 4 + (tid & 3) + lz]);
+            if (!(FLAGS & 32)) {
+#pragma unroll
+                for (int n3 = 0; n3 < 16; ++n3) s_d[base + 4 * n3] = v[n3];
+            }
+        }
+        if (nosync) __builtin_amdgcn_wave_barrier(); else __syncthreads();
+        {
+            const int n1 = tid & 15, n2 = (tid >> 4) & 15, q4 = tid >> 8;
+            const int base = n1 * F_N1 + n2 * F_ROW;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int n3 = q4 + 4 * i;
+                int lzi = 0;
+                asm volatile("" : "+v"(lzi));
+                v2f a0, a1, a2, a3;
+                if (!(FLAGS & 64)) {
+                    const float4 lo = *reinterpret_cast<const float4*>(&s_d[base + 4 * n3 + lzi]);
+                    const float4 hi = *reinterpret_cast<const float4*>(&s_d[base + 4 * n3 + 2 + lzi]);
+                    a0 = (v2f){lo.x, lo.y}; a1 = (v2f){lo.z, lo.w}; a2 = (v2f){hi.x, hi.y}; a3 = (v2f){hi.z, hi.w};
+                } else {
+                    a0 = v[4 * i]; a1 = v[4 * i + 1]; a2 = v[4 * i + 2]; a3 = v[4 * i + 3];
+                }
+                pk_idft4(a0, a1, a2, a3);
+                const v2f y[4] = {a0, a1, a2, a3};
+#pragma unroll
+                for (int n4 = 0; n4 < 4; ++n4) {
+                    const int tile_u = 16 * i + 64 * n4;
+                    const int tile_t = (n2 >> 2) + 4 * q4;
+                    float* pu = vt_blk + (int64_t)tile_u * nhyp * 64 + hoff;
+                    const uint32_t voff = ((uint32_t)tile_t * (uint32_t)nhyp * 64u + (uint32_t)(n1 + 16 * (n2 & 3))) << 2;
+                    const v2f sq = y[n4] * y[n4];
+                    const float val = sq.x + sq.y;
+                    if (FLAGS & 1)
+                        acc += val;
+                    else if (tile_u + tile_t < tiles_per_blk)
+                        gst1(pu, voff, val);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int a = 0; a < 16; ++a) pr[a] = pk_cmul(xr[a], hn[a]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (FLAGS & 1) vt_blk[tid] = acc;
+}
+
 // Variant 2: the next hypothesis' pass-1 butterfly (X*H product, DFT16, twiddle recurrence: VALU only) is placed
 // INSIDE the LDS-bound stretch, between passes 2 and 3 of the current hypothesis, instead of after pass 4.
 // ORDER 0: P2, P1c(next), P3.   ORDER 1: P1c(next) split: product+DFT16 after P2, recurrence twiddles after P3.
@@ -412,6 +627,33 @@ static void run2(const char* what, float2* xb, float2* hc, int32_t* sh, float2* 
     fflush(stdout);
 }
 
+template <int FLAGS>
+static void run_pk(const char* what, float2* xb, float2* hc, int32_t* sh, float2* tw1, float2* tw23, float* vt, int nblk) {
+    const int nfreq = 256, nhyp = 256, hpw = 64, tiles = 193;
+    const int ngroups = nhyp / hpw;
+    const dim3 grid((unsigned)(ngroups * 8 * ((nblk + 7) / 8)));
+    auto launch = [&]() {
+        hipLaunchKernelGGL((caf::k_probe_pk<FLAGS>), grid, dim3(1024), 0, 0, xb, hc, sh, tw1, tw23, nfreq, nhyp, hpw, nblk, tiles, vt);
+    };
+    launch();
+    (void)hipDeviceSynchronize();
+    float best = 1e9f;
+    for (int r = 0; r < 3; ++r) {
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0);
+        (void)hipEventCreate(&e1);
+        (void)hipEventRecord(e0);
+        launch();
+        (void)hipEventRecord(e1);
+        (void)hipEventSynchronize(e1);
+        float ms;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        best = ms < best ? ms : best;
+    }
+    printf("PACKED flags %3d  %-50s %8.3f ms   %6.2f us per transform per CU\n", FLAGS, what, best, best * 1e3 / ((double)nblk * nhyp / 256.0));
+    fflush(stdout);
+}
+
 int main() {
     const int nblk = 512;  // 2048 workgroups = 8 rounds over 256 CUs
     const size_t FBs = 16384;
@@ -451,6 +693,14 @@ int main() {
 #define AB(F, WHAT)                                              \
     run<0>("full loop", xb, hc, sh, tw1, tw23, vt, nblk);       \
     run<F>(WHAT, xb, hc, sh, tw1, tw23, vt, nblk);
+    run<0>("full loop", xb, hc, sh, tw1, tw23, vt, nblk);
+    run_pk<0>("full loop, packed arithmetic", xb, hc, sh, tw1, tw23, vt, nblk);
+    run<0>("full loop", xb, hc, sh, tw1, tw23, vt, nblk);
+    run_pk<0>("full loop, packed arithmetic", xb, hc, sh, tw1, tw23, vt, nblk);
+    run<111>("arithmetic only", xb, hc, sh, tw1, tw23, vt, nblk);
+    run_pk<111>("arithmetic only, packed", xb, hc, sh, tw1, tw23, vt, nblk);
+    run<7>("- stores - rows - barriers", xb, hc, sh, tw1, tw23, vt, nblk);
+    run_pk<7>("- stores - rows - barriers, packed", xb, hc, sh, tw1, tw23, vt, nblk);
     AB(8192, "row loads issued after pass 3")
     AB(32768, "row loads: 8 before pass 3, 8 after")
     AB(16384, "row loads nontemporal")
