@@ -61,7 +61,7 @@ void scan_tiles(double* tile_sums, int64_t ntiles, hipStream_t st);
 // caf_rows.hip
 void launch_sliding_multiply(const float2* x, int32_t xlen, const float2* y, int64_t ylen, const double* prefix,
                              int64_t start, int64_t step, int64_t rows, double coef, int32_t zero_oor, float2* z,
-                             hipStream_t st, const double* d_coef = nullptr);  // d_coef: launch_cutout_norm's partial sums; coef *= ||x||
+                             hipStream_t st, const double* d_coef = nullptr);  // d_coef: device scalar multiplied into coef (launch_cutout_norm's result)
 // part: optional scratch of rows * rows_argmax_chunks(rows, len) 64-bit words -- long rows are then cut into chunks
 void launch_rows_argmax(const float2* z, int64_t rows, int64_t len, int32_t use_normsq, float scale, uint32_t* argmax,
                         float* maxv, float* plane, hipStream_t st, unsigned long long* part = nullptr);
@@ -112,7 +112,7 @@ int launch_perdelay_fused(const float2* x, int32_t n, const float2* y, int64_t y
                           int64_t num, int32_t zero_oor, float* qf2, uint32_t* fidx, float* plane, float2* cplane,
                           hipStream_t st);
 int cutout_norm_scratch_doubles();
-void launch_cutout_norm(const float2* x, int64_t n, double* parts, hipStream_t st);  // partial sums of |x|^2
+const double* launch_cutout_norm(const float2* x, int64_t n, double* parts, hipStream_t st);  // -> device address of ||x||
 // e^{+j 2 pi q / 16384}, q < 16384: the twiddle table of the in-LDS transforms (caf_ldsfft.h), built once per device
 int lds_fft_twiddles(int device, const float2** out);
 

@@ -309,7 +309,7 @@ int32_t caf_xcorr_perdelay(const float* d_cutout, int32_t n, const float* d_rx, 
     // ||cutout|| in float64 on the device (no host round trip)
     double* d_cnorm = nullptr;
     if ((rc = sc.get(&d_cnorm, cutout_norm_scratch_doubles()))) return rc;
-    launch_cutout_norm((const float2*)d_cutout, n, d_cnorm, st);
+    const double* d_norm = launch_cutout_norm((const float2*)d_cutout, n, d_cnorm, st);
     // rows per batch: up to 2^28 product elements (2 GiB of the 288) in flight, so that even 1e7-sample cutouts go
     // through rocFFT and the argmax a few dozen rows at a time
     if (batch_rows <= 0) batch_rows = std::max<int64_t>(1, std::min<int64_t>(num, ((int64_t)1 << 28) / n));
@@ -324,7 +324,7 @@ int32_t caf_xcorr_perdelay(const float* d_cutout, int32_t n, const float* d_rx, 
         const int64_t nr = std::min(batch_rows, num - r0);
         float2* buf = direct ? direct + r0 * n : rows;
         launch_sliding_multiply((const float2*)d_cutout, n, yv, ylen_v, prefix, start_v + r0 * step, step, nr, 1.0,
-                                zero_oor ? 1 : 0, buf, st, d_cnorm);
+                                zero_oor ? 1 : 0, buf, st, d_norm);
         if ((rc = fft_rows(buf, buf, nr, n, false, st))) return rc;
         if (d_qf2 || d_fidx || d_caf)
             launch_rows_argmax(buf, nr, n, 1, 1.0f, (uint32_t*)(d_fidx ? d_fidx + r0 : nullptr), d_qf2 ? d_qf2 + r0 : nullptr,

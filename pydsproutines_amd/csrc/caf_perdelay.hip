@@ -26,7 +26,7 @@ namespace caf {
 namespace {
 
 // WG threads = max(256, N/16); rows handled concurrently RPW = WG / (N/16); each workgroup walks `rows_per_wg`
-// consecutive groups of RPW rows with the cutout resident in registers.
+// consecutive groups of RPW rows (neighbouring rows share all but one sample of their rx windows: L1/L2 hits).
 template <int LOGN>
 // (4 waves per SIMD: 128 VGPRs, the budget that lets four 256-thread workgroups -- or one of 1024 -- share a CU)
 __global__ __launch_bounds__((1 << LOGN) / 16 > 256 ? (1 << LOGN) / 16 : 256, 4) void k_perdelay_fused(
@@ -45,13 +45,19 @@ __global__ __launch_bounds__((1 << LOGN) / 16 > 256 ? (1 << LOGN) / 16 : 256, 4)
     float2* buf = s_buf + rl * (N + N / 16);
     const int lane = tid & 63, wave = tid >> 6;
 
-    // cutout: 16 points per thread (pass-1 positions), resident; ||x||^2 in float64
-    float2 xr[16];
+    // ||x||^2 in float64 from the thread's 16 cutout points (pass-1 positions).  The cutout stays in registers across
+    // rows where that fits (measured faster for N <= 1024 and N = 16384); for N = 2048 .. 8192 it spilled ~60 registers
+    // per thread to scratch together with the row data, twiddle powers and butterfly temporaries (28 GB of HBM
+    // traffic for 1e6 rows of N = 4096; 12.5 -> 10.9 ms without), so there it is re-read per row -- a few tens of KB
+    // shared by every workgroup, L1/L2-resident.
+    constexpr bool RESIDENT = LOGN <= 10 || LOGN == 14;
+    float2 xr[RESIDENT ? 16 : 1];
     double xs = 0.0;
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
-        xr[t] = x[l + t * NTR];
-        xs += (double)xr[t].x * xr[t].x + (double)xr[t].y * xr[t].y;
+        const float2 a = x[l + t * NTR];
+        if (RESIDENT) xr[t] = a;
+        xs += (double)a.x * a.x + (double)a.y * a.y;
     }
     // sum over the lanes of the row slot that share this wave
     auto wave_sum = [&](double e) {
@@ -79,6 +85,8 @@ __global__ __launch_bounds__((1 << LOGN) / 16 > 256 ? (1 << LOGN) / 16 : 256, 4)
         const bool zero = !live || (oor && zero_oor);
         float2 v[16];
         double es = 0.0;
+        int xo = 0;  // (opaque: keeps the cutout loads inside the row loop)
+        asm volatile("" : "+v"(xo));
         // one 64-bit row pointer, 32-bit offsets; the bounds-checked form only for windows that leave rx
         const float2* yrow = y + s;
         if (!zero && !oor) {
@@ -93,7 +101,7 @@ __global__ __launch_bounds__((1 << LOGN) / 16 > 256 ? (1 << LOGN) / 16 : 256, 4)
         }
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
-            const float2 a = xr[t], b = v[t];
+            const float2 a = RESIDENT ? xr[RESIDENT ? t : 0] : x[l + t * NTR + xo], b = v[t];
             es += (double)b.x * b.x + (double)b.y * b.y;
             // conj(x * y): the inverse butterflies then deliver conj(FFT(x * y))
             v[t] = make_float2(a.x * b.x - a.y * b.y, -(a.x * b.y + a.y * b.x));

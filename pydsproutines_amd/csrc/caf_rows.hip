@@ -32,14 +32,17 @@ __global__ __launch_bounds__(256) void k_cutout_sumsq(const float2* __restrict__
     __syncthreads();
     if (threadIdx.x == 0) parts[blockIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
 }
-__device__ __forceinline__ double norm_from_parts(const double* __restrict__ parts) {
+__global__ void k_cutout_final(double* __restrict__ parts) {  // parts[NORM_PARTS] = sqrt(sum of the partials), fixed order
     double t = 0.0;
     for (int i = 0; i < NORM_PARTS; ++i) t += parts[i];
-    return sqrt(t);
+    parts[NORM_PARTS] = sqrt(t);
 }
-int cutout_norm_scratch_doubles() { return NORM_PARTS; }
-void launch_cutout_norm(const float2* x, int64_t n, double* parts, hipStream_t st) {
+int cutout_norm_scratch_doubles() { return NORM_PARTS + 1; }
+// returns the device address of ||x|| (valid once the two kernels have run on `st`)
+const double* launch_cutout_norm(const float2* x, int64_t n, double* parts, hipStream_t st) {
     hipLaunchKernelGGL(k_cutout_sumsq, dim3(NORM_PARTS), dim3(256), 0, st, x, n, parts);
+    hipLaunchKernelGGL(k_cutout_final, dim3(1), dim3(1), 0, st, parts);
+    return parts + NORM_PARTS;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -63,7 +66,7 @@ __global__ __launch_bounds__(256) void k_sliding_multiply(const float2* __restri
         int64_t b = s + xlen;
         b = b < 0 ? 0 : (b > ylen ? ylen : b);
         const double e = prefix[b] - prefix[a];
-        inv = (float)(1.0 / (sqrt(e) * (d_coef ? coef * norm_from_parts(d_coef) : coef)));
+        inv = (float)(1.0 / (sqrt(e) * (d_coef ? coef * *d_coef : coef)));
     }
     float2* zr = z + row * (int64_t)xlen;
     for (int t = blockIdx.x * 256 + threadIdx.x; t < xlen; t += gridDim.x * 256) {

@@ -100,6 +100,29 @@ def w_c4_share():
     return caf("persistent", False, T=64, F=512, reps=1, rows=False)
 
 
+def w_c2_long_template():
+    """C2 shape with a 16384-sample template: 32768-point blocks = two chained 16384-point in-LDS transforms."""
+    n = 16384
+    t = qpsk(rng, n)
+    d_rx = asarray(cn(rng, M))
+    plan = CAFPlan(t, max_rx_len=M, bins=np.arange(-128, 128), grid=16384)
+    res = None
+    for _ in range(2):
+        res = plan.run(d_rx, surface=True, out=res)
+    sync()
+    Sn = M - n + 1
+    B, step = plan.block, plan.step
+    nblk = -(-Sn // step)
+    tiles = -(-step // 64)
+    # compulsory HBM bytes: |y|^2 tiles written + read, surface written, block spectra read once (their per-hypothesis
+    # re-reads are L2 / Infinity-Cache traffic: visible in FETCH_SIZE, not algorithmic)
+    alg = nblk * (tiles * 64 * 256 * 4.0 + 8.0 * B) + Sn * 256 * 8.0 + Sn * 12.0
+    flops = nblk * 256 * (2 * 5.0 * 16384 * 14 + 6.0 * B + 10.0 * 16384 + 3.0 * step)
+    plan.close()
+    return [("k_caf_persistent", "one-launch engine, N=16384 (B=32768 as 2 x 16384), F=256, surface", alg, flops, 2),
+            ("k_parity_major", "block spectra -> parity-major (8 B read + 8 B written per point)", nblk * B * 16.0, 0.0, 2)]
+
+
 def w_c5_zoom():
     from pydsproutines_amd.zoom import caf_with_zoom
 
