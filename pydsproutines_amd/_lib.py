@@ -168,11 +168,42 @@ EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 _lib = None
 
 
+def _share_rocm_runtime_with_torch():
+    """One HIP runtime per process.
+
+    PyTorch-ROCm wheels bundle their own libamdhip64.so / libhsa-runtime64.so / librocfft.so under torch/lib and ask
+    for them by file name ("libamdhip64.so", RPATH $ORIGIN), while libcaf.so asks for the soname ("libamdhip64.so.7").
+    If torch is imported AFTER libcaf.so has pulled in the system ROCm, the dynamic linker does not recognise the two
+    as the same library and the process ends up with two HIP + two HSA runtimes: torch then reports "no ROCm-capable
+    device" and the interpreter aborts in free() while both tear down at exit.  With the bundled copies loaded first,
+    libcaf's soname requests and torch's file-name requests resolve to the same objects in either import order.
+    Nothing is imported from torch here; CAF_SYSTEM_ROCM=1 keeps the system runtime (a process that never loads torch).
+    """
+    import sys
+
+    if os.environ.get("CAF_SYSTEM_ROCM") == "1" or "torch" in sys.modules:
+        return  # torch already loaded: its runtime is in the process and libcaf's sonames bind to it
+    try:
+        import importlib.util
+
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so", "librocfft.so", "librccl.so"):  # rccl: caf_comm_* dlopens its soname
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            ct.CDLL(path)  # RTLD_LOCAL: global scope would interpose the amd::smi statics of libamd_smi
+
+
 def load():
     """Load libcaf.so (once).  Raises OSError with build instructions if absent."""
     global _lib
     if _lib is not None:
         return _lib
+    _share_rocm_runtime_with_torch()
     try:
         lib = np.ctypeslib.load_library("libcaf", _HERE)
     except OSError as e:

@@ -33,8 +33,10 @@ const Rccl* rccl() {
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
-        void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        // RTLD_LOCAL on purpose: a global RCCL (and its librocm_smi64) interposes the amd::smi statics that
+        // libamd_smi repeats, and both then run their destructors over one object at exit ("double free").
+        void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
         if (!h) return;
         r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
         r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
