@@ -74,3 +74,33 @@ def test_product_never_imports_oracle():
         if fn.endswith(".py"):
             src = open(os.path.join(pkg, fn)).read()
             assert not re.search(r"^\s*(import|from)\s+oracle\b", src, re.M), fn
+
+
+def test_one_rocm_runtime_per_process_in_either_import_order():
+    """libcaf then torch, and torch then libcaf, each leave ONE libamdhip64 / libhsa-runtime64 / librocfft / librccl
+    in the process and exit cleanly (two copies abort in free() at interpreter exit and break torch's device probe)."""
+    import subprocess
+    import sys
+
+    body = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "%s\n"
+        "import collections\n"
+        "seen = collections.defaultdict(set)\n"
+        "for line in open('/proc/self/maps'):\n"
+        "    path = line.split()[-1]\n"
+        "    base = path.rsplit('/', 1)[-1]\n"
+        "    for stem in ('libamdhip64.so', 'libhsa-runtime64.so', 'librocfft.so', 'librccl.so'):\n"
+        "        if base.startswith(stem):\n"
+        "            seen[stem].add(path)\n"
+        "assert seen['libamdhip64.so'], 'no HIP runtime loaded?'\n"
+        "dup = {k: sorted(v) for k, v in seen.items() if len(v) > 1}\n"
+        "assert not dup, dup\n"
+        "print('single runtime')\n"
+    )
+    first = "from pydsproutines_amd import _lib; _lib.load(); import torch"
+    second = "import torch; from pydsproutines_amd import _lib; _lib.load()"
+    for order in (first, second):
+        r = subprocess.run([sys.executable, "-c", body % (ROOT, order)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (order, r.stdout, r.stderr)
+        assert "single runtime" in r.stdout
