@@ -57,13 +57,34 @@ __device__ __forceinline__ float4 gld4(const float* base, uint32_t byteoff) {
 __device__ __forceinline__ float gld1(const float* base, uint32_t byteoff) {
     return *reinterpret_cast<const CAF_AS1 float*>((const CAF_AS1 char*)base + byteoff);
 }
-__device__ __forceinline__ void gst1(float* base, uint32_t byteoff, float v) {
-    *reinterpret_cast<CAF_AS1 float*>((CAF_AS1 char*)base + byteoff) = v;
-}
 // write-through store (sc1): visible device-wide once it has completed, without an L2 write-back fence
 __device__ __forceinline__ void gst1_wt(float* base, uint32_t byteoff, float v) {
     __hip_atomic_store(reinterpret_cast<CAF_AS1 float*>((CAF_AS1 char*)base + byteoff), v, __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// a pointer whose value is wave-uniform, moved (back) into scalar registers
+template <typename Tp>
+__device__ __forceinline__ Tp* uniform_ptr(Tp* p) {
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return reinterpret_cast<Tp*>(((uint64_t)hi << 32) | lo);
+}
+// raw buffer descriptor (gfx9 family: DATA_FORMAT = 32 in word 3) over [base, base + bytes)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_of(const void* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+// sc1 in the cache-policy operand of buffer instructions: device-scope coherent (write-through store / load that is not
+// served from a stale line of this XCD's L2)
+constexpr int CAF_AUX_SC1 = 16;
+// A |y|^2 tile store: uniform descriptor + uniform (SGPR) offset + one per-thread 32-bit offset.  The descriptor covers
+// exactly the valid tiles of the block, so a store to a tile past the end (the last 63 of the 256 tiles of a block whose
+// step is 12289 delays) is dropped by the hardware range check -- which on gfx950 includes the SGPR offset
+// (scripts/ubench/buffer_bounds.hip) -- instead of being branched around 16 times per hypothesis.
+template <int MODE>
+__device__ __forceinline__ void tile_store(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, float val) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, val), r, (int)voff, (int)soff, MODE == 1 ? CAF_AUX_SC1 : 0);
 }
 
 // |y|^2 tiles: vt[blk_local][s_tile][h][64]  (s_tile = delay/64 inside the block)
@@ -105,6 +126,7 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
 #pragma unroll
     for (int j = 0; j < BPT; ++j) w[j] = ld2(tw1, (uint32_t)(1024 + tid + j * FT));
     float* vt_blk = vt + (int64_t)blk * tiles_per_blk * nhyp * 64;
+    const __amdgpu_buffer_rsrc_t rvt = buf_of(uniform_ptr(vt_blk), (uint32_t)tiles_per_blk * (uint32_t)nhyp * 256u);
 
     // row of the template-spectrum table used by hypothesis h (uniform) and its circular shift
     const float2* hrow_cur;
@@ -139,7 +161,7 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
         const bool more = h + 1 < h1;
         // h*64 as an opaque scalar: otherwise loop-strength-reduction turns the 32 store addresses of pass 4
         // into 32 64-bit induction variables (64 VGPRs + 32 adds per hypothesis)
-        int64_t hoff = (int64_t)h * 64;
+        uint32_t hoff = (uint32_t)h * 256u;  // bytes
         asm volatile("" : "+s"(hoff));
         int lz = 0;  // an opaque zero added to loop-invariant LDS table indices (see pass 1)
         asm volatile("" : "+v"(lz));
@@ -270,7 +292,7 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
                 for (int n4 = 0; n4 < 4; ++n4) {
                     const int tile_u = 16 * i + 64 * n4;                      // uniform part of the tile index
                     const int tile_t = (n2 >> 2) + 4 * q;                     // per-thread part
-                    float* pu = vt_blk + (int64_t)tile_u * nhyp * 64 + hoff;  // uniform (scalar) base
+                    const uint32_t soff = (uint32_t)tile_u * (uint32_t)nhyp * 256u + hoff;  // uniform (scalar) offset
                     const uint32_t voff = ((uint32_t)tile_t * (uint32_t)nhyp * 64u + (uint32_t)(n1 + 16 * (n2 & 3))) << 2;
                     const float val = y[n4].x * y[n4].x + y[n4].y * y[n4].y;
                     if (MODE == 2) {
@@ -283,11 +305,8 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
                         const uint32_t sh8 = 8u * (uint32_t)(oo & 3);
                         const uint32_t repl = (bi[oo >> 2] & ~(0xffu << sh8)) | ((uint32_t)(h - h0) << sh8);
                         bi[oo >> 2] = up ? repl : bi[oo >> 2];
-                    } else if (tile_u + tile_t < tiles_per_blk) {
-                        if (MODE == 1)
-                            gst1_wt(pu, voff, val);
-                        else
-                            gst1(pu, voff, val);
+                    } else {
+                        tile_store<MODE>(rvt, voff, soff, val);  // tiles >= tiles_per_blk: dropped by the range check
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);  // keep the four sub-steps from being co-scheduled (registers)
@@ -342,6 +361,7 @@ __device__ __forceinline__ void fused_item2(float2* __restrict__ s_d, const floa
     const float2 w = ld2(tw1, (uint32_t)(1024 + tid));  // pass-1 twiddle base e^{+j 2 pi m2 / 16384}
     const float2* xp = xb + (int64_t)blk * FB2;
     float* vt_blk = vt + (int64_t)blk * tiles_per_blk * nhyp * 64;
+    const __amdgpu_buffer_rsrc_t rvt = buf_of(uniform_ptr(vt_blk), (uint32_t)tiles_per_blk * (uint32_t)nhyp * 256u);
     // combination twiddle base e^{+j 2 pi nb / 32768}, nb = n1 + 16 n2 + 256 q (the thread's pass-4 position, < 1024)
     const int n1o = tid & 15, n2o = (tid >> 4) & 15, qo = tid >> 8;
     float2 wb;
@@ -372,7 +392,7 @@ __device__ __forceinline__ void fused_item2(float2* __restrict__ s_d, const floa
     float2 e[16];  // E's outputs (register 4 i + n4 <-> n3 = q + 4 i, n4)
 
     for (int h = h0; h < h1; ++h) {
-        int64_t hoff = (int64_t)h * 64;
+        uint32_t hoff = (uint32_t)h * 256u;  // bytes
         asm volatile("" : "+s"(hoff));
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
@@ -463,16 +483,12 @@ __device__ __forceinline__ void fused_item2(float2* __restrict__ s_d, const floa
                         const float2 ylo = cadd(e[4 * i + n4], t), yhi = csub(e[4 * i + n4], t);
                         const int tile_u = 16 * i + 64 * n4;
                         const int tile_t = (n2o >> 2) + 4 * qo;
-                        float* pu = vt_blk + (int64_t)tile_u * nhyp * 64 + hoff;
+                        const uint32_t soff = (uint32_t)tile_u * (uint32_t)nhyp * 256u + hoff;  // uniform (scalar) offset
                         const uint32_t voff = ((uint32_t)tile_t * (uint32_t)nhyp * 64u + (uint32_t)(n1o + 16 * (n2o & 3))) << 2;
                         const uint32_t voff_hi = voff + (((uint32_t)256 * (uint32_t)nhyp * 64u) << 2);  // n + 16384: tile + 256
                         const float vlo = ylo.x * ylo.x + ylo.y * ylo.y, vhi = yhi.x * yhi.x + yhi.y * yhi.y;
-                        if (tile_u + tile_t < tiles_per_blk) {
-                            if (MODE == 1) gst1_wt(pu, voff, vlo); else gst1(pu, voff, vlo);
-                        }
-                        if (256 + tile_u + tile_t < tiles_per_blk) {
-                            if (MODE == 1) gst1_wt(pu, voff_hi, vhi); else gst1(pu, voff_hi, vhi);
-                        }
+                        tile_store<MODE>(rvt, voff, soff, vlo);      // tiles >= tiles_per_blk: dropped by the range check
+                        tile_store<MODE>(rvt, voff_hi, soff, vhi);
                     }
                     // four positions of the next E half's inputs, into the registers the combination just freed
 #pragma unroll
@@ -692,13 +708,6 @@ __global__ __launch_bounds__(256) void k_transpose_norm_argmax(
     }
 }
 
-template <typename Tp>
-__device__ __forceinline__ Tp* uniform_ptr(Tp* p) {
-    const uint64_t v = reinterpret_cast<uint64_t>(p);
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
-    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-    return reinterpret_cast<Tp*>(((uint64_t)hi << 32) | lo);
-}
 
 // ----------------------------------------------------------------------------------------
 // Work-queue kernel: BOTH stages in one launch, overlapped across CUs.
@@ -762,14 +771,9 @@ __device__ __forceinline__ const CAF_AS4 PersistParams* params_of(const PersistP
     asm volatile("" : "+s"(v));
     return reinterpret_cast<const CAF_AS4 PersistParams*>(v);
 }
-// raw buffer descriptor (gfx9 family: DATA_FORMAT = 32 in word 3) over [base, base + bytes)
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_of(const void* base, uint32_t bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
-}
 // Cache policy of the |y|^2 tile reads: sc1 = device-scope coherent load.  The tiles were written during the SAME
 // launch by workgroups on other XCDs (each XCD has its own L2) with write-through stores; the readers must not be
 // served from a line their own L2 may still hold.  (Measured: no cost against plain loads.)
-constexpr int CAF_AUX_SC1 = 16;
 // 16-byte vector stores to addresses that are only 4-byte aligned (delay offsets are arbitrary)
 typedef float v4f_u_t __attribute__((ext_vector_type(4), aligned(4)));
 typedef int v4i_u_t __attribute__((ext_vector_type(4), aligned(4)));
@@ -1290,6 +1294,7 @@ __global__ __launch_bounds__(1024) void k_caf_persistent(const PersistParams* __
     const bool lane0 = (tid & 63) == 0;
     // per-workgroup role statistics for CAF_PERSIST_DEBUG (100 MHz wall clock; wave 0 only)
     uint64_t tmark = STATS ? wall_clock64() : 0;
+    const uint32_t t_start = (uint32_t)tmark;
     uint32_t t_claim = 0, t_fft = 0, t_tile = 0, c_fft = 0, c_tile = 0;
     for (;;) {
         if (wave_id == 0) {
@@ -1359,6 +1364,8 @@ __global__ __launch_bounds__(1024) void k_caf_persistent(const PersistParams* __
                 pq_mark(pp, 2, (int)t_tile);
                 pq_mark(pp, 3, (int)c_fft);
                 pq_mark(pp, 4, (int)c_tile);
+                pq_mark(pp, 5, (int)t_start);
+                pq_mark(pp, 6, (int)(uint32_t)wall_clock64());
             }
             break;
         }

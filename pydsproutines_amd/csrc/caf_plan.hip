@@ -735,6 +735,10 @@ int32_t caf_plan_execute(caf_plan p, const float* d_rx, int64_t rx_len, int64_t 
                 if (2 * (int64_t)T * gpt <= (int64_t)T * F) ns_gpt = gpt;
             }
         }
+        // the |y|^2 tiles of one block are addressed with 32-bit byte offsets (descriptor + SGPR + VGPR offset)
+        CAF_REQUIRE(ns_gpt || (int64_t)(p->B / 64) * T * F * 256 < ((int64_t)1 << 32),
+                    "too many hypotheses (templates x frequencies) for one launch with |y|^2 tiles: ask for no surface, "
+                    "or split the templates over several plans");
         const int nb_launch = ns_gpt ? p->nb_nosurf : p->nb;  // blocks per launch
         for (int64_t b0 = 0; p->persistent && b0 < nblk; b0 += nb_launch) {
             const int32_t nbk = (int32_t)std::min<int64_t>(nb_launch, nblk - b0);
@@ -781,7 +785,11 @@ int32_t caf_plan_execute(caf_plan p, const float* d_rx, int64_t rx_len, int64_t 
             h.n_tr = nbk * h.ipb;
             // both stages are one kernel: its time is booked on the multiply/FFT stage
             int32_t* h_dbg = nullptr;
-            if (getenv("CAF_PERSIST_DEBUG")) {  // host-mapped role statistics, 8 ints per workgroup
+            // CAF_PERSIST_DEBUG=1: role statistics of every launch; =2: of every 10th launch only, so that the nine before it
+            // run back to back with the plain kernel (the report waits for the launch, which idles the GPU)
+            static int dbg_launches = 0;
+            const char* dbg_env = getenv("CAF_PERSIST_DEBUG");
+            if (dbg_env && (atoi(dbg_env) < 2 || ++dbg_launches % 10 == 0)) {  // host-mapped, 8 ints per workgroup
                 (void)hipHostMalloc((void**)&h_dbg, sizeof(int32_t) * 8 * (size_t)p->n_cus, hipHostMallocMapped);
                 std::memset(h_dbg, 0, sizeof(int32_t) * 8 * (size_t)p->n_cus);
                 (void)hipHostGetDevicePointer((void**)&h.dbg, h_dbg, 0);
@@ -812,8 +820,14 @@ int32_t caf_plan_execute(caf_plan p, const float* d_rx, int64_t rx_len, int64_t 
                     ++cnt[pref];
                     for (int k = 0; k < 5; ++k) sum[pref][k] += h_dbg[8 * w + k];
                 }
-                fprintf(stderr, "[caf persistent] n_fft=%d n_tr=%d | fft_next=%d tr_next=%d watchdog=%d,%d\n", h.n_fft, h.n_tr,
-                        q[0], q[1], q[2], q[3]);
+                uint32_t t0 = 0xffffffffu, t1 = 0, tl = 0;
+                for (int w = 0; w < p->n_cus; ++w) {
+                    t0 = std::min(t0, (uint32_t)h_dbg[8 * w + 5]);
+                    tl = std::max(tl, (uint32_t)h_dbg[8 * w + 5]);
+                    t1 = std::max(t1, (uint32_t)h_dbg[8 * w + 6]);
+                }
+                fprintf(stderr, "[caf persistent] n_fft=%d n_tr=%d | fft_next=%d tr_next=%d watchdog=%d,%d | first start -> last end "
+                        "%.0f us, last start +%.0f us\n", h.n_fft, h.n_tr, q[0], q[1], q[2], q[3], (t1 - t0) / 100.0, (tl - t0) / 100.0);
                 for (int r = 0; r < 2; ++r)
                     if (cnt[r])
                         fprintf(stderr,

@@ -4,7 +4,8 @@
 set -e
 ENGINE=${1:-auto}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$REPO/gpurun_out/pmc_sq
+OUT=$REPO/gpurun_out/pmc_sq_$ENGINE
+export PMC_SQ_OUT=$OUT
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 i=0
@@ -13,9 +14,9 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
   rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/g$i -- python3 $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-side-figure --engine $ENGINE > $OUT/b$i.json 2> $OUT/e$i.err || { tail -5 $OUT/e$i.err; exit 1; }
 done
 cd $REPO
-python3 - <<'PY'
+python3 - > $OUT/summary.txt <<'PY'
 import csv, glob, collections, os
-out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out", "pmc_sq")
+out = os.environ["PMC_SQ_OUT"]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/g*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
@@ -27,3 +28,4 @@ for k, d in acc.items():
     for c, v in sorted(d.items()):
         print("   %-24s %16.0f  (n=%d)" % (c, sum(v) / len(v), len(v)))
 PY
+cat $OUT/summary.txt
