@@ -16,6 +16,12 @@
 #include <vector>
 
 namespace caf {
+__device__ __forceinline__ void gst1(float* base, uint32_t byteoff, float v) {
+    *reinterpret_cast<CAF_AS1 float*>((CAF_AS1 char*)base + byteoff) = v;
+}
+// flag 65536: wave stagger.  g_st[0] / g_st[1] = units of 64 cycles that the second wave group sleeps after B2 / B3,
+// g_st[2] = 1: the first group runs at priority 3, g_st[3] = how the groups are formed (0: waves 8..15, 1: waves with bit 2)
+__device__ int g_st[8];
 
 template <int FLAGS>
 __global__ __launch_bounds__(1024) void k_probe(const float2* __restrict__ xb, const float2* __restrict__ hc,
@@ -61,6 +67,10 @@ __global__ __launch_bounds__(1024) void k_probe(const float2* __restrict__ xb, c
 #pragma unroll
     for (int a = 0; a < 16; ++a) pr[a] = cmul(xr[a], ld2(hrow_cur, (uint32_t)((1024 * a + tid - sh_cur) & (FB - 1))));
     float acc = 0.f;
+    const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int st_a = (FLAGS & 65536) ? g_st[0] : 0, st_b = (FLAGS & 65536) ? g_st[1] : 0;
+    const bool grp_b = (FLAGS & 65536) && (g_st[3] ? ((wave_id >> 2) & 1) : (wave_id >> 3));
+    if ((FLAGS & 65536) && g_st[2] && !grp_b) __builtin_amdgcn_s_setprio(3);
     __syncthreads();
 
     for (int h = h0; h < h1; ++h) {
@@ -93,6 +103,8 @@ __global__ __launch_bounds__(1024) void k_probe(const float2* __restrict__ xb, c
             }
         }
         bar(2);
+        if ((FLAGS & 65536) && grp_b)
+            for (int i = 0; i < st_a; ++i) __builtin_amdgcn_s_sleep(1);
         row_of(more ? h + 1 : h);
         float2 v[16];
         {
@@ -162,6 +174,8 @@ __global__ __launch_bounds__(1024) void k_probe(const float2* __restrict__ xb, c
             for (int a = 8; a < 16; ++a) hload(a);
         }
         bar(3);
+        if ((FLAGS & 65536) && grp_b)
+            for (int i = 0; i < st_b; ++i) __builtin_amdgcn_s_sleep(1);
         {
             const int n1 = tid & 15, n2 = (tid >> 4) & 15, q4 = tid >> 8;
             const int base = n1 * F_N1 + n2 * F_ROW;
@@ -569,13 +583,14 @@ __global__ __launch_bounds__(1024) void k_probe2(const float2* __restrict__ xb, 
 
 }  // namespace caf
 
+static int g_threads = 1024;  // (arithmetic-only variants also run with fewer waves per workgroup)
 template <int FLAGS>
 static void run(const char* what, float2* xb, float2* hc, int32_t* sh, float2* tw1, float2* tw23, float* vt, int nblk) {
     const int nfreq = 256, nhyp = 256, hpw = 64, tiles = 193;
     const int ngroups = nhyp / hpw;
     const dim3 grid((unsigned)(ngroups * 8 * ((nblk + 7) / 8)));
     auto launch = [&]() {
-        hipLaunchKernelGGL((caf::k_probe<FLAGS>), grid, dim3(1024), 0, 0, xb, hc, sh, tw1, tw23, nfreq, nhyp, hpw, nblk, tiles, vt);
+        hipLaunchKernelGGL((caf::k_probe<FLAGS>), grid, dim3(g_threads), 0, 0, xb, hc, sh, tw1, tw23, nfreq, nhyp, hpw, nblk, tiles, vt);
     };
     launch();
     (void)hipDeviceSynchronize();
@@ -690,6 +705,34 @@ int main() {
 
     // the chip's clock sags over the first seconds of load: warm up, then measure every variant right after a baseline
     for (int r = 0; r < 12; ++r) run<0>("full loop (warm-up)", xb, hc, sh, tw1, tw23, vt, nblk);
+    if (getenv("PROBE_WAVES")) {
+        // does the butterfly arithmetic need four waves per SIMD?  (no memory, no LDS, no barriers; time is per workgroup
+        // of g_threads threads: at a wave-count-independent issue rate it scales with the thread count)
+        for (int t : {1024, 768, 512, 256}) {
+            g_threads = t;
+            char what[96];
+            snprintf(what, sizeof(what), "arithmetic only, %d threads per workgroup (%d waves per SIMD)", t, t / 256);
+            run<111>(what, xb, hc, sh, tw1, tw23, vt, nblk);
+        }
+        g_threads = 1024;
+        return 0;
+    }
+    if (getenv("PROBE_STAGGER")) {
+        // wave stagger sweep: sleep units after B2 / B3 for the second wave group, priorities, group shapes
+        for (int grp = 0; grp < 2; ++grp)
+            for (int prio = 0; prio < 2; ++prio)
+                for (int ka : {0, 4, 8, 12, 16, 24, 32})
+                    for (int kb : {0, 8, 16}) {
+                        if (ka == 0 && kb == 0 && !prio) continue;
+                        const int st[8] = {ka, kb, prio, grp, 0, 0, 0, 0};
+                        (void)hipMemcpyToSymbol(HIP_SYMBOL(caf::g_st), st, sizeof(st));
+                        char what[96];
+                        snprintf(what, sizeof(what), "stagger: groups %d prio %d sleep %2d after B2, %2d after B3", grp, prio, ka, kb);
+                        run<0>("full loop", xb, hc, sh, tw1, tw23, vt, nblk);
+                        run<65536>(what, xb, hc, sh, tw1, tw23, vt, nblk);
+                    }
+        return 0;
+    }
 #define AB(F, WHAT)                                              \
     run<0>("full loop", xb, hc, sh, tw1, tw23, vt, nblk);       \
     run<F>(WHAT, xb, hc, sh, tw1, tw23, vt, nblk);
