@@ -504,7 +504,7 @@ def main():
                 flops_per_launch / (st["spectral_conj_multiply"]["avg_ms"] * 1e-3) / 1e12
                 if st["spectral_conj_multiply"]["avg_ms"] > 0 else 0.0)
             st["magsq_norm_argmax"]["kernel"] = "k_transpose_norm_argmax"
-        for name in ("fft_forward(rocFFT)", "fft_inverse(rocFFT)", "energy_prefix", "gather_blocks", "peak_reduce"):
+        for name in ("fft_forward", "fft_inverse(rocFFT)", "energy_prefix", "gather_blocks", "peak_reduce"):
             ms, n = stages[name]
             st[name] = {"avg_ms": ms / max(n, 1), "launches": n}
         stage_total = {k: v["avg_ms"] * v["launches"] / args.steps for k, v in st.items()}

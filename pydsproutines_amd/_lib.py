@@ -42,7 +42,7 @@ CAF_NUM_STAGES = 7
 STAGE_NAMES = (
     "energy_prefix",
     "gather_blocks",
-    "fft_forward(rocFFT)",
+    "fft_forward",
     "spectral_conj_multiply",
     "fft_inverse(rocFFT)",
     "magsq_norm_argmax",

@@ -207,6 +207,67 @@ int lds_fft_twiddles(int device, const float2** out) {
     return CAF_OK;
 }
 
+// ----------------------------------------------------------------------------------------
+// Forward spectra of the overlap-save blocks of the LDS engines (B = 16384): X[b][m] = sum_n rx[src0 + b step + n]
+// e^{-j 2 pi m n / B} (zeros past the end of rx), unnormalised -- gather + transform in ONE launch, one workgroup per
+// block, instead of k_gather_blocks (8 B written + 8 B read back per point) followed by ~60 batched rocFFT launches.
+// forward = conj(IDFT(conj x)) on the shared in-LDS transform.  Replaces cuFFT's forward plan of the reference's
+// batched xcorr (xcorrRoutines.py:1221-1232) on the hot path; rocFFT keeps the one-off template spectra.
+// ----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_block_spectra(const float2* __restrict__ rx, int64_t rx_len, int64_t src0,
+                                                        int32_t step, const float2* __restrict__ tw,
+                                                        float2* __restrict__ xb) {
+    constexpr int LOGN = 14, N = 1 << LOGN, NTR = N / 16;
+    extern __shared__ __attribute__((aligned(16))) float2 s_bs[];
+    const int l = threadIdx.x;
+    const int64_t s0 = src0 + (int64_t)blockIdx.x * step;
+    float2 v[16];
+    if (s0 + N <= rx_len) {
+        const float2* p = rx + s0;  // whole block inside rx: one 64-bit base, 32-bit offsets
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const float2 x = p[l + t * NTR];
+            v[t] = make_float2(x.x, -x.y);
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int64_t i = s0 + l + t * NTR;
+            float2 x = make_float2(0.f, 0.f);
+            if (i < rx_len) x = rx[i];
+            v[t] = make_float2(x.x, -x.y);
+        }
+    }
+    pd_fft<LOGN>(s_bs, tw, l, v);
+    float2* o = xb + (int64_t)blockIdx.x * N;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[pd_out_index<LOGN>(l, r)] = make_float2(v[r].x, -v[r].y);
+}
+
+int launch_block_spectra(const float2* rx, int64_t rx_len, int64_t src0, int32_t step, int64_t nblk, float2* xb,
+                         hipStream_t st) {
+    int dev = 0;
+    CAF_HIP_TRY(hipGetDevice(&dev));
+    const float2* tw = nullptr;
+    const int rc = lds_fft_twiddles(dev, &tw);
+    if (rc) return rc;
+    const size_t lds = (size_t)(16384 + 1024) * sizeof(float2);
+    static std::mutex mu;
+    static std::vector<char> attr_set;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if ((int)attr_set.size() <= dev) attr_set.resize(dev + 1, 0);
+        if (!attr_set[dev]) {
+            CAF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_block_spectra),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set[dev] = 1;
+        }
+    }
+    hipLaunchKernelGGL(k_block_spectra, dim3((unsigned)nblk), dim3(1024), lds, st, rx, rx_len, src0, step, tw, xb);
+    CAF_HIP_TRY(hipGetLastError());
+    return CAF_OK;
+}
+
 namespace {
 
 template <int LOGN>

@@ -707,14 +707,27 @@ int32_t caf_plan_execute(caf_plan p, const float* d_rx, int64_t rx_len, int64_t 
     const int64_t nblk_pad = (nblk + p->nb - 1) / p->nb * p->nb;
     // overlap-save blocks of rx -> spectra X[b] for every block of this call
     const int64_t nfwd = ((p->fused ? nblk : nblk_pad) + p->fwd_chunk - 1) / p->fwd_chunk;
-    p->stage_begin(1, st);
-    launch_gather_blocks(rx, rx_len, shift_start, p->step, p->B, (int32_t)(nfwd * p->fwd_chunk), p->d_xb, st);
-    p->stage_end(st);
-    for (int64_t c = 0; c < nfwd; ++c) {
+    // LDS engines with 16384-point blocks: gather + forward transform in one launch of the in-LDS FFT
+    // (CAF_FWD_ROCFFT=1: the gather kernel + batched rocFFT transforms that every other block size uses)
+    static const bool fwd_rocfft = [] {
+        const char* e = getenv("CAF_FWD_ROCFFT");
+        return e && atoi(e);
+    }();
+    if (p->fused && p->B == 16384 && !fwd_rocfft) {
         p->stage_begin(2, st);
-        int rc = p->fwd.exec(p->d_xb + c * p->fwd_chunk * (int64_t)p->B, nullptr, st);
+        const int rc = launch_block_spectra(rx, rx_len, shift_start, p->step, nfwd * p->fwd_chunk, p->d_xb, st);
         p->stage_end(st);
         if (rc) return rc;
+    } else {
+        p->stage_begin(1, st);
+        launch_gather_blocks(rx, rx_len, shift_start, p->step, p->B, (int32_t)(nfwd * p->fwd_chunk), p->d_xb, st);
+        p->stage_end(st);
+        for (int64_t c = 0; c < nfwd; ++c) {
+            p->stage_begin(2, st);
+            int rc = p->fwd.exec(p->d_xb + c * p->fwd_chunk * (int64_t)p->B, nullptr, st);
+            p->stage_end(st);
+            if (rc) return rc;
+        }
     }
     if (p->fused && p->B == 32768)  // block spectra parity-major for the two chained half-transforms
         launch_parity_major(p->d_xb, p->d_xb2, nfwd * p->fwd_chunk, p->B / 2, st);

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(1024) void k_probe(const float2* __restrict__ xb, c
                 v1[n1] = cmul(v1[n1], p);
             }
         }
-        bar(1);
+        if (!(FLAGS & 131072)) bar(1);
         {
             const int off = (tid >> 6) * F_ROW + (tid & 63);
             if (!(FLAGS & 32)) {
@@ -180,13 +180,30 @@ __global__ __launch_bounds__(1024) void k_probe(const float2* __restrict__ xb, c
             const int n1 = tid & 15, n2 = (tid >> 4) & 15, q4 = tid >> 8;
             const int base = n1 * F_N1 + n2 * F_ROW;
             __builtin_amdgcn_sched_barrier(0);
+            // flag 131072: B1 directly after the pass-4 reads (all 16 values in registers), so that the stretch up to B2
+            // holds pass-4 arithmetic + stores + next products + pass-1 butterfly + pass-1 writes with no barrier between
+            float4 lo_all[4], hi_all[4];
+            if (FLAGS & 131072) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int n3 = q4 + 4 * i;
+                    lo_all[i] = *reinterpret_cast<const float4*>(&s_d[base + 4 * n3 + lz]);
+                    hi_all[i] = *reinterpret_cast<const float4*>(&s_d[base + 4 * n3 + 2 + lz]);
+                }
+                bar(1);
+                if ((FLAGS & 65536) && grp_b)
+                    for (int i = 0; i < g_st[4]; ++i) __builtin_amdgcn_s_sleep(1);
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int n3 = q4 + 4 * i;
                 int lzi = 0;
                 asm volatile("" : "+v"(lzi));
                 float4 lo, hi;
-                if (!(FLAGS & 64)) {
+                if (FLAGS & 131072) {
+                    lo = lo_all[i];
+                    hi = hi_all[i];
+                } else if (!(FLAGS & 64)) {
                     lo = *reinterpret_cast<const float4*>(&s_d[base + 4 * n3 + lzi]);
                     hi = *reinterpret_cast<const float4*>(&s_d[base + 4 * n3 + 2 + lzi]);
                 } else {
@@ -715,6 +732,24 @@ int main() {
             run<111>(what, xb, hc, sh, tw1, tw23, vt, nblk);
         }
         g_threads = 1024;
+        return 0;
+    }
+    if (getenv("PROBE_EARLY_B1")) {
+        for (int rep = 0; rep < 2; ++rep) {
+            run<0>("full loop", xb, hc, sh, tw1, tw23, vt, nblk);
+            run<131072>("B1 right after the pass-4 reads", xb, hc, sh, tw1, tw23, vt, nblk);
+        }
+        for (int grp = 0; grp < 2; ++grp)
+            for (int prio = 0; prio < 2; ++prio)
+                for (int k1 : {4, 8, 12, 16, 24})
+                    for (int ka : {0, 8}) {
+                        const int st[8] = {ka, 0, prio, grp, k1, 0, 0, 0};
+                        (void)hipMemcpyToSymbol(HIP_SYMBOL(caf::g_st), st, sizeof(st));
+                        char what[96];
+                        snprintf(what, sizeof(what), "early B1 + stagger: groups %d prio %d sleep %2d after B1, %2d after B2", grp, prio, k1, ka);
+                        run<0>("full loop", xb, hc, sh, tw1, tw23, vt, nblk);
+                        run<131072 + 65536>(what, xb, hc, sh, tw1, tw23, vt, nblk);
+                    }
         return 0;
     }
     if (getenv("PROBE_STAGGER")) {
