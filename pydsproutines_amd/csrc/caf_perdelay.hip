@@ -25,6 +25,22 @@ namespace caf {
 
 namespace {
 
+// global load of element `elem` of a complex64 array: when `base` is wave-uniform this is the scalar-base form
+// (s[base] + 32-bit VGPR byte offset), so no 64-bit per-thread address is kept alive across the row loop
+#define PD_AS1 __attribute__((address_space(1)))
+__device__ __forceinline__ float2 pd_ld2(const float2* base, uint32_t elem) {
+    const uint64_t u = *reinterpret_cast<const PD_AS1 uint64_t*>((const PD_AS1 char*)base + (elem << 3));
+    float2 r;
+    __builtin_memcpy(&r, &u, 8);
+    return r;
+}
+__device__ __forceinline__ const float2* pd_uniform(const float2* p) {
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return reinterpret_cast<const float2*>(((uint64_t)hi << 32) | lo);
+}
+
 // WG threads = max(256, N/16); rows handled concurrently RPW = WG / (N/16); each workgroup walks `rows_per_wg`
 // consecutive groups of RPW rows (neighbouring rows share all but one sample of their rx windows: L1/L2 hits).
 template <int LOGN>
@@ -85,13 +101,17 @@ __global__ __launch_bounds__((1 << LOGN) / 16 > 256 ? (1 << LOGN) / 16 : 256, 4)
         const bool zero = !live || (oor && zero_oor);
         float2 v[16];
         double es = 0.0;
-        int xo = 0;  // (opaque: keeps the cutout loads inside the row loop)
-        asm volatile("" : "+v"(xo));
-        // one 64-bit row pointer, 32-bit offsets; the bounds-checked form only for windows that leave rx
+        // (opaque copy of the row-local id: otherwise the load offsets, the twiddle powers and the LDS addresses of all
+        // passes are hoisted out of the row loop as loop invariants -- ~150 registers, most of them spilled)
+        int lo = l;
+        asm volatile("" : "+v"(lo));
+        // one row pointer (wave-uniform, i.e. scalar, when a row fills the workgroup), 32-bit offsets; the
+        // bounds-checked form only for windows that leave rx
         const float2* yrow = y + s;
+        if (RPW == 1) yrow = pd_uniform(yrow);
         if (!zero && !oor) {
 #pragma unroll
-            for (int t = 0; t < 16; ++t) v[t] = yrow[l + t * NTR];
+            for (int t = 0; t < 16; ++t) v[t] = pd_ld2(yrow, (uint32_t)(lo + t * NTR));
         } else {
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
@@ -101,7 +121,7 @@ __global__ __launch_bounds__((1 << LOGN) / 16 > 256 ? (1 << LOGN) / 16 : 256, 4)
         }
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
-            const float2 a = RESIDENT ? xr[RESIDENT ? t : 0] : x[l + t * NTR + xo], b = v[t];
+            const float2 a = RESIDENT ? xr[RESIDENT ? t : 0] : pd_ld2(x, (uint32_t)(lo + t * NTR)), b = v[t];
             es += (double)b.x * b.x + (double)b.y * b.y;
             // conj(x * y): the inverse butterflies then deliver conj(FFT(x * y))
             v[t] = make_float2(a.x * b.x - a.y * b.y, -(a.x * b.y + a.y * b.x));
@@ -110,10 +130,6 @@ __global__ __launch_bounds__((1 << LOGN) / 16 > 256 ? (1 << LOGN) / 16 : 256, 4)
         // barrier that ends the first pass
         double e = wave_sum(es);
         if (WPR > 1 && lane == 0) s_e[it & 1][wave] = e;
-        // (opaque copy of the row-local id: otherwise the twiddle powers and LDS addresses of all passes are hoisted
-        // out of the row loop as loop invariants -- ~150 registers)
-        int lo = l;
-        asm volatile("" : "+v"(lo));
         pd_fft<LOGN>(buf, tw, lo, v);
         if (WPR > 1) {
             e = 0.0;
@@ -128,7 +144,7 @@ __global__ __launch_bounds__((1 << LOGN) / 16 > 256 ? (1 << LOGN) / 16 : 256, 4)
         float2* crow = (cplane && live) ? cplane + row * N : nullptr;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int idx = pd_out_index<LOGN>(l, r);
+            const int idx = pd_out_index<LOGN>(lo, r);  // (from the opaque copy: 16 loop-invariant indices otherwise)
             const float zr = v[r].x * inv, zi = v[r].y * inv;
             const float val = zr * zr + zi * zi;
             if (prow) prow[idx] = val;

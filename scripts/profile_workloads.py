@@ -71,7 +71,12 @@ def caf(engine, surface, T=1, F=256, reps=2, rows=True):
         man.append(("k_magsq_norm_argmax", "|.|^2 + normalise + argmax (8 B read + 4 B write per cell)", cells * (8.0 + (4.0 if surface else 0.0)) + T * S * 12.0, 0.0, reps))
     man.append(("k_power_tile_sums|k_prefix_write|k_scan_tile_sums", "f64 energy prefix of |rx|^2 (8 B read + 8 B written per sample)", M * 16.0, 0.0, reps))
     man.append(("k_inv_energy", "1 / window energy (16 B read + 4 B written per delay)", S * 20.0, 0.0, reps))
-    man.append(("k_gather_blocks", "overlap-save blocks (8 B read + 8 B written per block point)", nblk * B * 16.0, 0.0, reps))
+    if plan.engine_used in ("persistent", "fused") and B == 16384:
+        # gather + in-LDS forward transform in one launch: rx samples read once per block, spectra written
+        man.append(("k_block_spectra", "block spectra: gather + in-LDS forward FFT (8 B read + 8 B written per block point)",
+                    nblk * B * 16.0, nblk * 5.0 * B * np.log2(B), reps))
+    else:
+        man.append(("k_gather_blocks", "overlap-save blocks (8 B read + 8 B written per block point)", nblk * B * 16.0, 0.0, reps))
     plan.close()
     return man
 
