@@ -52,32 +52,47 @@ const double* launch_cutout_norm(const float2* x, int64_t n, double* parts, hipS
 // (IppXcorrFFT.cpp:125-130 semantics), otherwise they are computed with zero padding
 // (multiplySlices.cu:147-163 semantics).
 // ---------------------------------------------------------------------------------------
+// A workgroup handles `rpw` consecutive rows (short rows: one 1/sqrt(E) in float64 per LANE instead of one per wave --
+// for 1000-sample rows the float64 square root and division were three quarters of the instructions) and the
+// blockIdx.x-th chunk of their samples.
+constexpr int SM_MAX_RPW = 64;
 __global__ __launch_bounds__(256) void k_sliding_multiply(const float2* __restrict__ x, int32_t xlen,
                                                           const float2* __restrict__ y, int64_t ylen,
                                                           const double* __restrict__ prefix, int64_t start,
                                                           int64_t step, double coef, int32_t zero_oor,
-                                                          float2* __restrict__ z, const double* __restrict__ d_coef) {
-    const int64_t row = blockIdx.y;
-    const int64_t s = start + row * step;
-    const bool oor = (s < 0) || (s + xlen > ylen);
-    float inv = 0.f;
-    if (!(oor && zero_oor)) {
-        int64_t a = s < 0 ? 0 : (s > ylen ? ylen : s);
-        int64_t b = s + xlen;
-        b = b < 0 ? 0 : (b > ylen ? ylen : b);
-        const double e = prefix[b] - prefix[a];
-        inv = (float)(1.0 / (sqrt(e) * (d_coef ? coef * *d_coef : coef)));
-    }
-    float2* zr = z + row * (int64_t)xlen;
-    for (int t = blockIdx.x * 256 + threadIdx.x; t < xlen; t += gridDim.x * 256) {
-        float2 r = make_float2(0.f, 0.f);
-        const int64_t j = s + t;
-        if (!(oor && zero_oor) && j >= 0 && j < ylen) {
-            const float2 a = x[t], b = y[j];
-            r.x = (a.x * b.x - a.y * b.y) * inv;
-            r.y = (a.x * b.y + a.y * b.x) * inv;
+                                                          float2* __restrict__ z, const double* __restrict__ d_coef,
+                                                          int64_t rows, int32_t rpw) {
+    __shared__ float s_inv[SM_MAX_RPW];
+    const int64_t row0 = (int64_t)blockIdx.y * rpw;
+    if ((int)threadIdx.x < rpw && row0 + threadIdx.x < rows) {
+        const int64_t s = start + (row0 + threadIdx.x) * step;
+        const bool oor = (s < 0) || (s + xlen > ylen);
+        float inv = 0.f;
+        if (!(oor && zero_oor)) {
+            int64_t a = s < 0 ? 0 : (s > ylen ? ylen : s);
+            int64_t b = s + xlen;
+            b = b < 0 ? 0 : (b > ylen ? ylen : b);
+            const double e = prefix[b] - prefix[a];
+            inv = (float)(1.0 / (sqrt(e) * (d_coef ? coef * *d_coef : coef)));
         }
-        zr[t] = r;
+        s_inv[threadIdx.x] = inv;
+    }
+    __syncthreads();
+    for (int r = 0; r < rpw && row0 + r < rows; ++r) {
+        const int64_t s = start + (row0 + r) * step;
+        const bool zero = ((s < 0) || (s + xlen > ylen)) && zero_oor;
+        const float inv = s_inv[r];
+        float2* zr = z + (row0 + r) * (int64_t)xlen;
+        for (int t = blockIdx.x * 256 + threadIdx.x; t < xlen; t += gridDim.x * 256) {
+            float2 o = make_float2(0.f, 0.f);
+            const int64_t j = s + t;
+            if (!zero && j >= 0 && j < ylen) {
+                const float2 a = x[t], b = y[j];
+                o.x = (a.x * b.x - a.y * b.y) * inv;
+                o.y = (a.x * b.y + a.y * b.x) * inv;
+            }
+            zr[t] = o;
+        }
     }
 }
 
@@ -1123,11 +1138,21 @@ static inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1
 void launch_sliding_multiply(const float2* x, int32_t xlen, const float2* y, int64_t ylen, const double* prefix,
                              int64_t start, int64_t step, int64_t rows, double coef, int32_t zero_oor, float2* z,
                              hipStream_t st, const double* d_coef) {
-    const unsigned gx = std::min<unsigned>(cdiv(xlen, 256), 64);
-    for (int64_t r0 = 0; r0 < rows; r0 += 65535) {
-        const int64_t nr = std::min<int64_t>(65535, rows - r0);
-        hipLaunchKernelGGL(k_sliding_multiply, dim3(gx, (unsigned)nr), dim3(256), 0, st, x, xlen, y, ylen, prefix,
-                           start + r0 * step, step, coef, zero_oor, z + r0 * (int64_t)xlen, d_coef);
+    // rows of up to 8192 samples: ~64K elements per workgroup (up to 64 rows), one chunk; longer rows: one row per
+    // workgroup row, up to 64 chunks
+    int rpw = 1;
+    unsigned gx = std::min<unsigned>(cdiv(xlen, 256), 64);
+    if (xlen <= 8192) {
+        rpw = (int)std::max<int64_t>(1, std::min<int64_t>(SM_MAX_RPW, 65536 / std::max(xlen, 1)));
+        // keep at least ~2048 workgroups in flight when there are that many rows
+        while (rpw > 1 && (rows + rpw - 1) / rpw < 2048) rpw >>= 1;
+        if (rpw > 1) gx = 1;
+    }
+    const int64_t rows_per_launch = (int64_t)65535 * rpw;
+    for (int64_t r0 = 0; r0 < rows; r0 += rows_per_launch) {
+        const int64_t nr = std::min<int64_t>(rows_per_launch, rows - r0);
+        hipLaunchKernelGGL(k_sliding_multiply, dim3(gx, (unsigned)((nr + rpw - 1) / rpw)), dim3(256), 0, st, x, xlen, y, ylen,
+                           prefix, start + r0 * step, step, coef, zero_oor, z + r0 * (int64_t)xlen, d_coef, nr, rpw);
     }
 }
 
