@@ -22,6 +22,50 @@ __device__ __forceinline__ void gst1(float* base, uint32_t byteoff, float v) {
 // flag 65536: wave stagger.  g_st[0] / g_st[1] = units of 64 cycles that the second wave group sleeps after B2 / B3,
 // g_st[2] = 1: the first group runs at priority 3, g_st[3] = how the groups are formed (0: waves 8..15, 1: waves with bit 2)
 __device__ int g_st[8];
+// flag 262144: in-kernel stamps (s_memtime, shader cycles) of one transform per workgroup: 12 points per wave, read at the
+// end of the iteration (one lgkmcnt wait there), written by lane 0 of every wave of workgroups 0..63
+__device__ unsigned long long* g_stamps;
+// flag 524288: progress-based issue priority (s_setprio): a wave that is ahead inside a barrier-free stretch yields to
+// the ones behind it.  g_st[5] selects the variant (see PRIO below).
+#define PRIO(point)                                                                              \
+    {                                                                                            \
+        constexpr int pv = (FLAGS >> 19) & 15; /* compile-time variant: flags 524288 * variant */ \
+        if (pv == 1) {                                                                           \
+            if (point == 0) __builtin_amdgcn_s_setprio(3);                                       \
+            if (point == 1) __builtin_amdgcn_s_setprio(2);                                       \
+            if (point == 2) __builtin_amdgcn_s_setprio(1);                                       \
+            if (point == 3) __builtin_amdgcn_s_setprio(0);                                       \
+        } else if (pv == 2) { /* only the tail: low priority once pass 3 is computed */          \
+            if (point == 0) __builtin_amdgcn_s_setprio(2);                                       \
+            if (point == 3) __builtin_amdgcn_s_setprio(0);                                       \
+        } else if (pv == 3) { /* reversed static order: youngest waves first */                  \
+            if (point == 0) {                                                                    \
+                if ((wave_id >> 2) == 1) __builtin_amdgcn_s_setprio(1);                          \
+                if ((wave_id >> 2) == 2) __builtin_amdgcn_s_setprio(2);                          \
+                if ((wave_id >> 2) == 3) __builtin_amdgcn_s_setprio(3);                          \
+            }                                                                                    \
+        } else if (pv == 4) { /* as 1, and the same ladder over pass 4 / pass 1 */               \
+            if (point == 0 || point == 4) __builtin_amdgcn_s_setprio(3);                         \
+            if (point == 1 || point == 5) __builtin_amdgcn_s_setprio(2);                         \
+            if (point == 2) __builtin_amdgcn_s_setprio(1);                                       \
+            if (point == 3 || point == 6) __builtin_amdgcn_s_setprio(0);                         \
+        } else if (pv == 6) { /* static order, oldest waves first */                             \
+            if (point == 0) {                                                                    \
+                if ((wave_id >> 2) == 0) __builtin_amdgcn_s_setprio(3);                          \
+                if ((wave_id >> 2) == 1) __builtin_amdgcn_s_setprio(2);                          \
+                if ((wave_id >> 2) == 2) __builtin_amdgcn_s_setprio(1);                          \
+            }                                                                                    \
+        } else if (pv == 5) { /* LDS-write phases at high priority (they feed the barrier), arithmetic low */ \
+            if (point == 1 || point == 3 || point == 6) __builtin_amdgcn_s_setprio(3);           \
+            if (point == 0 || point == 2 || point == 4) __builtin_amdgcn_s_setprio(0);           \
+        }                                                                                        \
+    }
+#define STAMP(i)                                        \
+    if (FLAGS & 262144) {                               \
+        __builtin_amdgcn_sched_barrier(0);              \
+        tstamp[i] = __builtin_amdgcn_s_memtime();       \
+        __builtin_amdgcn_sched_barrier(0);              \
+    }
 
 template <int FLAGS>
 __global__ __launch_bounds__(1024) void k_probe(const float2* __restrict__ xb, const float2* __restrict__ hc,
@@ -71,6 +115,7 @@ __global__ __launch_bounds__(1024) void k_probe(const float2* __restrict__ xb, c
     const int st_a = (FLAGS & 65536) ? g_st[0] : 0, st_b = (FLAGS & 65536) ? g_st[1] : 0;
     const bool grp_b = (FLAGS & 65536) && (g_st[3] ? ((wave_id >> 2) & 1) : (wave_id >> 3));
     if ((FLAGS & 65536) && g_st[2] && !grp_b) __builtin_amdgcn_s_setprio(3);
+
     __syncthreads();
 
     for (int h = h0; h < h1; ++h) {
@@ -79,6 +124,8 @@ __global__ __launch_bounds__(1024) void k_probe(const float2* __restrict__ xb, c
         asm volatile("" : "+s"(hoff));
         int lz = 0;
         asm volatile("" : "+v"(lz));
+        unsigned long long tstamp[12];
+        STAMP(0)
         float2 v1[16];
 #pragma unroll
         for (int a = 0; a < 16; ++a) v1[a] = pr[a];
@@ -94,7 +141,10 @@ __global__ __launch_bounds__(1024) void k_probe(const float2* __restrict__ xb, c
                 v1[n1] = cmul(v1[n1], p);
             }
         }
+        STAMP(1)
+        PRIO(6)
         if (!(FLAGS & 131072)) bar(1);
+        STAMP(2)
         {
             const int off = (tid >> 6) * F_ROW + (tid & 63);
             if (!(FLAGS & 32)) {
@@ -102,7 +152,10 @@ __global__ __launch_bounds__(1024) void k_probe(const float2* __restrict__ xb, c
                 for (int n1 = 0; n1 < 16; ++n1) s_d[n1 * F_N1 + off] = v1[n1];
             }
         }
+        STAMP(3)
         bar(2);
+        STAMP(4)
+        PRIO(0)
         if ((FLAGS & 65536) && grp_b)
             for (int i = 0; i < st_a; ++i) __builtin_amdgcn_s_sleep(1);
         row_of(more ? h + 1 : h);
@@ -119,12 +172,16 @@ __global__ __launch_bounds__(1024) void k_probe(const float2* __restrict__ xb, c
             if (!(FLAGS & 128)) idft16(v);
 #pragma unroll
             for (int n2 = 1; n2 < 16; ++n2) v[n2] = cmul(v[n2], (FLAGS & 8) ? w : s_tw2[n2 * 64 + (tid & 63) + lz]);
+            STAMP(5)
+            PRIO(1)
             if (!(FLAGS & 32)) {
 #pragma unroll
                 for (int n2 = 0; n2 < 16; ++n2) s_d[base + n2 * F_ROW] = v[n2];
             }
         }
         __builtin_amdgcn_wave_barrier();
+        STAMP(6)
+        PRIO(2)
         float2 hn[16];
         auto hload = [&](int a) {
             const uint32_t e = (uint32_t)(((1024 * a + tid - sh_cur) & (FB - 1)) + lz);
@@ -160,11 +217,14 @@ __global__ __launch_bounds__(1024) void k_probe(const float2* __restrict__ xb, c
             if (!(FLAGS & 128)) idft16(v);
 #pragma unroll
             for (int n3 = 1; n3 < 16; ++n3) v[n3] = cmul(v[n3], (FLAGS & 8) ? w : s_tw3[n3 * 4 + (tid & 3) + lz]);
+            STAMP(7)
+            PRIO(3)
             if (!(FLAGS & 32)) {
 #pragma unroll
                 for (int n3 = 0; n3 < 16; ++n3) s_d[base + 4 * n3] = v[n3];
             }
         }
+        STAMP(8)
         if (FLAGS & 8192) {
 #pragma unroll
             for (int a = 0; a < 16; ++a) hload(a);
@@ -174,6 +234,8 @@ __global__ __launch_bounds__(1024) void k_probe(const float2* __restrict__ xb, c
             for (int a = 8; a < 16; ++a) hload(a);
         }
         bar(3);
+        STAMP(9)
+        PRIO(4)
         if ((FLAGS & 65536) && grp_b)
             for (int i = 0; i < st_b; ++i) __builtin_amdgcn_s_sleep(1);
         {
@@ -228,9 +290,17 @@ __global__ __launch_bounds__(1024) void k_probe(const float2* __restrict__ xb, c
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            STAMP(10)
+            PRIO(5)
 #pragma unroll
             for (int a = 0; a < 16; ++a) pr[a] = cmul(xr[a], hn[a]);
             __builtin_amdgcn_sched_barrier(0);
+            STAMP(11)
+        }
+        if ((FLAGS & 262144) && h == h0 + 20 && blockIdx.x < 64 && (tid & 63) == 0) {
+            unsigned long long* d = g_stamps + ((size_t)blockIdx.x * 16 + (tid >> 6)) * 12;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) d[i] = tstamp[i];
         }
     }
     if (FLAGS & 1) vt_blk[tid] = acc;
@@ -732,6 +802,65 @@ int main() {
             run<111>(what, xb, hc, sh, tw1, tw23, vt, nblk);
         }
         g_threads = 1024;
+        return 0;
+    }
+    if (getenv("PROBE_PRIO")) {
+        for (int rep = 0; rep < 2; ++rep) {
+            run<0>("full loop", xb, hc, sh, tw1, tw23, vt, nblk);
+            run<524288 * 1>("priorities by progress, passes 2-3 (3,2,1,0)", xb, hc, sh, tw1, tw23, vt, nblk);
+            run<0>("full loop", xb, hc, sh, tw1, tw23, vt, nblk);
+            run<524288 * 2>("priority 2 from B2, 0 once pass 3 is computed", xb, hc, sh, tw1, tw23, vt, nblk);
+            run<0>("full loop", xb, hc, sh, tw1, tw23, vt, nblk);
+            run<524288 * 3>("static priorities, youngest waves first", xb, hc, sh, tw1, tw23, vt, nblk);
+            run<0>("full loop", xb, hc, sh, tw1, tw23, vt, nblk);
+            run<524288 * 4>("priorities by progress, all four passes", xb, hc, sh, tw1, tw23, vt, nblk);
+            run<0>("full loop", xb, hc, sh, tw1, tw23, vt, nblk);
+            run<524288 * 5>("LDS-write phases high, arithmetic low", xb, hc, sh, tw1, tw23, vt, nblk);
+            run<0>("full loop", xb, hc, sh, tw1, tw23, vt, nblk);
+            run<131072>("early B1", xb, hc, sh, tw1, tw23, vt, nblk);
+            run<131072 + 524288 * 3>("early B1 + static priorities, youngest first", xb, hc, sh, tw1, tw23, vt, nblk);
+            run<131072 + 524288 * 6>("early B1 + static priorities, oldest first", xb, hc, sh, tw1, tw23, vt, nblk);
+            run<524288 * 6>("static priorities, oldest first", xb, hc, sh, tw1, tw23, vt, nblk);
+        }
+        return 0;
+    }
+    if (getenv("PROBE_STAMPS")) {
+        unsigned long long* d_st;
+        const size_t nst = 64 * 16 * 12;
+        (void)hipMalloc(&d_st, nst * 8);
+        (void)hipMemset(d_st, 0, nst * 8);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(caf::g_stamps), &d_st, sizeof(d_st));
+        run<0>("full loop", xb, hc, sh, tw1, tw23, vt, nblk);
+        run<262144>("full loop with stamps", xb, hc, sh, tw1, tw23, vt, nblk);
+        std::vector<unsigned long long> st(nst);
+        (void)hipMemcpy(st.data(), d_st, nst * 8, hipMemcpyDeviceToHost);
+        static const char* names[11] = {"pass-1 butterfly + twiddles", "wait B1", "pass-1 writes (issue)", "wait B2",
+                                        "pass 2: reads + butterfly + twiddles", "pass-2 writes (issue) + wave barrier",
+                                        "row loads (issue) + pass 3: reads + butterfly + twiddles", "pass-3 writes (issue)", "wait B3",
+                                        "pass 4: reads + radix 4 + |y|^2 + stores", "next products X * H"};
+        // one workgroup in detail (every wave), then the mean over 64 workgroups x 16 waves
+        printf("workgroup 0, cycles per phase for each of its 16 waves (s_memtime):\n");
+        for (int i = 0; i < 11; ++i) {
+            printf("  %-58s", names[i]);
+            for (int w = 0; w < 16; ++w) printf(" %5lld", (long long)(st[(0 * 16 + w) * 12 + i + 1] - st[(0 * 16 + w) * 12 + i]));
+            printf("\n");
+        }
+        printf("  %-58s", "whole iteration");
+        for (int w = 0; w < 16; ++w) printf(" %5lld", (long long)(st[w * 12 + 11] - st[w * 12]));
+        printf("\nmean over 64 workgroups x 16 waves (min .. max):\n");
+        double tot = 0;
+        for (int i = 0; i < 11; ++i) {
+            double sum = 0, mn = 1e18, mx = 0;
+            for (int g = 0; g < 64 * 16; ++g) {
+                const double dlt = (double)(st[g * 12 + i + 1] - st[g * 12 + i]);
+                sum += dlt;
+                mn = dlt < mn ? dlt : mn;
+                mx = dlt > mx ? dlt : mx;
+            }
+            tot += sum / (64 * 16);
+            printf("  %-58s %8.0f  (%6.0f .. %6.0f)\n", names[i], sum / (64 * 16), mn, mx);
+        }
+        printf("  %-58s %8.0f\n", "sum", tot);
         return 0;
     }
     if (getenv("PROBE_EARLY_B1")) {
