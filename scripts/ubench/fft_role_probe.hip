@@ -13,6 +13,7 @@
 #include "caf_fused.hip"
 
 #include <cstdio>
+#include <type_traits>
 #include <vector>
 
 namespace caf {
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(1024) void k_probe(const float2* __restrict__ xb, c
         }
         STAMP(1)
         PRIO(6)
-        if (!(FLAGS & 131072)) bar(1);
+        if (!(FLAGS & (131072 | 8388608))) bar(1);
         STAMP(2)
         {
             const int off = (tid >> 6) * F_ROW + (tid & 63);
@@ -214,11 +215,49 @@ __global__ __launch_bounds__(1024) void k_probe(const float2* __restrict__ xb, c
 #pragma unroll
                 for (int c = 0; c < 16; ++c) v[c] = s_d[base + 4 * c];
             }
+            // flag 8388608: pass 4 across the four lanes of a quad (DPP) instead of through LDS.  The last LDS reads of a
+            // transform are these: B1 can follow them directly, and B3 disappears.
+            if (FLAGS & 8388608) bar(1);
             if (!(FLAGS & 128)) idft16(v);
 #pragma unroll
             for (int n3 = 1; n3 < 16; ++n3) v[n3] = cmul(v[n3], (FLAGS & 8) ? w : s_tw3[n3 * 4 + (tid & 3) + lz]);
             STAMP(7)
             PRIO(3)
+            if (FLAGS & 8388608) {
+                const int lane4 = tid & 3;
+                const float sg_a = (lane4 & 2) ? -1.f : 1.f, sg_b = (lane4 & 1) ? -1.f : 1.f;
+                const bool rot = lane4 == 3;
+                const int n1w = __builtin_amdgcn_readfirstlane(tid >> 6);
+                const uint32_t lane_off = (uint32_t)(tid & 63) << 2;
+#pragma unroll
+                for (int n3 = 0; n3 < 16; ++n3) {
+                    const float2 m = v[n3];
+                    // lanes (0,2) and (1,3): s0 = x0 + x2, s2 = x1 + x3, s1 = x0 - x2, s3 = x1 - x3
+                    const float smx = sg_a * m.x, smy = sg_a * m.y;
+                    float2 t;
+                    asm volatile("v_add_f32_dpp %0, %1, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=v"(t.x) : "v"(m.x), "v"(smx));
+                    asm volatile("v_add_f32_dpp %0, %1, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=v"(t.y) : "v"(m.y), "v"(smy));
+                    // lane 3: times j
+                    const float2 r = rot ? make_float2(-t.y, t.x) : t;
+                    // lanes (0,1) and (2,3): y0 = s0 + s2, y2 = s0 - s2, y1 = s1 + j s3, y3 = s1 - j s3
+                    const float srx = sg_b * r.x, sry = sg_b * r.y;
+                    float2 y;
+                    asm volatile("v_add_f32_dpp %0, %1, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(y.x) : "v"(r.x), "v"(srx));
+                    asm volatile("v_add_f32_dpp %0, %1, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(y.y) : "v"(r.y), "v"(sry));
+                    const float val = y.x * y.x + y.y * y.y;
+                    // probe layout: the 64 lanes of a wave contiguous per (n3, n1, hypothesis); uniform base + lane offset
+                    // (tile index folded into the 193 tiles a block owns in this harness: 256 would run past the buffer)
+                    const int tile_p = ((n3 * 16 + n1w) * 193) >> 8;
+                    float* pu = vt_blk + (int64_t)(tile_p * nhyp) * 64 + hoff;
+                    if (FLAGS & 1)
+                        acc += val;
+                    else
+                        gst1(pu, lane_off, val);
+                }
+#pragma unroll
+                for (int a = 0; a < 16; ++a) pr[a] = cmul(xr[a], hn[a]);
+                continue;
+            }
             if (!(FLAGS & 32)) {
 #pragma unroll
                 for (int n3 = 0; n3 < 16; ++n3) s_d[base + 4 * n3] = v[n3];
@@ -802,6 +841,13 @@ int main() {
             run<111>(what, xb, hc, sh, tw1, tw23, vt, nblk);
         }
         g_threads = 1024;
+        return 0;
+    }
+    if (getenv("PROBE_DPP")) {
+        for (int rep = 0; rep < 3; ++rep) {
+            run<0>("full loop", xb, hc, sh, tw1, tw23, vt, nblk);
+            run<8388608>("pass 4 across quad lanes (DPP), two barriers", xb, hc, sh, tw1, tw23, vt, nblk);
+        }
         return 0;
     }
     if (getenv("PROBE_PRIO")) {
