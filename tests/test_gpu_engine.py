@@ -208,6 +208,14 @@ def test_argument_validation():
         plan.run(asarray(np.ones(2000, np.complex64)))  # longer than max_rx_len
     with pytest.raises(TypeError):
         plan.run(np.ones(500, np.complex64))  # host array where a device array is required
+    # 65536 hypotheses: their |y|^2 tiles would need more than 32-bit byte offsets inside a block -- refused with a
+    # message for surface / tile launches, still served without a surface (running maxima, no tiles)
+    many = CAFPlan(t, max_rx_len=400, bins=np.arange(65536) % 64, grid=64)
+    small = asarray((np.arange(400) % 7).astype(np.complex64))
+    with pytest.raises(ValueError, match="too many hypotheses"):
+        many.run(small, surface=True)
+    res = many.run(small, surface=False, rows=True, peak=True)
+    assert res.row_max.shape == (1, 337) and int(res.row_arg.get().max()) < 65536
 
 
 @pytest.mark.parametrize("engine", ["fused", "persistent", "rocfft"])
