@@ -234,7 +234,7 @@ def w_kernels_misc():
     d_tp = asarray((rng.standard_normal(128) / 11).astype(np.float32))
     for _ in range(3):
         out = f.upfirdn_sm(d_m, d_tp, 5, 2)
-    man.append(("k_upfirdn", "upfirdn 64 x 2^18, 128 taps, up 5 down 2 (8 B read per input + 8 B written per output)",
+    man.append(("k_upfirdn_poly|k_upfirdn", "upfirdn 64 x 2^18, 128 taps, up 5 down 2 (8 B read per input + 8 B written per output)",
                 d_m.size * 8.0 + out.size * 8.0, 0.0, 3))
     for _ in range(3):
         cupyFindLocalMaxima(d_p, 3.0)
