@@ -104,3 +104,16 @@ def test_one_rocm_runtime_per_process_in_either_import_order():
         r = subprocess.run([sys.executable, "-c", body % (ROOT, order)], capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, (order, r.stdout, r.stderr)
         assert "single runtime" in r.stdout
+
+
+def test_header_is_plain_c_and_the_library_links_from_c():
+    """include/caf.h compiles as strict C99 and examples/c_client links against libcaf.so with gcc (no C++, no HIP
+    headers on the client side): the drop-in boundary is a C-ABI, not a C++ one."""
+    import subprocess
+
+    d = os.path.join(ROOT, "examples", "c_client")
+    subprocess.run(["make", "-C", d, "clean"], check=True, capture_output=True)
+    r = subprocess.run(["make", "-C", d], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "warning" not in (r.stdout + r.stderr).lower()
+    assert os.path.exists(os.path.join(d, "caf_client"))

@@ -805,3 +805,18 @@ def test_c_abi_peak_table_allgather_world_of_one():
     _lib.check(lib.caf_stream_sync(None))
     np.testing.assert_array_equal(d_tab.get()[0], rows)
     _lib.check(lib.caf_comm_destroy(comm))
+
+
+def test_plain_c_client_of_the_abi():
+    """examples/c_client/caf_client.c -- a C99 program that only includes include/caf.h -- plans, executes on device
+    buffers, zooms around the peak (caf_zoom_czt) and repeats the call in the host-pointer DLL style; it checks the
+    planted (delay, bin) itself and exits 0."""
+    import os
+    import subprocess
+
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "c_client")
+    r = subprocess.run(["make", "-C", d], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    r = subprocess.run([os.path.join(d, "caf_client")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "caf_client: ok" in r.stdout
