@@ -116,8 +116,10 @@ const double* launch_cutout_norm(const float2* x, int64_t n, double* parts, hipS
 // e^{+j 2 pi q / 16384}, q < 16384: the twiddle table of the in-LDS transforms (caf_ldsfft.h), built once per device
 int lds_fft_twiddles(int device, const float2** out);
 // forward spectra of nblk overlap-save blocks of 16384 points (gather + in-LDS transform in one launch)
+// inv_e != NULL: the same launch also writes 1 / (window energy) of the blocks' delays (num_shifts of them in all)
 int launch_block_spectra(const float2* rx, int64_t rx_len, int64_t src0, int32_t step, int64_t nblk, float2* xb,
-                         hipStream_t st);
+                         hipStream_t st, float* inv_e = nullptr, int64_t num_shifts = 0, const int32_t* gstart = nullptr,
+                         const int32_t* glen = nullptr, int32_t ngroups = 0);
 
 // what caf_zoom_czt needs from a plan (caf_plan.hip)
 struct PlanZoomView {

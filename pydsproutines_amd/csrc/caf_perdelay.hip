@@ -14,6 +14,7 @@
 // the conjugate.  Twiddles: one table lookup (W_16384^q, exact to f32) per butterfly and pass, powers by
 // recurrence.  LDS addresses are padded by one element per sixteen, which makes the stride-16 stores of the
 // first pass conflict-free.
+#include <algorithm>
 #include <mutex>
 #include <vector>
 #include <complex>
@@ -225,43 +226,118 @@ int lds_fft_twiddles(int device, const float2** out) {
 
 // ----------------------------------------------------------------------------------------
 // Forward spectra of the overlap-save blocks of the LDS engines (B = 16384): X[b][m] = sum_n rx[src0 + b step + n]
-// e^{-j 2 pi m n / B} (zeros past the end of rx), unnormalised -- gather + transform in ONE launch, one workgroup per
-// block, instead of k_gather_blocks (8 B written + 8 B read back per point) followed by ~60 batched rocFFT launches.
+// e^{-j 2 pi m n / B} (zeros past the end of rx), unnormalised -- gather + transform in ONE launch instead of
+// k_gather_blocks (8 B written + 8 B read back per point) followed by ~60 batched rocFFT launches.
 // forward = conj(IDFT(conj x)) on the shared in-LDS transform.  Replaces cuFFT's forward plan of the reference's
 // batched xcorr (xcorrRoutines.py:1221-1232) on the hot path; rocFFT keeps the one-off template spectra.
+// The block's samples are exactly the ones the sliding energies of its delays need (step + N - 1 = B), so with
+// inv_e != NULL the same launch also writes 1 / sum_g sum_{n in group g} |rx[d + n]|^2 for the block's delays
+// (filter.cu:291-347 + multiplySlices.cu:190-204 in the reference): |x|^2 in float64 into the idle LDS image, a
+// block-wide exclusive prefix, differences per group -- no pass over rx of its own and no float64 prefix in HBM.
+// One workgroup per CU walks blocks b, b + grid, ...: the next block's samples are in flight while this one is
+// transformed (a workgroup owns the CU's LDS, so nothing else could hide that latency).
 // ----------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_block_spectra(const float2* __restrict__ rx, int64_t rx_len, int64_t src0,
-                                                        int32_t step, const float2* __restrict__ tw,
-                                                        float2* __restrict__ xb) {
+                                                        int32_t step, int64_t nblk, const float2* __restrict__ tw,
+                                                        float2* __restrict__ xb, float* __restrict__ inv_e,
+                                                        int64_t num_shifts, const int32_t* __restrict__ gstart,
+                                                        const int32_t* __restrict__ glen, int32_t ngroups) {
     constexpr int LOGN = 14, N = 1 << LOGN, NTR = N / 16;
     extern __shared__ __attribute__((aligned(16))) float2 s_bs[];
+    __shared__ double s_wtot[16];
+    __shared__ double s_total;
     const int l = threadIdx.x;
-    const int64_t s0 = src0 + (int64_t)blockIdx.x * step;
-    float2 v[16];
-    if (s0 + N <= rx_len) {
-        const float2* p = rx + s0;  // whole block inside rx: one 64-bit base, 32-bit offsets
+    // conj(x) of the block's 16 points of this thread (zeros past the end of rx)
+    auto load = [&](int64_t b, float2 (&d)[16], int lo) {
+        const int64_t s0 = src0 + b * step;
+        if (s0 + N <= rx_len) {
+            const float2* p = rx + s0;  // whole block inside rx: one 64-bit base, 32-bit offsets
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const float2 x = p[l + t * NTR];
-            v[t] = make_float2(x.x, -x.y);
-        }
-    } else {
+            for (int t = 0; t < 16; ++t) {
+                const float2 x = p[lo + t * NTR];
+                d[t] = make_float2(x.x, -x.y);
+            }
+        } else {
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const int64_t i = s0 + l + t * NTR;
-            float2 x = make_float2(0.f, 0.f);
-            if (i < rx_len) x = rx[i];
-            v[t] = make_float2(x.x, -x.y);
+            for (int t = 0; t < 16; ++t) {
+                const int64_t i = s0 + lo + t * NTR;
+                float2 x = make_float2(0.f, 0.f);
+                if (i < rx_len) x = rx[i];
+                d[t] = make_float2(x.x, -x.y);
+            }
         }
+    };
+    float2 v[16], nx[16];
+    int64_t b = blockIdx.x;
+    if (b < nblk) load(b, v, l);
+    for (; b < nblk; b += gridDim.x) {
+        // (opaque copy of the thread id: otherwise the load offsets, twiddle powers and LDS addresses of all passes are
+        // hoisted out of the block loop as loop invariants and spilled)
+        int lo = l;
+        asm volatile("" : "+v"(lo));
+        if (inv_e) {
+            // P[m] = sum_{i<m} |x_i|^2 over the block, element m at m + (m >> 4) (a thread's 16 consecutive values at an
+            // odd pitch); the image is free here: the previous transform ended with a barrier and wrote nothing after it
+            double* s_p = reinterpret_cast<double*>(s_bs);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int m = lo + t * NTR;
+                s_p[m + (m >> 4)] = (double)v[t].x * (double)v[t].x + (double)v[t].y * (double)v[t].y;
+            }
+            __syncthreads();
+            double tot = 0.0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) tot += s_p[17 * lo + j];
+            const int lane = lo & 63, wave = lo >> 6;
+            double incl = tot;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const double u = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += u;
+            }
+            if (lane == 63) s_wtot[wave] = incl;
+            double base = __shfl_up(incl, 1, 64);  // exclusive value from the neighbour (no inclusive-minus-own)
+            if (lane == 0) base = 0.0;
+            __syncthreads();
+            for (int w = 0; w < wave; ++w) base += s_wtot[w];
+            // in place: value -> exclusive prefix (each thread touches only its own 16 elements)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const double e = s_p[17 * lo + j];
+                s_p[17 * lo + j] = base;
+                base += e;
+            }
+            if (lo == 1023) s_total = base;  // P[16384]
+            __syncthreads();
+            auto P = [&](int m) { return m >= N ? s_total : s_p[m + (m >> 4)]; };
+            const int64_t i0 = b * step;
+            for (int k = lo; k < step; k += 1024) {
+                const int64_t i = i0 + k;
+                if (i < num_shifts) {
+                    double e = 0.0;
+                    for (int g = 0; g < ngroups; ++g) {
+                        const int a = k + gstart[g];
+                        e += P(a + glen[g]) - P(a);
+                    }
+                    inv_e[i] = (float)(1.0 / e);
+                }
+            }
+            __syncthreads();  // the image is overwritten by the transform's first pass
+        }
+        const int64_t bn = b + gridDim.x;
+        if (bn < nblk) load(bn, nx, lo);
+        pd_fft<LOGN>(s_bs, tw, lo, v);
+        float2* o = xb + b * N;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[pd_out_index<LOGN>(lo, r)] = make_float2(v[r].x, -v[r].y);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) v[t] = nx[t];
     }
-    pd_fft<LOGN>(s_bs, tw, l, v);
-    float2* o = xb + (int64_t)blockIdx.x * N;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[pd_out_index<LOGN>(l, r)] = make_float2(v[r].x, -v[r].y);
 }
 
 int launch_block_spectra(const float2* rx, int64_t rx_len, int64_t src0, int32_t step, int64_t nblk, float2* xb,
-                         hipStream_t st) {
+                         hipStream_t st, float* inv_e, int64_t num_shifts, const int32_t* gstart, const int32_t* glen,
+                         int32_t ngroups) {
     int dev = 0;
     CAF_HIP_TRY(hipGetDevice(&dev));
     const float2* tw = nullptr;
@@ -279,7 +355,11 @@ int launch_block_spectra(const float2* rx, int64_t rx_len, int64_t src0, int32_t
             attr_set[dev] = 1;
         }
     }
-    hipLaunchKernelGGL(k_block_spectra, dim3((unsigned)nblk), dim3(1024), lds, st, rx, rx_len, src0, step, tw, xb);
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const unsigned grid = (unsigned)std::min<int64_t>(nblk, std::max(cus, 1));
+    hipLaunchKernelGGL(k_block_spectra, dim3(grid), dim3(1024), lds, st, rx, rx_len, src0, step, nblk, tw, xb, inv_e,
+                       num_shifts, gstart, glen, ngroups);
     CAF_HIP_TRY(hipGetLastError());
     return CAF_OK;
 }

@@ -689,33 +689,46 @@ int32_t caf_plan_execute(caf_plan p, const float* d_rx, int64_t rx_len, int64_t 
     const int T = p->T, F = p->F;
     const bool want_peak = out->d_peak_val || out->d_peak_delay || out->d_peak_freq;
 
-    // The sliding-energy pass is independent of the block spectra: it runs on the plan's auxiliary stream beside
-    // gather + forward FFTs (small memory-bound kernels that do not fill the chip one at a time) and is joined
-    // before the first consumer of inv_e.
-    hipStream_t se = p->s_aux ? p->s_aux : st;
-    if (p->s_aux) {
-        CAF_HIP_TRY(hipEventRecord(p->ev_fork, st));
-        CAF_HIP_TRY(hipStreamWaitEvent(p->s_aux, p->ev_fork, 0));
-    }
-    p->stage_begin(0, se);
-    launch_energy_prefix(rx, rx_len, p->d_tile_sums, p->d_prefix, se);
-    launch_inv_energy(p->d_prefix, shift_start, num_shifts, p->d_gstart, p->d_glen, p->G, p->d_inv_e, se);
-    p->stage_end(se);
-    if (p->s_aux) CAF_HIP_TRY(hipEventRecord(p->ev_join, p->s_aux));
-
     const int64_t nblk = (num_shifts + p->step - 1) / p->step;
     const int64_t nblk_pad = (nblk + p->nb - 1) / p->nb * p->nb;
     // overlap-save blocks of rx -> spectra X[b] for every block of this call
     const int64_t nfwd = ((p->fused ? nblk : nblk_pad) + p->fwd_chunk - 1) / p->fwd_chunk;
-    // LDS engines with 16384-point blocks: gather + forward transform in one launch of the in-LDS FFT
-    // (CAF_FWD_ROCFFT=1: the gather kernel + batched rocFFT transforms that every other block size uses)
+    // LDS engines with 16384-point blocks: gather + forward transform in one launch of the in-LDS FFT, which also
+    // writes the sliding energies of each block's delays from the samples it holds anyway.
+    // (CAF_FWD_ROCFFT=1: the gather kernel + batched rocFFT transforms that every other block size uses;
+    //  CAF_ENERGY_PREFIX=1: the separate float64-prefix pass for the energies)
     static const bool fwd_rocfft = [] {
         const char* e = getenv("CAF_FWD_ROCFFT");
         return e && atoi(e);
     }();
-    if (p->fused && p->B == 16384 && !fwd_rocfft) {
+    static const bool energy_prefix = [] {
+        const char* e = getenv("CAF_ENERGY_PREFIX");
+        return e && atoi(e);
+    }();
+    const bool lds_fwd = p->fused && p->B == 16384 && !fwd_rocfft;
+    const bool energy_in_fwd = lds_fwd && !energy_prefix;
+    // Otherwise the sliding-energy pass (float64 prefix of |rx|^2, then differences) is independent of the block
+    // spectra: it runs on the plan's auxiliary stream beside gather + forward FFTs (small memory-bound kernels that do
+    // not fill the chip one at a time) and is joined before the first consumer of inv_e.
+    const bool aux = p->s_aux && !energy_in_fwd;
+    if (!energy_in_fwd) {
+        hipStream_t se = aux ? p->s_aux : st;
+        if (aux) {
+            CAF_HIP_TRY(hipEventRecord(p->ev_fork, st));
+            CAF_HIP_TRY(hipStreamWaitEvent(p->s_aux, p->ev_fork, 0));
+        }
+        p->stage_begin(0, se);
+        launch_energy_prefix(rx, rx_len, p->d_tile_sums, p->d_prefix, se);
+        launch_inv_energy(p->d_prefix, shift_start, num_shifts, p->d_gstart, p->d_glen, p->G, p->d_inv_e, se);
+        p->stage_end(se);
+        if (aux) CAF_HIP_TRY(hipEventRecord(p->ev_join, p->s_aux));
+    }
+    if (lds_fwd) {
         p->stage_begin(2, st);
-        const int rc = launch_block_spectra(rx, rx_len, shift_start, p->step, nfwd * p->fwd_chunk, p->d_xb, st);
+        const int rc = energy_in_fwd
+                           ? launch_block_spectra(rx, rx_len, shift_start, p->step, nfwd * p->fwd_chunk, p->d_xb, st, p->d_inv_e,
+                                                  num_shifts, p->d_gstart, p->d_glen, p->G)
+                           : launch_block_spectra(rx, rx_len, shift_start, p->step, nfwd * p->fwd_chunk, p->d_xb, st);
         p->stage_end(st);
         if (rc) return rc;
     } else {
@@ -731,7 +744,7 @@ int32_t caf_plan_execute(caf_plan p, const float* d_rx, int64_t rx_len, int64_t 
     }
     if (p->fused && p->B == 32768)  // block spectra parity-major for the two chained half-transforms
         launch_parity_major(p->d_xb, p->d_xb2, nfwd * p->fwd_chunk, p->B / 2, st);
-    if (p->s_aux) CAF_HIP_TRY(hipStreamWaitEvent(st, p->ev_join, 0));
+    if (aux) CAF_HIP_TRY(hipStreamWaitEvent(st, p->ev_join, 0));
     if (p->fused) {
         CAF_REQUIRE(!out->d_cqf, "the fused engine has no complex-QF output (create the plan with CAF_ENGINE_ROCFFT)");
         // No surface wanted (per-delay traces / peaks only): the FFT items keep running per-delay maxima and
