@@ -69,13 +69,14 @@ def caf(engine, surface, T=1, F=256, reps=2, rows=True):
         Bc = plan.block
         man.append(("k_spectral_mul", "X * conj(H_h) for all hypotheses (8(1+2/F) B per point)", nblk * 8.0 * Bc * (T * F + 2), 0.0, reps))
         man.append(("k_magsq_norm_argmax", "|.|^2 + normalise + argmax (8 B read + 4 B write per cell)", cells * (8.0 + (4.0 if surface else 0.0)) + T * S * 12.0, 0.0, reps))
-    man.append(("k_power_tile_sums|k_prefix_write|k_scan_tile_sums", "f64 energy prefix of |rx|^2 (8 B read + 8 B written per sample)", M * 16.0, 0.0, reps))
-    man.append(("k_inv_energy", "1 / window energy (16 B read + 4 B written per delay)", S * 20.0, 0.0, reps))
     if plan.engine_used in ("persistent", "fused") and B == 16384:
-        # gather + in-LDS forward transform in one launch: rx samples read once per block, spectra written
-        man.append(("k_block_spectra", "block spectra: gather + in-LDS forward FFT (8 B read + 8 B written per block point)",
-                    nblk * B * 16.0, nblk * 5.0 * B * np.log2(B), reps))
+        # gather + in-LDS forward transform + sliding energies in one launch: rx samples read once per block, spectra
+        # and 1/energy written
+        man.append(("k_block_spectra", "block spectra + sliding energies: gather, in-LDS forward FFT, f64 block prefix "
+                    "(8 B read + 8 B written per block point, 4 B per delay)", nblk * B * 16.0 + S * 4.0, nblk * 5.0 * B * np.log2(B), reps))
     else:
+        man.append(("k_power_tile_sums|k_prefix_write|k_scan_tile_sums", "f64 energy prefix of |rx|^2 (8 B read + 8 B written per sample)", M * 16.0, 0.0, reps))
+        man.append(("k_inv_energy", "1 / window energy (16 B read + 4 B written per delay)", S * 20.0, 0.0, reps))
         man.append(("k_gather_blocks", "overlap-save blocks (8 B read + 8 B written per block point)", nblk * B * 16.0, 0.0, reps))
     plan.close()
     return man
