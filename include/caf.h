@@ -109,7 +109,7 @@ typedef struct caf_plan_desc {
     int64_t max_rx_len;        /* largest rx length (samples) execute() will be given             */
     int32_t log2_block;        /* overlap-save FFT size B = 2^log2_block; 0 => library default    */
     int32_t blocks_per_batch;  /* rx blocks processed per launch group; 0 => library default      */
-    int32_t engine;            /* CAF_ENGINE_AUTO / _ROCFFT / _FUSED (see below)                  */
+    int32_t engine;            /* CAF_ENGINE_AUTO / _ROCFFT / _FUSED / _PERSISTENT / _DIRECT      */
     int32_t reserved;          /* must be 0                                                       */
 } caf_plan_desc;
 
@@ -126,6 +126,12 @@ typedef struct caf_plan_desc {
 #define CAF_ENGINE_ROCFFT 1
 #define CAF_ENGINE_FUSED 2
 #define CAF_ENGINE_PERSISTENT 3
+/*   DIRECT: the definition itself, product by product in the time domain, for templates with at most 64 non-zero
+ *           samples (composite templates whose groups cover only a few samples of a long span): no overlap-save
+ *           blocks, so the error does not follow the block's energy; float64 window energies over the samples used.
+ *           AUTO picks it for composite templates (num_groups >= 1) whose groups cover fewer than 64 samples.
+ *           No d_cqf. */
+#define CAF_ENGINE_DIRECT 4
 
 CAF_EXPORT int32_t caf_plan_create(caf_plan* plan, const caf_plan_desc* desc);
 CAF_EXPORT int32_t caf_plan_destroy(caf_plan plan);
@@ -134,7 +140,7 @@ CAF_EXPORT int32_t caf_plan_destroy(caf_plan plan);
 CAF_EXPORT int32_t caf_plan_info(caf_plan plan, int32_t* block, int32_t* step, int32_t* blocks_per_batch,
                                  int64_t* workspace_bytes);
 
-/* Engine actually selected by the plan: CAF_ENGINE_ROCFFT, CAF_ENGINE_FUSED or CAF_ENGINE_PERSISTENT. */
+/* Engine actually selected by the plan: CAF_ENGINE_ROCFFT, _FUSED, _PERSISTENT or _DIRECT. */
 CAF_EXPORT int32_t caf_plan_engine(caf_plan plan, int32_t* engine);
 
 /* Outputs of one execute (any pointer may be NULL = not wanted). */

@@ -31,11 +31,13 @@ CAF_ENGINE_AUTO = 0
 CAF_ENGINE_ROCFFT = 1
 CAF_ENGINE_FUSED = 2
 CAF_ENGINE_PERSISTENT = 3
+CAF_ENGINE_DIRECT = 4
 ENGINE_IDS = {
     "auto": CAF_ENGINE_AUTO,
     "rocfft": CAF_ENGINE_ROCFFT,
     "fused": CAF_ENGINE_FUSED,
     "persistent": CAF_ENGINE_PERSISTENT,
+    "direct": CAF_ENGINE_DIRECT,
 }
 ENGINE_NAMES = {v: k for k, v in ENGINE_IDS.items() if k != "auto"}
 CAF_NUM_STAGES = 7

@@ -41,6 +41,10 @@ int64_t prefix_num_tiles(int64_t m);
 void launch_energy_prefix(const float2* rx, int64_t m, double* tile_sums, double* prefix, hipStream_t st);
 void launch_inv_energy(const double* prefix, int64_t shift_start, int64_t num_shifts, const int32_t* gstart,
                        const int32_t* glen, int32_t ngroups, float* inv_e, hipStream_t st);
+// direct (time-domain) engine over nk <= 64 non-zero template positions (caf_direct.hip)
+void launch_direct_caf(const float2* rx, int64_t shift_start, int64_t num_shifts, int32_t ntmpl, int32_t nfreq, int32_t nk,
+                       const int32_t* pos, const float2* w, const float* tscale, float* surface, float* row_max,
+                       int32_t* row_arg, PeakRec* partial, int64_t partial_per_tmpl, hipStream_t st);
 void launch_gather_blocks(const float2* rx, int64_t rx_len, int64_t src0, int32_t step, int32_t bsz, int32_t nblk,
                           float2* xb, hipStream_t st);
 void launch_conj_scale(float2* h, int64_t n, float scale, hipStream_t st);

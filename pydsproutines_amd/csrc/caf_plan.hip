@@ -85,6 +85,10 @@ struct caf_plan_t {
     PeakRec* d_partial = nullptr;
     bool fused = false;
     bool persistent = false;  // fused stages as one work-queue launch (k_caf_persistent)
+    bool direct = false;      // time-domain evaluation over <= 64 non-zero template samples (caf_direct.hip)
+    int dir_k = 0;
+    int32_t* d_dir_pos = nullptr;
+    float2* d_dir_w = nullptr;
     int n_cus = 0, tr_slots = 0;
     PersistParams* d_params = nullptr;
     int32_t* d_pq = nullptr;
@@ -164,7 +168,7 @@ struct caf_plan_t {
         aux_release(device, s_aux, ev_fork, ev_join);
         s_aux = nullptr;
         ev_fork = ev_join = nullptr;
-        void* ptrs[] = {d_hc,  d_shifts, d_tscale, d_gstart,  d_glen, d_tile_sums, d_prefix, d_inv_e,
+        void* ptrs[] = {d_dir_pos, d_dir_w, d_hc,  d_shifts, d_tscale, d_gstart,  d_glen, d_tile_sums, d_prefix, d_inv_e,
                         d_xb,  d_pbuf,   d_partial, d_vt,     d_params, d_pq,     d_uconj, d_nu,    d_xb2};  // (d_tw1 / d_tw23 are shared, per device)
         for (void* p : ptrs)
             if (p) (void)pool_free(p);
@@ -237,7 +241,7 @@ int32_t caf_last_error(char* buf, int32_t len) {
     return CAF_OK;
 }
 
-int32_t caf_abi_version(void) { return (1 << 16) | 3; }  // minor: +1 per batch of added entry points
+int32_t caf_abi_version(void) { return (1 << 16) | 4; }  // minor: +1 per batch of added entry points
 
 int32_t caf_device_count(int32_t* count) {
     CAF_REQUIRE(count, "count is NULL");
@@ -326,6 +330,62 @@ int32_t caf_plan_destroy(caf_plan plan) {
     return CAF_OK;
 }
 
+// Direct engine (caf_direct.hip): everything the plan needs is the list of non-zero template positions, one complex
+// multiplier per (template, hypothesis, position), the template scales, the peak records -- and what caf_zoom_czt reads.
+static int32_t plan_build_direct(caf_plan p, const caf_plan_desc* d, const std::vector<int32_t>& gs,
+                                 const std::vector<int32_t>& gl, const std::vector<int32_t>& nz) {
+    const int T = p->T, N = p->N, F = p->F, K = (int)nz.size();
+    const std::complex<float>* tm = reinterpret_cast<const std::complex<float>*>(d->h_templates);
+    p->direct = true;
+    p->dir_k = K;
+    p->B = p->step = p->nb = 0;
+    p->partial_per_tmpl = (d->max_rx_len - N + 1 + 255) / 256;
+    std::vector<double> nu(F);
+    for (int f = 0; f < F; ++f) {
+        if (d->freq_mode == CAF_FREQ_BINS) {
+            CAF_REQUIRE(d->h_bins && d->grid >= 1, "CAF_FREQ_BINS needs bins and grid");
+            nu[f] = (double)d->h_bins[f] / (double)d->grid;
+        } else {
+            CAF_REQUIRE(d->h_freqs_norm, "CAF_FREQ_NORM needs freqs_norm");
+            nu[f] = d->h_freqs_norm[f];
+        }
+    }
+    // w[t][f][k] = conj(u_t[n_k]) exp(-j 2 pi nu_f n_k),  u = auto_conj ? tmpl : conj(tmpl)
+    std::vector<std::complex<float>> w((size_t)T * F * K);
+    std::vector<float> tscale(T);
+    for (int t = 0; t < T; ++t) {
+        double e = 0.0;
+        for (int n = 0; n < N; ++n) e += std::norm(std::complex<double>(tm[(size_t)t * N + n]));
+        tscale[t] = (float)(1.0 / e);
+        for (int f = 0; f < F; ++f)
+            for (int k = 0; k < K; ++k) {
+                std::complex<double> u(tm[(size_t)t * N + nz[k]]);
+                if (d->auto_conj) u = std::conj(u);  // conj(u) with u = tmpl
+                double cyc = nu[f] * (double)nz[k];
+                cyc -= std::floor(cyc);  // phase reduced in cycles before the trig call
+                const double ph = -2.0 * M_PI * cyc;
+                u *= std::complex<double>(std::cos(ph), std::sin(ph));
+                w[((size_t)t * F + f) * K + k] = std::complex<float>((float)u.real(), (float)u.imag());
+            }
+    }
+    int rc;
+    if ((rc = p->alloc(&p->d_dir_pos, K)) || (rc = p->alloc(&p->d_dir_w, (int64_t)T * F * K)) || (rc = p->alloc(&p->d_tscale, T)) ||
+        (rc = p->alloc(&p->d_partial, (int64_t)T * p->partial_per_tmpl + (int64_t)T * PEAK_PARTS)) ||
+        (rc = p->alloc(&p->d_gstart, p->G)) || (rc = p->alloc(&p->d_glen, p->G)) || (rc = p->alloc(&p->d_uconj, (int64_t)T * N)) ||
+        (rc = p->alloc(&p->d_nu, F)))
+        return rc;
+    std::vector<std::complex<float>> uc((size_t)T * N);
+    for (size_t i = 0; i < uc.size(); ++i) uc[i] = d->auto_conj ? std::conj(tm[i]) : tm[i];
+    CAF_HIP_TRY(hipMemcpy(p->d_dir_pos, nz.data(), (size_t)K * 4, hipMemcpyHostToDevice));
+    CAF_HIP_TRY(hipMemcpy(p->d_dir_w, w.data(), w.size() * 8, hipMemcpyHostToDevice));
+    CAF_HIP_TRY(hipMemcpy(p->d_tscale, tscale.data(), (size_t)T * 4, hipMemcpyHostToDevice));
+    CAF_HIP_TRY(hipMemcpy(p->d_gstart, gs.data(), gs.size() * 4, hipMemcpyHostToDevice));
+    CAF_HIP_TRY(hipMemcpy(p->d_glen, gl.data(), gl.size() * 4, hipMemcpyHostToDevice));
+    CAF_HIP_TRY(hipMemcpy(p->d_uconj, uc.data(), uc.size() * 8, hipMemcpyHostToDevice));
+    CAF_HIP_TRY(hipMemcpy(p->d_nu, nu.data(), nu.size() * 8, hipMemcpyHostToDevice));
+    return CAF_OK;
+}
+
 static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
     CAF_REQUIRE(d->num_templates >= 1 && d->template_len >= 1 && d->h_templates, "need >= 1 template");
     CAF_REQUIRE(d->num_freqs >= 1, "need >= 1 frequency hypothesis");
@@ -354,8 +414,29 @@ static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
         CAF_REQUIRE(gs[g] >= 0 && gl[g] >= 1 && (int64_t)gs[g] + gl[g] <= N, "group outside the template span");
 
     // engine: the fused LDS-resident kernel works on 16384-point blocks
-    CAF_REQUIRE(d->engine >= CAF_ENGINE_AUTO && d->engine <= CAF_ENGINE_PERSISTENT && d->reserved == 0,
-                "bad engine field");
+    CAF_REQUIRE(d->engine >= CAF_ENGINE_AUTO && d->engine <= CAF_ENGINE_DIRECT && d->reserved == 0, "bad engine field");
+    {   // the direct engine: asked for, or chosen for composite templates whose groups cover fewer than 64 samples
+        int64_t support = 0;
+        for (int g = 0; g < p->G; ++g) support += gl[g];
+        static const bool auto_direct = [] {
+            const char* e = getenv("CAF_DIRECT");  // A/B switch for AUTO plans, default on
+            return !e || atoi(e);
+        }();
+        const bool composite = d->num_groups >= 1 && d->h_group_start && d->h_group_len;
+        if (d->engine == CAF_ENGINE_DIRECT || (d->engine == CAF_ENGINE_AUTO && auto_direct && composite && support < 64)) {
+            const std::complex<float>* tm0 = reinterpret_cast<const std::complex<float>*>(d->h_templates);
+            std::vector<int32_t> nz;  // union over the templates of their non-zero positions
+            for (int n = 0; n < N && nz.size() <= 64; ++n)
+                for (int t = 0; t < T; ++t)
+                    if (tm0[(size_t)t * N + n] != std::complex<float>(0.f, 0.f)) {
+                        nz.push_back(n);
+                        break;
+                    }
+            const bool ok = !nz.empty() && nz.size() <= 64;
+            CAF_REQUIRE(d->engine != CAF_ENGINE_DIRECT || ok, "the direct engine needs 1 .. 64 non-zero template samples");
+            if (ok) return plan_build_direct(p, d, gs, gl, nz);
+        }
+    }
     // the LDS-resident engines: 16384-point blocks for templates up to 8192 samples, 32768-point blocks (two chained
     // 16384-point transforms per hypothesis, persistent engine only) up to 16384
     const int fused_lb = N <= 8192 ? 14 : 15;
@@ -639,7 +720,10 @@ int32_t caf_plan_info(caf_plan plan, int32_t* block, int32_t* step, int32_t* blo
 
 int32_t caf_plan_engine(caf_plan plan, int32_t* engine) {
     CAF_REQUIRE(plan && engine, "NULL argument");
-    *engine = plan->persistent ? CAF_ENGINE_PERSISTENT : plan->fused ? CAF_ENGINE_FUSED : CAF_ENGINE_ROCFFT;
+    *engine = plan->direct ? CAF_ENGINE_DIRECT
+              : plan->persistent ? CAF_ENGINE_PERSISTENT
+              : plan->fused      ? CAF_ENGINE_FUSED
+                                 : CAF_ENGINE_ROCFFT;
     return CAF_OK;
 }
 
@@ -688,6 +772,23 @@ int32_t caf_plan_execute(caf_plan p, const float* d_rx, int64_t rx_len, int64_t 
     const float2* rx = reinterpret_cast<const float2*>(d_rx);
     const int T = p->T, F = p->F;
     const bool want_peak = out->d_peak_val || out->d_peak_delay || out->d_peak_freq;
+
+    if (p->direct) {
+        CAF_REQUIRE(!out->d_cqf, "the direct engine has no complex-QF output (create the plan with CAF_ENGINE_ROCFFT)");
+        p->stage_begin(3, st);
+        launch_direct_caf(rx, shift_start, num_shifts, T, F, p->dir_k, p->d_dir_pos, p->d_dir_w, p->d_tscale, out->d_surface,
+                          out->d_row_max, out->d_row_arg, want_peak ? p->d_partial : nullptr, p->partial_per_tmpl, st);
+        p->stage_end(st);
+        if (want_peak) {
+            p->stage_begin(6, st);
+            launch_peak_reduce(p->d_partial, (num_shifts + 255) / 256, p->partial_per_tmpl, T,
+                               p->d_partial + (int64_t)T * p->partial_per_tmpl, out->d_peak_val, out->d_peak_delay,
+                               out->d_peak_freq, st);
+            p->stage_end(st);
+        }
+        CAF_HIP_TRY(hipGetLastError());
+        return CAF_OK;
+    }
 
     const int64_t nblk = (num_shifts + p->step - 1) / p->step;
     const int64_t nblk_pad = (nblk + p->nb - 1) / p->nb * p->nb;

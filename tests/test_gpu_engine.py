@@ -404,3 +404,77 @@ def test_long_template_explicit_frequencies_and_many_hypotheses():
         rows = np.array([d - 1, d, d + 1, 50_000])
         ref = _oracle_rows(tm[i], rx, freqs, rows)
         np.testing.assert_allclose(a[i][rows], ref, atol=1e-4 * ref.max())
+
+
+def test_direct_engine_for_templates_with_a_handful_of_samples():
+    """Composite templates whose groups cover fewer than 64 samples go to the direct (time-domain) engine: the
+    overlap-save engines' float32 error follows the energy of a whole 16384-sample block, which for a normalisation
+    over 16 samples is 3-6e-5; the definition evaluated product by product is at 1e-6.  Checked: AUTO picks it, its
+    surface against the oracle's GroupXcorr plane at a tight tolerance, agreement with the persistent engine at the
+    wide one, rows / peak consistent with its own surface, the no-surface call, explicit selection and refusal."""
+    from pydsproutines_amd import CAFPlan, asarray
+
+    rng = np.random.default_rng(2024)
+    fs = 1000.0
+    starts = np.array([0, 700, 2991])
+    lengths = np.array([5, 2, 9])
+    span = int(starts[-1] + lengths[-1])
+    T, m = 2, 30000
+    freqs = np.linspace(-40.0, 40.0, 37)
+    ys = [cn(rng, span) for _ in range(T)]
+    rx = cn(rng, m)
+    comps = []
+    for y in ys:
+        c = np.zeros(span, np.complex64)
+        for s0, l in zip(starts, lengths):
+            c[s0 : s0 + l] = y[s0 : s0 + l]
+        comps.append(c)
+    d_true = [4321, 25000]
+    for i, d0 in enumerate(d_true):
+        rx[d0 : d0 + span] += (3 * comps[i] * np.exp(2j * np.pi * freqs[7 + 11 * i] * np.arange(span) / fs)).astype(np.complex64)
+    tm = np.stack(comps)
+    d_rx = asarray(rx)
+    kw = dict(max_rx_len=m, freqs_norm=freqs / fs, group_starts=starts, group_lens=lengths)
+    plan = CAFPlan(tm, **kw)
+    assert plan.engine_used == "direct"
+    S = m - span + 1
+    res = plan.run(d_rx, surface=True)
+    surf = res.surface.get()
+    assert surf.shape == (T, S, freqs.size)
+    rows = np.unique(np.concatenate((rng.integers(0, S, 300), d_true, [0, S - 1])))
+    for i in range(T):
+        ref = O.GroupXcorr(ys[i], starts, lengths, freqs, fs).caf(rx, rows)
+        assert np.max(np.abs(surf[i][rows] - ref)) <= 3e-6 * max(1.0, float(ref.max()))
+        np.testing.assert_array_equal(res.row_max.get()[i], surf[i].max(axis=1))
+        np.testing.assert_array_equal(res.row_arg.get()[i], np.argmax(surf[i], axis=1))
+        j = int(np.argmax(res.row_max.get()[i]))
+        assert int(res.peak_delay.get()[i]) == j == d_true[i]
+        assert float(res.peak_val.get()[i]) == res.row_max.get()[i][j] and int(res.peak_freq.get()[i]) == 7 + 11 * i
+    # no surface: identical rows and peaks; a sub-range equals the slice
+    r2 = plan.run(d_rx, surface=False)
+    np.testing.assert_array_equal(r2.row_max.get(), res.row_max.get())
+    np.testing.assert_array_equal(r2.row_arg.get(), res.row_arg.get())
+    np.testing.assert_array_equal(r2.peak_delay.get(), res.peak_delay.get())
+    r3 = plan.run(d_rx, shift_start=4000, num_shifts=1000, surface=True)
+    np.testing.assert_array_equal(r3.surface.get(), surf[:, 4000:5000])
+    assert int(r3.peak_delay.get()[0]) == d_true[0]
+    # the overlap-save engine agrees at ITS tolerance for such a template
+    per = CAFPlan(tm, engine="persistent", **kw).run(d_rx, surface=True)
+    scale = float(np.nanmax(surf))
+    assert np.nanmax(np.abs(per.surface.get() - surf)) <= 2e-5 * scale * 64.0 / lengths.sum()
+    np.testing.assert_array_equal(per.peak_delay.get(), res.peak_delay.get())
+    # explicit selection on a plain short template (bins mode), and the limit of 64 non-zero samples
+    t48 = qpsk(rng, 48)
+    rx48 = cn(rng, 5000)
+    rx48[1234 : 1234 + 48] += (2 * t48 * np.exp(2j * np.pi * 5 * np.arange(48) / 48)).astype(np.complex64)
+    b48 = np.arange(-8, 9)
+    pd48 = CAFPlan(t48, max_rx_len=5000, bins=b48, grid=48, engine="direct")
+    assert pd48.engine_used == "direct"
+    r48 = pd48.run(asarray(rx48), surface=True)
+    assert (int(r48.peak_delay.get()[0]), int(b48[r48.peak_freq.get()[0]])) == (1234, 5)
+    ref48 = O.caf_bins(t48, rx48, b48, np.arange(5000 - 48 + 1))
+    assert np.max(np.abs(r48.surface.get()[0] - ref48)) <= 3e-6 * float(ref48.max())
+    with pytest.raises(ValueError, match="64 non-zero"):
+        CAFPlan(qpsk(rng, 100), max_rx_len=5000, bins=[0], grid=100, engine="direct")
+    with pytest.raises(ValueError):
+        plan.run(d_rx, cqf=True)
