@@ -146,6 +146,28 @@ def w_c5_zoom():
             ("k_rows_mul_vec", "CZT spectral / output chirp multiplies (16 B per element)", 8 * nfft * 16.0 + 8 * 129 * 16.0, 0.0, 3)]
 
 
+def w_direct_small_support():
+    """Composite template with 16 samples of support over a 3000-sample span, 64 explicit frequencies, 2^22-sample rx:
+    the direct engine (what AUTO picks below 64 samples of support)."""
+    m, span, F2 = 1 << 22, 3000, 64
+    starts, lengths = np.array([0, 700, 2991]), np.array([5, 2, 9])
+    comp = np.zeros(span, np.complex64)
+    y = cn(rng, span)
+    for a, l in zip(starts, lengths):
+        comp[a : a + l] = y[a : a + l]
+    d_rx = asarray(cn(rng, m))
+    plan = CAFPlan(comp, max_rx_len=m, freqs_norm=np.linspace(-0.04, 0.04, F2), group_starts=starts, group_lens=lengths)
+    assert plan.engine_used == "direct"
+    res = None
+    for _ in range(3):
+        res = plan.run(d_rx, surface=True, rows=True, peak=True, out=res)
+    sync()
+    s2, k = m - span + 1, int(lengths.sum())
+    plan.close()
+    return [("k_direct_caf", "direct engine: 16 products per (delay, hypothesis), 64 hypotheses, surface written "
+             "(8 B read per sample, 4 B written per cell + 8 B per delay)", m * 8.0 + s2 * (F2 * 4.0 + 8.0), s2 * F2 * (8.0 * k + 3), 3)]
+
+
 def perdelay(n, num, label):
     rx = cn(rng, n + num)
     d_rx, d_cut = asarray(rx), asarray(rx[500 : 500 + n].conj().copy())
