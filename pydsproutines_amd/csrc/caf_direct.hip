@@ -9,13 +9,13 @@
 //     w_{t,f,k} = conj(u_t[n_k]) * exp(-j 2 pi nu_f n_k)   (float64 on the host, rounded once),
 // which is what GroupXcorr.xcorr evaluates per delay (freqMat @ product, :917-954).  One thread per delay; the
 // multipliers are wave-uniform (scalar loads), the samples run with the lane (coalesced, L1-resident across the
-// hypothesis loop); eight hypotheses share each sample load.  The window energy is the float64 sum over the K
+// hypothesis loop); sixteen hypotheses share each sample load.  The window energy is the float64 sum over the K
 // samples themselves (no prefix differences), so a window of zeros has energy exactly 0.
 #include "caf_internal.h"
 
 namespace caf {
 
-constexpr int DIR_FCHUNK = 8;
+constexpr int DIR_FCHUNK = 16;  // hypotheses per sample load (and 64-byte surface segments per delay)
 
 __global__ __launch_bounds__(256) void k_direct_caf(const float2* __restrict__ rx, int64_t shift_start, int64_t num_shifts,
                                                     int32_t ntmpl, int32_t nfreq, int32_t nk, const int32_t* __restrict__ pos,
