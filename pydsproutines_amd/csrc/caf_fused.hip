@@ -98,6 +98,17 @@ __device__ __forceinline__ void tile_store(__amdgpu_buffer_rsrc_t r, uint32_t vo
 // MODE 0: |y|^2 tiles with plain stores; 1: with write-through (sc1) stores; 2: no tiles at all -- every thread
 // keeps the running maximum (value + hypothesis) of its 16 delays over the item's hypotheses and writes one
 // (value, hypothesis) pair per delay at the end (callers that want no surface: per-delay traces and peaks only).
+// MODE 3 (no frequency scan, one hypothesis per template: config C3, TemplateCrossCorrelator-style banks): every |y|^2
+// IS a per-delay result, so the FFT item normalises it and writes it where the caller wants it -- row_max (T, S) and / or
+// the (T, S, 1) surface -- instead of a tile that a second role reads back, scales and writes again.
+struct F1Direct {
+    float* out0;          // row_max or surface, [T][num_shifts]
+    float* out1;          // the other one of the two when both are wanted, else nullptr
+    const float* inv_e;   // [num_shifts] 1 / window energy
+    const float* tscale;  // [T]
+    int64_t num_shifts;
+    int32_t step, blk_abs;
+};
 template <int FT, int MODE = 0>
 __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float2* __restrict__ s_tw2,
                                            const float2* __restrict__ s_tw3,
@@ -107,9 +118,9 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
                                            const float2* __restrict__ tw1,      // [16][1024]
                                            int32_t table_mode, int32_t nfreq, int32_t nhyp, int blk, int h0, int h1,
                                            int32_t tiles_per_blk, float* __restrict__ vt,
-                                           int32_t* __restrict__ imax = nullptr) {
+                                           int32_t* __restrict__ imax = nullptr, const F1Direct* f1 = nullptr) {
     constexpr int BPT = 1024 / FT;
-    static_assert(MODE != 2 || BPT == 1, "the running-maximum mode is written for one butterfly per thread");
+    static_assert(MODE < 2 || BPT == 1, "the running-maximum and direct-row modes are written for one butterfly per thread");
     const int tid = threadIdx.x;
     float bv[16];     // MODE 2: running maxima of this thread's 16 delays ...
     uint32_t bi[4];   // ... and the item-local hypothesis (8 bits each) that produced them
@@ -118,6 +129,24 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
         for (int o = 0; o < 16; ++o) bv[o] = -1.f;
 #pragma unroll
         for (int o = 0; o < 4; ++o) bi[o] = 0u;
+    }
+    // MODE 3: 1 / window energy of this thread's 16 delays (bv doubles as their storage), the valid extent of the block
+    uint32_t f1_bytes = 0;
+    int64_t f1_rel0 = 0;
+    if (MODE == 3) {
+        f1_rel0 = (int64_t)f1->blk_abs * f1->step;
+        int64_t nv = f1->num_shifts - f1_rel0;
+        if (nv > f1->step) nv = f1->step;
+        f1_bytes = (uint32_t)nv * 4u;
+        const __amdgpu_buffer_rsrc_t rie = buf_of(uniform_ptr(f1->inv_e + f1_rel0), f1_bytes);  // delays past the end: 0
+        const int n1 = tid & 15, n2 = (tid >> 4) & 15, q = tid >> 8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int n4 = 0; n4 < 4; ++n4)
+                bv[4 * i + n4] = __builtin_bit_cast(
+                    float, __builtin_amdgcn_raw_buffer_load_b32(rie, (((n2 >> 2) + 4 * q) * 64 + n1 + 16 * (n2 & 3)) * 4,
+                                                                (16 * i + 64 * n4) * 256, 0));
     }
 
     // hypothesis-independent per-thread state: the pass-1 twiddle base e^{+j 2 pi m2 / 16384}
@@ -165,6 +194,15 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
         asm volatile("" : "+s"(hoff));
         int lz = 0;  // an opaque zero added to loop-invariant LDS table indices (see pass 1)
         asm volatile("" : "+v"(lz));
+        // MODE 3: this hypothesis' (= template's) output rows and scale
+        __amdgpu_buffer_rsrc_t f1_r0 = rvt, f1_r1 = rvt;
+        float f1_ts = 0.f;
+        if (MODE == 3) {
+            f1_ts = *((const CAF_AS1 float*)f1->tscale + h);
+            f1_r0 = buf_of(uniform_ptr(f1->out0 + (int64_t)h * f1->num_shifts + f1_rel0), f1_bytes);  // past the block's
+            if (f1->out1)                                                                            // delays: dropped
+                f1_r1 = buf_of(uniform_ptr(f1->out1 + (int64_t)h * f1->num_shifts + f1_rel0), f1_bytes);
+        }
         // ---- pass 1: P = X * Hc_h ; DFT16 over a ; twiddle w^n1 ; write A[n1][m2] ----
         // One butterfly at a time (32 live data registers).  pr is dead after this pass and is refilled
         // with the next hypothesis' products during pass 4, the low-pressure phase.
@@ -227,7 +265,7 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
         // next hypothesis' template-spectrum row: issued before pass 3 so that the L2 latency is covered by
         // the pass-3 butterfly and the pass-4 work
         float2 hn[BPT][16];
-        if (MODE != 2) {
+        if (MODE < 2) {
 #pragma unroll
             for (int j = 0; j < BPT; ++j)
 #pragma unroll
@@ -255,7 +293,7 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
                 for (int n3 = 0; n3 < 16; ++n3) s_d[base + 4 * n3] = v[j][n3];
             }
         }
-        if (MODE == 2) {
+        if (MODE >= 2) {
             // (the 20 registers of the running maxima leave no room for the row during pass 3: it is fetched here,
             // under the barrier and the pass-4 work; there are no tile stores to compete with in this mode)
 #pragma unroll
@@ -305,6 +343,12 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
                         const uint32_t sh8 = 8u * (uint32_t)(oo & 3);
                         const uint32_t repl = (bi[oo >> 2] & ~(0xffu << sh8)) | ((uint32_t)(h - h0) << sh8);
                         bi[oo >> 2] = up ? repl : bi[oo >> 2];
+                    } else if (MODE == 3) {
+                        // the finished per-delay value, rounded as the tile roles round it: value * (1/energy * 1/||t||^2)
+                        const float outv = val * (bv[4 * i + n4] * f1_ts);
+                        const uint32_t v3 = (uint32_t)(tile_t * 64 + n1 + 16 * (n2 & 3)) << 2, s3 = (uint32_t)tile_u * 256u;
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, outv), f1_r0, (int)v3, (int)s3, 0);
+                        if (f1->out1) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, outv), f1_r1, (int)v3, (int)s3, 0);
                     } else {
                         tile_store<MODE>(rvt, voff, soff, val);  // tiles >= tiles_per_blk: dropped by the range check
                     }
@@ -1217,7 +1261,7 @@ __device__ __forceinline__ void pq_mark(const PersistParams* pp, int slot, int v
 // spilled values every hypothesis).  Called ~21 times per workgroup: the call and the callee-saved register
 // traffic are negligible.  Arguments arrive in VGPRs; v_readfirstlane makes them scalar again.
 typedef __attribute__((address_space(3))) float2 lds_float2;
-template <bool NOSURF>
+template <int KIND>  // 0: |y|^2 tiles, 1: running maxima (no surface), 2: finished rows (no frequency scan)
 __device__ __attribute__((noinline)) void persistent_fft_item(lds_float2* s_d, const lds_float2* s_tw2,
                                                               const lds_float2* s_tw3, const PersistParams* pp_in,
                                                               int item_in) {
@@ -1234,7 +1278,18 @@ __device__ __attribute__((noinline)) void persistent_fft_item(lds_float2* s_d, c
         h0 = t * P->nfreq + (grp - t * gpt) * hyp_per_wg;
         h1 = min(h0 + hyp_per_wg, (t + 1) * P->nfreq);
     }
-    if (NOSURF) {
+    if (KIND == 2) {
+        F1Direct f1;
+        f1.out0 = P->row_max ? P->row_max : P->surface;
+        f1.out1 = (P->row_max && P->surface) ? P->surface : nullptr;
+        f1.inv_e = P->inv_e;
+        f1.tscale = P->tscale;
+        f1.num_shifts = P->num_shifts;
+        f1.step = P->step;
+        f1.blk_abs = P->blk0 + blk;
+        fused_item<1024, 3>((float2*)s_d, (const float2*)s_tw2, (const float2*)s_tw3, P->xb, P->hc, P->shifts, P->tw1,
+                            P->table_mode, P->nfreq, nhyp, blk, h0, h1, P->tiles_per_blk, nullptr, nullptr, &f1);
+    } else if (KIND == 1) {
         // no surface wanted: one (maximum, hypothesis) pair per delay and item instead of the |y|^2 tiles
         const int64_t o = ((int64_t)blk * ngroups + grp) * P->tiles_per_blk * 64;
         fused_item<1024, 2>((float2*)s_d, (const float2*)s_tw2, (const float2*)s_tw3, P->xb, P->hc, P->shifts, P->tw1,
@@ -1372,10 +1427,12 @@ __global__ __launch_bounds__(1024) void k_caf_persistent(const PersistParams* __
         if (kind == 1) {
             if (__builtin_amdgcn_readfirstlane(params_of(pp)->block_log2) == 15)
                 persistent_fft_item2((lds_float2*)s_d, (const lds_float2*)s_tw2, (const lds_float2*)s_tw3, pp, item);
+            else if (__builtin_amdgcn_readfirstlane(params_of(pp)->f1_direct))
+                persistent_fft_item<2>((lds_float2*)s_d, (const lds_float2*)s_tw2, (const lds_float2*)s_tw3, pp, item);
             else if (__builtin_amdgcn_readfirstlane(params_of(pp)->nosurf))
-                persistent_fft_item<true>((lds_float2*)s_d, (const lds_float2*)s_tw2, (const lds_float2*)s_tw3, pp, item);
+                persistent_fft_item<1>((lds_float2*)s_d, (const lds_float2*)s_tw2, (const lds_float2*)s_tw3, pp, item);
             else
-                persistent_fft_item<false>((lds_float2*)s_d, (const lds_float2*)s_tw2, (const lds_float2*)s_tw3, pp, item);
+                persistent_fft_item<0>((lds_float2*)s_d, (const lds_float2*)s_tw2, (const lds_float2*)s_tw3, pp, item);
             if (STATS) {
                 const uint64_t now = wall_clock64();
                 t_fft += (uint32_t)(now - tmark);

@@ -41,6 +41,10 @@ int64_t prefix_num_tiles(int64_t m);
 void launch_energy_prefix(const float2* rx, int64_t m, double* tile_sums, double* prefix, hipStream_t st);
 void launch_inv_energy(const double* prefix, int64_t shift_start, int64_t num_shifts, const int32_t* gstart,
                        const int32_t* glen, int32_t ngroups, float* inv_e, hipStream_t st);
+// peak records from finished (T, S) rows: rows_peak_chunks(S) records per template
+int64_t rows_peak_chunks(int64_t num_shifts);
+void launch_rows_peak(const float* rows, int32_t ntmpl, int64_t num_shifts, int64_t shift_start, PeakRec* partial,
+                      int64_t partial_per_tmpl, hipStream_t st);
 // direct (time-domain) engine over nk <= 64 non-zero template positions (caf_direct.hip)
 void launch_direct_caf(const float2* rx, int64_t shift_start, int64_t num_shifts, int32_t ntmpl, int32_t nfreq, int32_t nk,
                        const int32_t* pos, const float2* w, const float* tscale, float* surface, float* row_max,
@@ -206,6 +210,7 @@ struct PersistParams {
     int32_t* pq;
     int32_t tr_slots, ngroups, n_fft, ipb, n_tr;
     int32_t nosurf;  // 1: no |y|^2 tiles; per item one (maximum, hypothesis) pair per delay in vmax / imax
+    int32_t f1_direct;  // 1 (nfreq == 1): the FFT items write the finished per-delay values to row_max / surface; no tile items
     float* vmax;     // [block][group][tile][64]
     int32_t* imax;
     int32_t* dbg;  // optional host-mapped progress marks (CAF_PERSIST_DEBUG), 4 ints per workgroup

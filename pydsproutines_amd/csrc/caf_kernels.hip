@@ -423,9 +423,55 @@ __global__ __launch_bounds__(1024) void k_peak_reduce(const PeakRec* __restrict_
     }
 }
 
+// Peak records from finished per-delay rows (T, S) float32 (the no-frequency-scan mode of the persistent engine writes
+// the rows directly): workgroup (chunk, t) scans RP_CHUNK delays of row t -- highest value, lowest delay on ties, NaN
+// never -- and leaves one record; k_peak_reduce finishes.
+constexpr int RP_CHUNK = 16384;
+__global__ __launch_bounds__(256) void k_rows_peak(const float* __restrict__ rows, int64_t num_shifts, int64_t shift_start,
+                                                   PeakRec* __restrict__ partial, int64_t partial_per_tmpl) {
+    __shared__ PeakRec s_w[4];
+    const int t = blockIdx.y;
+    const int64_t i0 = (int64_t)blockIdx.x * RP_CHUNK, i1 = min(num_shifts, i0 + RP_CHUNK);
+    const float* r = rows + (int64_t)t * num_shifts;
+    PeakRec b;
+    b.v = -1.f;
+    b.delay = 0x7fffffff;
+    b.f = 0;
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+        const float v = r[i];
+        if (v > b.v) {  // increasing delay per thread: the first maximum stays
+            b.v = v;
+            b.delay = (int32_t)(shift_start + i);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(b.v, o, 64);
+        const int32_t od = __shfl_xor(b.delay, o, 64);
+        if (ov > b.v || (ov == b.v && od < b.delay)) {
+            b.v = ov;
+            b.delay = od;
+        }
+    }
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = b;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (s_w[w].v > b.v || (s_w[w].v == b.v && s_w[w].delay < b.delay)) b = s_w[w];
+        partial[(int64_t)t * partial_per_tmpl + blockIdx.x] = b;
+    }
+}
+
 // ----------------------------------------------------------------------------------------
 // Launch wrappers (host)
 // ----------------------------------------------------------------------------------------
+int64_t rows_peak_chunks(int64_t num_shifts) { return (num_shifts + RP_CHUNK - 1) / RP_CHUNK; }
+void launch_rows_peak(const float* rows, int32_t ntmpl, int64_t num_shifts, int64_t shift_start, PeakRec* partial,
+                      int64_t partial_per_tmpl, hipStream_t st) {
+    hipLaunchKernelGGL(k_rows_peak, dim3((unsigned)rows_peak_chunks(num_shifts), (unsigned)ntmpl), dim3(256), 0, st, rows,
+                       num_shifts, shift_start, partial, partial_per_tmpl);
+}
+
 int64_t prefix_num_tiles(int64_t m) { return (m + 1 + PFX_TILE - 1) / PFX_TILE; }
 
 void launch_energy_prefix(const float2* rx, int64_t m, double* tile_sums, double* prefix, hipStream_t st) {

@@ -846,6 +846,7 @@ int32_t caf_plan_execute(caf_plan p, const float* d_rx, int64_t rx_len, int64_t 
     if (p->fused && p->B == 32768)  // block spectra parity-major for the two chained half-transforms
         launch_parity_major(p->d_xb, p->d_xb2, nfwd * p->fwd_chunk, p->B / 2, st);
     if (aux) CAF_HIP_TRY(hipStreamWaitEvent(st, p->ev_join, 0));
+    bool f1_direct = false;
     if (p->fused) {
         CAF_REQUIRE(!out->d_cqf, "the fused engine has no complex-QF output (create the plan with CAF_ENGINE_ROCFFT)");
         // No surface wanted (per-delay traces / peaks only): the FFT items keep running per-delay maxima and
@@ -866,6 +867,13 @@ int32_t caf_plan_execute(caf_plan p, const float* d_rx, int64_t rx_len, int64_t 
         CAF_REQUIRE(ns_gpt || (int64_t)(p->B / 64) * T * F * 256 < ((int64_t)1 << 32),
                     "too many hypotheses (templates x frequencies) for one launch with |y|^2 tiles: ask for no surface, "
                     "or split the templates over several plans");
+        // No frequency scan (F == 1) with per-delay rows wanted: the FFT items write the finished rows themselves
+        // (fused_item MODE 3) and there are no tile items at all; row_arg is all zeros and the peaks come from the rows.
+        static const bool f1_env = [] {
+            const char* e = getenv("CAF_PERSIST_F1DIRECT");  // A/B switch, default on
+            return !e || atoi(e);
+        }();
+        f1_direct = p->persistent && p->B == 16384 && F == 1 && f1_env && (out->d_row_max || out->d_surface);
         const int nb_launch = ns_gpt ? p->nb_nosurf : p->nb;  // blocks per launch
         for (int64_t b0 = 0; p->persistent && b0 < nblk; b0 += nb_launch) {
             const int32_t nbk = (int32_t)std::min<int64_t>(nb_launch, nblk - b0);
@@ -910,6 +918,10 @@ int32_t caf_plan_execute(caf_plan p, const float* d_rx, int64_t rx_len, int64_t 
             h.n_fft = nbk * h.ngroups;
             h.ipb = (p->tiles_per_blk + 15) / 16;  // 16 tiles per item (PQ_TILES, caf_fused.hip)
             h.n_tr = nbk * h.ipb;
+            if (f1_direct) {
+                h.f1_direct = 1;
+                h.n_tr = 0;
+            }
             // both stages are one kernel: its time is booked on the multiply/FFT stage
             int32_t* h_dbg = nullptr;
             // CAF_PERSIST_DEBUG=1: role statistics of every launch; =2: of every 10th launch only, so that the nine before it
@@ -1029,12 +1041,19 @@ int32_t caf_plan_execute(caf_plan p, const float* d_rx, int64_t rx_len, int64_t 
                      want_peak ? p->d_partial : nullptr, p->partial_per_tmpl, st);
         p->stage_end(st);
     }
+    // one hypothesis per template: its index is 0 everywhere.  (On this stream, after the launch: a fill running beside
+    // the persistent kernel on another stream takes CUs from its resident workgroups -- measured 0.6 ms slower.)
+    if (f1_direct && out->d_row_arg) CAF_HIP_TRY(hipMemsetAsync(out->d_row_arg, 0, (size_t)T * (size_t)num_shifts * 4, st));
     if (want_peak) {
         p->stage_begin(6, st);
-        // only the records of the blocks touched by this call are valid
-        launch_peak_reduce(p->d_partial, (p->fused ? nblk : nblk_pad) * p->tiles_per_blk, p->partial_per_tmpl, T,
-                           p->d_partial + (int64_t)T * p->partial_per_tmpl, out->d_peak_val,
-                           out->d_peak_delay, out->d_peak_freq, st);
+        int64_t nrec = (p->fused ? nblk : nblk_pad) * p->tiles_per_blk;  // only the records of the blocks touched by this call
+        if (f1_direct) {
+            launch_rows_peak(out->d_row_max ? out->d_row_max : out->d_surface, T, num_shifts, shift_start, p->d_partial,
+                             p->partial_per_tmpl, st);
+            nrec = rows_peak_chunks(num_shifts);
+        }
+        launch_peak_reduce(p->d_partial, nrec, p->partial_per_tmpl, T, p->d_partial + (int64_t)T * p->partial_per_tmpl,
+                           out->d_peak_val, out->d_peak_delay, out->d_peak_freq, st);
         p->stage_end(st);
     }
     CAF_HIP_TRY(hipGetLastError());
