@@ -124,7 +124,8 @@ class CAFPlan:
         """Asynchronous execute on device-resident rx (DeviceArray or CUDA torch tensor).
 
         Returns a CAFResult of DeviceArrays: surface (T,S,F) float32 if requested, row_max (T,S)
-        float32 / row_arg (T,S) int32 if ``rows``, peak_val/peak_delay/peak_freq (T,) if ``peak``.
+        float32 / row_arg (T,S) int32 if ``rows`` (``rows="max"``: row_max only), peak_val/peak_delay/peak_freq (T,)
+        if ``peak``.
         Pass ``out`` (a previous CAFResult) to reuse its buffers.
         """
         ptr, nbytes = as_device_ptr(rx)
@@ -135,8 +136,10 @@ class CAFPlan:
         res = out if out is not None else CAFResult()
         if surface and res.surface is None:
             res.surface = empty((self.T, S, self.F), np.float32)
+        want_arg = bool(rows) and rows != "max"  # rows="max": the per-delay maxima only (no argument array)
         if rows and res.row_max is None:
             res.row_max = empty((self.T, S), np.float32)
+        if want_arg and res.row_arg is None:
             res.row_arg = empty((self.T, S), np.int32)
         if peak and res.peak_val is None:
             res.peak_val = empty((self.T,), np.float32)
@@ -148,7 +151,7 @@ class CAFPlan:
         o.d_cqf = res.cqf.ptr if cqf else None
         o.d_surface = res.surface.ptr if surface else None
         o.d_row_max = res.row_max.ptr if rows else None
-        o.d_row_arg = res.row_arg.ptr if rows else None
+        o.d_row_arg = res.row_arg.ptr if want_arg else None
         o.d_peak_val = res.peak_val.ptr if peak else None
         o.d_peak_delay = res.peak_delay.ptr if peak else None
         o.d_peak_freq = res.peak_freq.ptr if peak else None

@@ -437,9 +437,21 @@ __global__ __launch_bounds__(256) void k_rows_peak(const float* __restrict__ row
     b.v = -1.f;
     b.delay = 0x7fffffff;
     b.f = 0;
-    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+    typedef float rp_v4 __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte loads at 4-byte alignment
+    int64_t i = i0 + 4 * (int64_t)threadIdx.x;
+    for (; i + 3 < i1; i += 1024) {
+        const rp_v4 q = *reinterpret_cast<const rp_v4*>(r + i);
+        const float x[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (x[k] > b.v || (x[k] == b.v && (int32_t)(shift_start + i + k) < b.delay)) {
+                b.v = x[k];
+                b.delay = (int32_t)(shift_start + i + k);
+            }
+    }
+    for (; i < i1; ++i) {  // (at most three values, of one thread)
         const float v = r[i];
-        if (v > b.v) {  // increasing delay per thread: the first maximum stays
+        if (v > b.v || (v == b.v && (int32_t)(shift_start + i) < b.delay)) {
             b.v = v;
             b.delay = (int32_t)(shift_start + i);
         }

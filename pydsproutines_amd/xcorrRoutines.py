@@ -419,7 +419,7 @@ class TemplateCrossCorrelator:
             # engine (no complex plane), then the maximum of their square roots over the templates
             if self._plan_max is None:
                 self._plan_max = CAFPlan(self._tm, max_rx_len=self._inputSize, bins=[0], grid=self._grid)
-            res = self._plan_max.run(x, surface=False, rows=True, peak=False)
+            res = self._plan_max.run(x, surface=False, rows="max", peak=False)
             qf = empty(S, np.float32)
             ti = empty(S, np.int64)
             _lib.check(_lib.load().caf_colmax_sqrt(ct.c_void_p(res.row_max.ptr), T, S, ct.c_void_p(qf.ptr),

@@ -57,7 +57,9 @@ def caf(engine, surface, T=1, F=256, reps=2, rows=True):
         elif F >= 64:
             gpt = -(-F // 64)
             alg = nblk * (tiles * 64 * T * gpt * 8.0 * 2 + 8.0 * B * (T * F / 64.0 + 1)) + T * S * 12.0
-        else:  # F == 1 streaming tile role: tiles written + read, traces written
+        elif F == 1:  # the FFT items write the finished rows themselves (no tiles): block spectra read, rows written
+            alg = nblk * 8.0 * B * (T / 64.0 + 1) + T * S * 4.0
+        else:  # fewer frequencies than a group: tiles written + read, traces written
             alg = nblk * (tiles * 64 * T * F * 4.0 * 2 + 8.0 * B * (T * F / 64.0 + 1)) + T * S * 8.0
         man.append(("k_caf_persistent", "one-launch engine, T=%d F=%d %s" % (T, F, "surface" if surface else "no surface"),
                     alg, fft_flops, reps))
@@ -69,6 +71,8 @@ def caf(engine, surface, T=1, F=256, reps=2, rows=True):
         Bc = plan.block
         man.append(("k_spectral_mul", "X * conj(H_h) for all hypotheses (8(1+2/F) B per point)", nblk * 8.0 * Bc * (T * F + 2), 0.0, reps))
         man.append(("k_magsq_norm_argmax", "|.|^2 + normalise + argmax (8 B read + 4 B write per cell)", cells * (8.0 + (4.0 if surface else 0.0)) + T * S * 12.0, 0.0, reps))
+    if plan.engine_used == "persistent" and F == 1 and not surface:
+        man.append(("k_rows_peak", "peak records from the finished rows (4 B read per template and delay)", T * S * 4.0, 0.0, reps))
     if plan.engine_used in ("persistent", "fused") and B == 16384:
         # gather + in-LDS forward transform + sliding energies in one launch: rx samples read once per block, spectra
         # and 1/energy written
