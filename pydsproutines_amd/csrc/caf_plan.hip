@@ -521,6 +521,19 @@ static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p->device);
         const int64_t want = ((int64_t)T * F * total_blocks + 2 * cus - 1) / (2 * cus);
         p->hyp_per_wg = (int)std::min<int64_t>(p->hyp_per_wg, std::max<int64_t>(4, want));
+        // whole rounds: 1365 items of 64 hypotheses on 256 CUs are 5.33 rounds, i.e. 6 with a third of the chip idle in
+        // the last one (config C3); halve the items while that buys more than the extra block-spectrum loads cost
+        if (!getenv("CAF_HYP_PER_WG")) {
+            auto eff = [&](int hp) {
+                const int64_t items = (((int64_t)T * F + hp - 1) / hp) * total_blocks;
+                const int64_t rounds = (items + cus - 1) / cus;
+                return (double)items / (double)(rounds * cus);
+            };
+            int best = p->hyp_per_wg;
+            for (int hp = best / 2; hp >= 16; hp /= 2)
+                if (eff(hp) > eff(best) + 0.03) best = hp;
+            p->hyp_per_wg = best;
+        }
         // groups that do not straddle templates allow the no-surface mode (running maxima instead of tiles):
         // prefer the largest divisor of F that is not much smaller than the group size chosen above
         if (F % p->hyp_per_wg != 0)
