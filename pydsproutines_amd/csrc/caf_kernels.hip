@@ -440,7 +440,7 @@ __global__ __launch_bounds__(256) void k_rows_peak(const float* __restrict__ row
     typedef float rp_v4 __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte loads at 4-byte alignment
     int64_t i = i0 + 4 * (int64_t)threadIdx.x;
     for (; i + 3 < i1; i += 1024) {
-        const rp_v4 q = *reinterpret_cast<const rp_v4*>(r + i);
+        const rp_v4 q = __builtin_nontemporal_load(reinterpret_cast<const rp_v4*>(r + i));  // read once
         const float x[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k)
