@@ -186,7 +186,14 @@ __global__ __launch_bounds__(1024) void k_probe(const float2* __restrict__ xb, c
         float2 hn[16];
         auto hload = [&](int a) {
             const uint32_t e = (uint32_t)(((1024 * a + tid - sh_cur) & (FB - 1)) + lz);
-            if (FLAGS & 16384) {
+            if (FLAGS & 16777216) {
+                // device-scope load (sc1): skips the CU's L1, which a 128 KB row per transform cannot use anyway
+                const uint64_t u = __hip_atomic_load(reinterpret_cast<const CAF_AS1 uint64_t*>((const CAF_AS1 char*)hrow_cur + (e << 3)),
+                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                float2 r;
+                __builtin_memcpy(&r, &u, 8);
+                hn[a] = r;
+            } else if (FLAGS & 16384) {
                 const uint64_t u = __builtin_nontemporal_load(reinterpret_cast<const CAF_AS1 uint64_t*>((const CAF_AS1 char*)hrow_cur + (e << 3)));
                 float2 r;
                 __builtin_memcpy(&r, &u, 8);
@@ -841,6 +848,13 @@ int main() {
             run<111>(what, xb, hc, sh, tw1, tw23, vt, nblk);
         }
         g_threads = 1024;
+        return 0;
+    }
+    if (getenv("PROBE_HLOAD")) {
+        for (int rep = 0; rep < 3; ++rep) {
+            run<0>("full loop", xb, hc, sh, tw1, tw23, vt, nblk);
+            run<16777216>("template-spectrum row loads at device scope (sc1: no L1)", xb, hc, sh, tw1, tw23, vt, nblk);
+        }
         return 0;
     }
     if (getenv("PROBE_DPP")) {
