@@ -389,7 +389,7 @@ class TemplateCrossCorrelator:
 
     ``fastMax`` (not upstream, default off): ``correlate(returnMax=True)`` then runs the one-launch engine on
     per-template QF^2 traces and never forms the complex plane (config C3, 64 templates x 4096 vs 2^24 samples:
-    4.7 ms instead of 17 ms).  Off, the returnMax output is bit-for-bit the column max / argmax of the complex output,
+    4.6 ms instead of 17 ms).  Off, the returnMax output is bit-for-bit the column max / argmax of the complex output,
     the property the reference's unit test asserts (xcorrRoutines.py:2229-2233); on, it agrees with it to
     float32 rounding (different FFT)."""
 
