@@ -333,6 +333,44 @@ def run_c4(args, torch, dist, device, world, rank, rehearse):
     print(json.dumps(out))
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` started by hand (no torchrun): start N child processes of this script, one per
+    LOCAL_RANK, with the rendezvous variables torch.distributed reads (127.0.0.1, a free port), wait for all of them,
+    print rank 0's JSON line and return non-zero if any rank failed.  The parent never initialises the GPU (children are
+    separate processes started with subprocess, never an exec of a process that has touched the device)."""
+    import socket
+    import subprocess
+
+    import torch  # device_count() does not initialise the GPU on this image
+
+    rehearse = os.environ.get("BENCH_REHEARSE_GLOO") == "1"
+    have = torch.cuda.device_count()
+    if not rehearse and have < n:
+        print("bench.py --gpus %d: only %d GPU(s) visible (set BENCH_REHEARSE_GLOO=1 to rehearse the %d-rank code path "
+              "on fewer GPUs over gloo)" % (n, have, n), file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, WORLD_SIZE=str(n), RANK=str(r), LOCAL_RANK=str(r), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    line = [ln for ln in (out0 or "").splitlines() if ln.startswith("{")]
+    if any(codes) or not line:
+        print("bench.py --gpus %d: rank exit codes %r" % (n, codes), file=sys.stderr)
+        return 1
+    if json.loads(line[-1]).get("n_gpus") != n:
+        print("bench.py --gpus %d: the world that formed reports n_gpus=%r" % (n, json.loads(line[-1]).get("n_gpus")), file=sys.stderr)
+        return 1
+    print(line[-1])
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -346,17 +384,31 @@ def main():
     ap.add_argument("--engine", default="auto", choices=["auto", "persistent", "fused", "rocfft"])
     ap.add_argument("--no-surface", action="store_true", help="peak-only mode (no CAF surface written)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rx-log2", type=int, default=24,
+                    help="log2 of the rx length (24 = BASELINE's configuration; smaller values are for rehearsals and "
+                         "tests only and say so in config.workload)")
     ap.add_argument("--no-side-figure", action="store_true",
                     help="skip the untimed no-surface side run (profiling: only the measured configuration launches)")
     args = ap.parse_args()
+
+    # --gpus N without a launcher: this process becomes the launcher.  It starts one child per rank (before anything
+    # here touches the GPU), waits for them and forwards rank 0's JSON line; see launch_ranks().
+    global M_RX, D0
+    if args.rx_log2 != 24:
+        if not 16 <= args.rx_log2 <= 26:
+            raise SystemExit("--rx-log2 must be within 16..26")
+        M_RX = 1 << args.rx_log2
+        D0 = min(D0, M_RX // 3)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
 
     import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but the world that formed has WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     # Rehearsal switch (NOT the measured configuration): BENCH_REHEARSE_GLOO=1 runs the N-rank code path
@@ -442,6 +494,11 @@ def main():
     elapsed = time.perf_counter() - t0
     stages = plan.profile_get()
     plan.profile(False)
+    # the timed steps themselves must have produced the planted peak (not only the warm-up)
+    pk = t_peak.cpu().numpy()
+    got = (int(pk[0]), int(bins[pk[1]]), float(pk[2:3].view(np.float32)[0]))
+    if got[:2] != (D0, K0):
+        raise SystemExit("rank %d: wrong peak after the timed steps %r, expected (%d, %d)" % (rank, got, D0, K0))
 
     # side figure (not the metric): the same job when only the per-delay argmax and the peak are wanted
     extra = None
@@ -526,7 +583,8 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "C2: 1x4096-sample template vs 2^24-sample rx, 256 on-grid freq bins, "
+                "workload": ("C2" if M_RX == 1 << 24 else "REHEARSAL SIZE (not C2)")
+                + ": 1x4096-sample template vs 2^%d-sample rx, 256 on-grid freq bins, " % int(np.log2(M_RX))
                 + ("full CAF surface f32[S][256] + per-delay argmax + peak" if surface_on else "per-delay argmax + peak only"),
                 "templates_per_gpu": 1, "freq_bins": F_BINS, "rx_len": M_RX, "delays": S,
                 "block": B, "blocks_per_batch": nb, "parallelism": "template-shard x%d" % world,
@@ -574,7 +632,7 @@ def main():
         if extra is not None:
             out["no_surface"] = extra
         if world == 1 and not args.no_cpu_baseline:
-            rx_h, tm_h = rx[: D0 + 560000].cpu().numpy(), tmpl.cpu().numpy()
+            rx_h, tm_h = rx[: min(M_RX, D0 + 560000)].cpu().numpy(), tmpl.cpu().numpy()
             out["cpu_baseline"] = cpu_baseline(rx_h, tm_h, bins)
             out["cpu_baseline_threaded"] = cpu_baseline_threaded(rx_h, tm_h)
             out["cpu_baseline_same_algorithm"] = cpu_baseline_same_algorithm(rx_h, tm_h, bins)

@@ -154,3 +154,50 @@ def test_c4_step_sharded_equals_single_process(world):
         assert p.exitcode == 0
     for r in range(world):
         np.testing.assert_array_equal(got[r], single)
+
+
+# ---- bench.py --gpus N starts its own ranks (no torchrun needed) and never silently measures fewer GPUs ----
+def _run_bench(extra_env, *argv, timeout=600):
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(extra_env)
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + list(argv), env=env, capture_output=True,
+                          text=True, timeout=timeout)
+
+
+def test_bench_gpus_n_without_enough_gpus_fails_loudly():
+    import torch
+
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs visible: the launcher would really start two ranks")
+    r = _run_bench({}, "--gpus", "2", "--steps", "1", "--warmup", "1", "--no-cpu-baseline")
+    assert r.returncode != 0
+    assert "GPU(s) visible" in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    # a world that does not match --gpus is refused as well (a stale WORLD_SIZE=1 must not measure one GPU as "2")
+    r = _run_bench({"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}, "--gpus", "2", "--steps", "1", "--warmup", "1")
+    assert r.returncode != 0 and "world that formed" in (r.stderr + r.stdout)
+
+
+@pytest.mark.skipif(__import__("torch").cuda.is_available(), reason="CPU-only check of the launcher's failure path")
+def test_bench_launcher_reports_failed_ranks_on_cpu():
+    r = _run_bench({"BENCH_REHEARSE_GLOO": "1"}, "--gpus", "2", "--steps", "1", "--warmup", "1", "--no-cpu-baseline")
+    assert r.returncode != 0 and "rank exit codes" in r.stderr
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_launches_its_own_ranks_rehearsal():
+    """python bench.py --gpus 2 with no launcher around it: two ranks are started, share GPU 0 (rehearsal switch), gather
+    the peak table over gloo, and rank 0's line says n_gpus = 2.  Small rx: this checks the launch path, not the rate."""
+    import json
+
+    r = _run_bench({"BENCH_REHEARSE_GLOO": "1"}, "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                   "--rx-log2", "20")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["parallelism"] == "template-shard x2" and "REHEARSAL" in j["config"]["workload"]
+    assert j["value"] > 0 and j["steps"] == 2
