@@ -207,7 +207,9 @@ def load():
         return _lib
     _share_rocm_runtime_with_torch()
     try:
-        lib = np.ctypeslib.load_library("libcaf", _HERE)
+        # CAF_LIBRARY=<name>: a development switch for A/B runs of two builds on one box (e.g. libcaf_r02, kept beside
+        # libcaf.so); the product always loads libcaf.so
+        lib = np.ctypeslib.load_library(os.environ.get("CAF_LIBRARY", "libcaf"), _HERE)
     except OSError as e:
         raise OSError(
             "pydsproutines_amd: libcaf.so (the HIP extension) is missing or cannot be loaded from %s "

@@ -33,9 +33,23 @@
 namespace caf {
 
 constexpr int FB = 16384;              // fused block size
-constexpr int F_ROW = 68;              // sub-row pitch (64 used)
-constexpr int F_N1 = 16 * F_ROW + 2;   // pitch between n1 planes (1090)
-constexpr int F_LDS_DATA = 16 * F_N1;  // complex elements
+// LDS image of the transform: PLANAR -- a real and an imaginary plane, each cut into 16 regions (one per n1 = the wave
+// that owns it in passes 2 and 3) of 16 rows of 64 floats.  Every exchange WRITES whole rows with ds_write_addtid_b32
+// (address = M0 + 16-bit immediate + 4 * lane: no address register, one source dword -> 2 cycles of the SIMD's
+// LDS path per instruction, against ~9 for the ds_write_b64 of the complex image this replaces: measured with
+// scripts/ubench/fft_struct_model.hip, -6 % per transform) and READS 16-byte pieces (ds_read_b128, four consecutive
+// values of the digit the next pass transforms).  Conflict-free by construction:
+//   exchange 1 (pass 1 -> 2): row = writer wave, position = writer lane; the reader's 16-lane groups see 16 different
+//                             16-byte slots of a 256-byte row;
+//   exchange 2 (pass 2 -> 3, inside one wave): rows start at fp_row2(n2): readers of one group differ in n2 and d, the
+//                             row starts spread n2 over the four 64-byte quarters of the bank window;
+//   exchange 3 (pass 3 -> 4): readers of one group differ in n1: the region pitch is 32 mod 256 bytes.
+constexpr int FP_P1 = 4384;              // bytes per (plane, n1) region: 4288 used by the skewed rows of exchange 2
+constexpr int FP_IM = 16 * FP_P1;        // byte offset of the imaginary plane
+constexpr int F_LDS_BYTES = 2 * FP_IM;   // 140 288
+constexpr int F_LDS_DATA = F_LDS_BYTES / 8;  // in complex elements (the image is declared as float2)
+__host__ __device__ constexpr int fp_row2(int n2) { return ((n2 >> 1) & 3) * 1088 + ((n2 & 1) + 2 * (n2 >> 3)) * 256; }
+static_assert(fp_row2(15) + 256 <= FP_P1 && FP_P1 % 256 == 32, "planar image geometry");
 
 // Global-memory accessors: uniform base + 32-bit BYTE offset lets the compiler pick the scalar-base (saddr)
 // addressing form instead of building a 64-bit address per access.  The explicit address-space-1 casts keep
@@ -61,6 +75,95 @@ __device__ __forceinline__ float gld1(const float* base, uint32_t byteoff) {
 __device__ __forceinline__ void gst1_wt(float* base, uint32_t byteoff, float v) {
     __hip_atomic_store(reinterpret_cast<CAF_AS1 float*>((CAF_AS1 char*)base + byteoff), v, __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---- planar image access ----
+typedef __attribute__((address_space(3))) char lds_char;
+typedef __attribute__((address_space(3))) v4f_t lds_v4f;
+// eight rows of one plane: lane l of the wave writes v_k to byte m0 + O_k + 4 l.  m0 must be wave-uniform.  (One
+// wait state between the scalar write of M0 and an add-TID LDS instruction; the compiler does not look inside.)
+template <int O0, int O1, int O2, int O3, int O4, int O5, int O6, int O7>
+__device__ __forceinline__ void lds_rows8(uint32_t m0, float v0, float v1, float v2, float v3, float v4, float v5, float v6,
+                                          float v7) {
+    asm volatile(
+        "s_mov_b32 m0, %0\n\ts_nop 0\n\t"
+        "ds_write_addtid_b32 %1 offset:%9\n\tds_write_addtid_b32 %2 offset:%10\n\t"
+        "ds_write_addtid_b32 %3 offset:%11\n\tds_write_addtid_b32 %4 offset:%12\n\t"
+        "ds_write_addtid_b32 %5 offset:%13\n\tds_write_addtid_b32 %6 offset:%14\n\t"
+        "ds_write_addtid_b32 %7 offset:%15\n\tds_write_addtid_b32 %8 offset:%16"
+        :
+        : "s"(m0), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "v"(v5), "v"(v6), "v"(v7), "n"(O0), "n"(O1), "n"(O2), "n"(O3),
+          "n"(O4), "n"(O5), "n"(O6), "n"(O7)
+        : "memory");
+}
+// sixteen complex values -> rows R(k) = B + k * S of both planes (k = register index)
+template <int S>
+__device__ __forceinline__ void lds_rows16c(uint32_t m0, const float2 (&v)[16]) {
+    lds_rows8<0, S, 2 * S, 3 * S, 4 * S, 5 * S, 6 * S, 7 * S>(m0, v[0].x, v[1].x, v[2].x, v[3].x, v[4].x, v[5].x, v[6].x, v[7].x);
+    lds_rows8<0, S, 2 * S, 3 * S, 4 * S, 5 * S, 6 * S, 7 * S>(m0 + 8 * S, v[8].x, v[9].x, v[10].x, v[11].x, v[12].x, v[13].x, v[14].x, v[15].x);
+    lds_rows8<0, S, 2 * S, 3 * S, 4 * S, 5 * S, 6 * S, 7 * S>(m0 + FP_IM, v[0].y, v[1].y, v[2].y, v[3].y, v[4].y, v[5].y, v[6].y, v[7].y);
+    lds_rows8<0, S, 2 * S, 3 * S, 4 * S, 5 * S, 6 * S, 7 * S>(m0 + FP_IM + 8 * S, v[8].y, v[9].y, v[10].y, v[11].y, v[12].y, v[13].y, v[14].y, v[15].y);
+}
+// exchange 2: row n2 starts at fp_row2(n2)
+__device__ __forceinline__ void lds_rows16c_x2(uint32_t m0, const float2 (&v)[16]) {
+    lds_rows8<fp_row2(0), fp_row2(1), fp_row2(2), fp_row2(3), fp_row2(4), fp_row2(5), fp_row2(6), fp_row2(7)>(
+        m0, v[0].x, v[1].x, v[2].x, v[3].x, v[4].x, v[5].x, v[6].x, v[7].x);
+    lds_rows8<fp_row2(8), fp_row2(9), fp_row2(10), fp_row2(11), fp_row2(12), fp_row2(13), fp_row2(14), fp_row2(15)>(
+        m0, v[8].x, v[9].x, v[10].x, v[11].x, v[12].x, v[13].x, v[14].x, v[15].x);
+    lds_rows8<fp_row2(0), fp_row2(1), fp_row2(2), fp_row2(3), fp_row2(4), fp_row2(5), fp_row2(6), fp_row2(7)>(
+        m0 + FP_IM, v[0].y, v[1].y, v[2].y, v[3].y, v[4].y, v[5].y, v[6].y, v[7].y);
+    lds_rows8<fp_row2(8), fp_row2(9), fp_row2(10), fp_row2(11), fp_row2(12), fp_row2(13), fp_row2(14), fp_row2(15)>(
+        m0 + FP_IM, v[8].y, v[9].y, v[10].y, v[11].y, v[12].y, v[13].y, v[14].y, v[15].y);
+}
+// four consecutive values of both planes at byte offset `off` of the image -> four complex numbers
+__device__ __forceinline__ void lds_get4c(const lds_char* img, uint32_t off, float2& c0, float2& c1, float2& c2, float2& c3) {
+    const v4f_t re = *reinterpret_cast<const lds_v4f*>(img + off);
+    const v4f_t im = *reinterpret_cast<const lds_v4f*>(img + off + FP_IM);
+    c0 = make_float2(re.x, im.x);
+    c1 = make_float2(re.y, im.y);
+    c2 = make_float2(re.z, im.z);
+    c3 = make_float2(re.w, im.w);
+}
+// Thread <-> data of the four passes (tid = lane + 64 wave):
+//   pass 1: butterfly m2 = 64 b + 4 c + d with b = (lane & 3) + 4 (wave & 3), c = ((lane >> 2) & 3) + 4 (wave >> 2),
+//           d = lane >> 4 -- the four b of a wave are four whole 128-byte lines of the block spectrum / template row,
+//           and the low lane bits carry the digit pass 2 transforms (its 16-byte reads);
+//   pass 2: wave = n1, lane = (c & 3) + 4 d + 16 (c >> 2);   pass 3: wave = n1, lane = d + 4 n2;
+//   pass 4: n1 = tid & 15, n2 = (tid >> 4) & 15, n3 = (tid >> 8) + 4 i  (lanes <-> consecutive delays, as before).
+__device__ __forceinline__ uint32_t fp_m2(uint32_t tid) {
+    const uint32_t lane = tid & 63, wave = tid >> 6;
+    const uint32_t b = (lane & 3) + 4 * (wave & 3), c = ((lane >> 2) & 3) + 4 * (wave >> 2), d = lane >> 4;
+    return 64 * b + 4 * c + d;
+}
+// ... and the thread whose pass-1 butterfly is m2 (the inverse of fp_m2).  The template-spectrum rows are STORED in this
+// "butterfly order" -- element m of a row at (m & ~1023) + fp_tid_of(m & 1023), k_butterfly_order below -- so that the
+// lanes of a wave, whose butterflies are not consecutive, still read consecutive addresses (an unshifted row: 512
+// contiguous bytes per load; a row shifted by the hypothesis: a few pieces of whole quads).  In natural order the same
+// loads touched 64 separate 8-byte pieces and the launch took 18.4 instead of 15.0 ms.  The block spectrum stays in
+// natural order: it is read once per work item, not once per transform.
+__host__ __device__ __forceinline__ uint32_t fp_tid_of(uint32_t m2) {
+    const uint32_t b = m2 >> 6, c = (m2 >> 2) & 15, d = m2 & 3;
+    return (b & 3) | ((c & 3) << 2) | (d << 4) | ((b >> 2) << 6) | ((c >> 2) << 8);
+}
+// index of element (1024 a + m2 - shift) mod 16384 of a butterfly-ordered row, as hb + 1024 a (mod 16384)
+__device__ __forceinline__ uint32_t fp_hbase(uint32_t m2, int32_t shift) {
+    const uint32_t t = m2 - (uint32_t)shift;
+    return (t & ~1023u) + fp_tid_of(t & 1023u);
+}
+__device__ __forceinline__ uint32_t fp_rd2(uint32_t tid) {  // pass-2 read base: + 256 bh
+    const uint32_t lane = tid & 63, wave = tid >> 6;
+    return wave * FP_P1 + (lane >> 4) * 1024 + (lane & 15) * 16;
+}
+__device__ __forceinline__ uint32_t fp_cd2(uint32_t tid) {  // pass-2 twiddle column 4 c + d
+    const uint32_t lane = tid & 63;
+    return 4 * ((lane & 3) + 4 * (lane >> 4)) + ((lane >> 2) & 3);
+}
+__device__ __forceinline__ uint32_t fp_rd3(uint32_t tid) {  // pass-3 read base: + 64 ch
+    const uint32_t lane = tid & 63, wave = tid >> 6, n2 = lane >> 2;
+    return wave * FP_P1 + ((n2 >> 1) & 3) * 1088 + ((n2 & 1) + 2 * (n2 >> 3)) * 256 + (lane & 3) * 16;
+}
+__device__ __forceinline__ uint32_t fp_rd4(uint32_t tid) {  // pass-4 read base: + 1024 i
+    return (tid & 15) * FP_P1 + (tid >> 8) * 256 + ((tid >> 4) & 15) * 16;
 }
 
 // a pointer whose value is wave-uniform, moved (back) into scalar registers
@@ -124,9 +227,15 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
                                            int32_t table_mode, int32_t nfreq, int32_t nhyp, int blk, int h0, int h1,
                                            int32_t tiles_per_blk, float* __restrict__ vt,
                                            int32_t* __restrict__ imax = nullptr, const F1Direct* f1 = nullptr) {
-    constexpr int BPT = 1024 / FT;
-    static_assert(MODE < 2 || BPT == 1, "the running-maximum and direct-row modes are written for one butterfly per thread");
+    static_assert(FT == 1024, "one radix-16 butterfly per thread and pass: 1024 threads (wave w owns plane n1 = w)");
+    constexpr int BPT = 1;
     const int tid = threadIdx.x;
+    const lds_char* img = (const lds_char*)s_d;
+    // wave-uniform LDS byte addresses for the row writes (M0): this wave's row of exchange 1, its region for 2 and 3
+    const uint32_t img0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)img);
+    const uint32_t wave_u = __builtin_amdgcn_readfirstlane((uint32_t)tid >> 6);
+    const uint32_t m0_x1 = img0 + wave_u * 256u, m0_w = img0 + wave_u * (uint32_t)FP_P1;
+    const uint32_t m2 = fp_m2((uint32_t)tid);
     float bv[16];     // MODE 2: running maxima of this thread's 16 delays ...
     uint32_t bi[4];   // ... and the item-local hypothesis (8 bits each) that produced them
     if (MODE == 2) {
@@ -158,21 +267,22 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
     float2 w[BPT];
     const float2* xp = xb + (int64_t)blk * FB;  // uniform base; per-thread offsets stay 32-bit (saddr loads)
 #pragma unroll
-    for (int j = 0; j < BPT; ++j) w[j] = ld2(tw1, (uint32_t)(1024 + tid + j * FT));
+    for (int j = 0; j < BPT; ++j) w[j] = ld2(tw1, 1024u + m2);
     float* vt_blk = vt + (int64_t)blk * tiles_per_blk * nhyp * 64;
     const __amdgpu_buffer_rsrc_t rvt = buf_of(uniform_ptr(vt_blk), (uint32_t)tiles_per_blk * (uint32_t)nhyp * 256u);
 
     // row of the template-spectrum table used by hypothesis h (uniform) and its circular shift
     const float2* hrow_cur;
-    int sh_cur;
+    uint32_t hb_cur;  // this thread's element of the (butterfly-ordered, shifted) row: hb_cur + 1024 a (mod FB)
     auto row_of = [&](int h) {
         if (table_mode) {
             hrow_cur = hc + (int64_t)h * FB;
-            sh_cur = 0;
+            hb_cur = (uint32_t)tid;
         } else {
             const int t = h / nfreq;
-            sh_cur = *((const CAF_AS1 int32_t*)shifts + (h - t * nfreq));
+            const int32_t sh = *((const CAF_AS1 int32_t*)shifts + (h - t * nfreq));
             hrow_cur = hc + (int64_t)t * FB;
+            hb_cur = fp_hbase(m2, sh);
         }
     };
     // pr[j][a] = X[1024 a + m2] * Hc_h[1024 a + m2]: the input of pass 1, produced one hypothesis ahead
@@ -182,14 +292,14 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
 #pragma unroll
     for (int j = 0; j < BPT; ++j)
 #pragma unroll
-        for (int a = 0; a < 16; ++a) xr[j][a] = ld2(xp, (uint32_t)(1024 * a + j * FT + tid));
+        for (int a = 0; a < 16; ++a) xr[j][a] = ld2(xp, 1024u * a + m2);
     row_of(h0);
 #pragma unroll
     for (int j = 0; j < BPT; ++j)
 #pragma unroll
         for (int a = 0; a < 16; ++a)
             pr[j][a] = cmul(xr[j][a],
-                            ld2(hrow_cur, (uint32_t)((1024 * a + tid + j * FT - sh_cur) & (FB - 1))));
+                            ld2(hrow_cur, (1024u * a + hb_cur) & (FB - 1)));
 
     for (int h = h0; h < h1; ++h) {
         const bool more = h + 1 < h1;
@@ -232,37 +342,21 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
             }
         }
         __syncthreads();  // previous hypothesis' pass-4 reads are done (and the LDS tables are in place)
-#pragma unroll
-        for (int j = 0; j < BPT; ++j) {
-            const int m2 = tid + j * FT;
-            const int off = (m2 >> 6) * F_ROW + (m2 & 63);
-#pragma unroll
-            for (int n1 = 0; n1 < 16; ++n1) s_d[n1 * F_N1 + off] = v1[j][n1];
-        }
+        lds_rows16c<FP_P1>(m0_x1, v1[0]);  // value n1 -> region n1, row = this wave, position = lane
         __syncthreads();
         row_of(more ? h + 1 : h);  // unconditional refill (the last one is redundant): no select keeps pr alive
         // ---- pass 2: DFT16 over b, in place (n1 = idx >> 6, col = idx & 63) ----
         // all of a thread's butterflies are read first, so the LDS reads of butterfly j+1 fly under the
         // arithmetic of butterfly j (they touch disjoint addresses)
         {
-            float2 v[BPT][16];
+            float2 v[16];
+            const uint32_t rd2 = fp_rd2((uint32_t)(tid + lz)), cd = fp_cd2((uint32_t)(tid + lz));
 #pragma unroll
-            for (int j = 0; j < BPT; ++j) {
-                const int idx = tid + j * FT;
-                const int base = (idx >> 6) * F_N1 + (idx & 63);
+            for (int bh = 0; bh < 4; ++bh) lds_get4c(img, rd2 + 256u * bh, v[4 * bh], v[4 * bh + 1], v[4 * bh + 2], v[4 * bh + 3]);
+            idft16(v);
 #pragma unroll
-                for (int b = 0; b < 16; ++b) v[j][b] = s_d[base + b * F_ROW];
-            }
-#pragma unroll
-            for (int j = 0; j < BPT; ++j) {
-                const int idx = tid + j * FT;
-                const int base = (idx >> 6) * F_N1 + (idx & 63);
-                idft16(v[j]);
-#pragma unroll
-                for (int n2 = 1; n2 < 16; ++n2) v[j][n2] = cmul(v[j][n2], s_tw2[n2 * 64 + (idx & 63) + lz]);
-#pragma unroll
-                for (int n2 = 0; n2 < 16; ++n2) s_d[base + n2 * F_ROW] = v[j][n2];
-            }
+            for (int n2 = 1; n2 < 16; ++n2) v[n2] = cmul(v[n2], s_tw2[n2 * 64 + cd]);
+            lds_rows16c_x2(m0_w, v);  // value n2 -> row n2 of this wave's region, position = lane
         }
         // No workgroup barrier here: plane n1 = idx >> 6 is written in pass 2 and read in pass 3 by the SAME
         // wave (wave w owns planes w, w + FT/64, ...), and a wave's LDS operations complete in order.
@@ -275,28 +369,18 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
             for (int j = 0; j < BPT; ++j)
 #pragma unroll
                 for (int a = 0; a < 16; ++a)
-                    hn[j][a] = ld2(hrow_cur, (uint32_t)(((1024 * a + tid + j * FT - sh_cur) & (FB - 1)) + lz));
+                    hn[j][a] = ld2(hrow_cur, ((1024u * a + hb_cur) & (FB - 1)) + lz);
         }
         // ---- pass 3: DFT16 over c, in place (n1 = idx >> 6, n2 = (idx >> 2) & 15, d = idx & 3) ----
         {
-            float2 v[BPT][16];
+            float2 v[16];
+            const uint32_t rd3 = fp_rd3((uint32_t)(tid + lz));
 #pragma unroll
-            for (int j = 0; j < BPT; ++j) {
-                const int idx = tid + j * FT;
-                const int base = (idx >> 6) * F_N1 + ((idx >> 2) & 15) * F_ROW + (idx & 3);
+            for (int ch = 0; ch < 4; ++ch) lds_get4c(img, rd3 + 64u * ch, v[4 * ch], v[4 * ch + 1], v[4 * ch + 2], v[4 * ch + 3]);
+            idft16(v);
 #pragma unroll
-                for (int c = 0; c < 16; ++c) v[j][c] = s_d[base + 4 * c];
-            }
-#pragma unroll
-            for (int j = 0; j < BPT; ++j) {
-                const int idx = tid + j * FT;
-                const int base = (idx >> 6) * F_N1 + ((idx >> 2) & 15) * F_ROW + (idx & 3);
-                idft16(v[j]);
-#pragma unroll
-                for (int n3 = 1; n3 < 16; ++n3) v[j][n3] = cmul(v[j][n3], s_tw3[n3 * 4 + (idx & 3) + lz]);
-#pragma unroll
-                for (int n3 = 0; n3 < 16; ++n3) s_d[base + 4 * n3] = v[j][n3];
-            }
+            for (int n3 = 1; n3 < 16; ++n3) v[n3] = cmul(v[n3], s_tw3[n3 * 4 + (tid & 3) + lz]);
+            lds_rows16c<256>(m0_w, v);  // value n3 -> row n3 of this wave's region, position = lane = d + 4 n2
         }
         if (MODE >= 2) {
             // (the 20 registers of the running maxima leave no room for the row during pass 3: it is fetched here,
@@ -305,7 +389,7 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
             for (int j = 0; j < BPT; ++j)
 #pragma unroll
                 for (int a = 0; a < 16; ++a)
-                    hn[j][a] = ld2(hrow_cur, (uint32_t)(((1024 * a + tid + j * FT - sh_cur) & (FB - 1)) + lz));
+                    hn[j][a] = ld2(hrow_cur, ((1024u * a + hb_cur) & (FB - 1)) + lz);
         }
         __syncthreads();
         // ---- pass 4: DFT4 over d ; |y|^2 -> vt tiles (lanes <-> consecutive delays) ----
@@ -313,19 +397,16 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
         for (int j = 0; j < BPT; ++j) {
             const int idx = tid + j * FT;
             const int n1 = idx & 15, n2 = (idx >> 4) & 15, q = idx >> 8;
-            const int base = n1 * F_N1 + n2 * F_ROW;
+            const uint32_t rd4 = fp_rd4((uint32_t)idx);
             // next hypothesis' template-spectrum row for butterfly j: the loads fly while this butterfly's
             // pass-4 work runs
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int n3 = q + 4 * i;
-                int lzi = 0;
+                uint32_t lzi = 0;
                 asm volatile("" : "+v"(lzi));
-                const float4 lo = *reinterpret_cast<const float4*>(&s_d[base + 4 * n3 + lzi]);
-                const float4 hi = *reinterpret_cast<const float4*>(&s_d[base + 4 * n3 + 2 + lzi]);
-                float2 a0 = make_float2(lo.x, lo.y), a1 = make_float2(lo.z, lo.w);
-                float2 a2 = make_float2(hi.x, hi.y), a3 = make_float2(hi.z, hi.w);
+                float2 a0, a1, a2, a3;
+                lds_get4c(img, rd4 + 1024u * i + lzi, a0, a1, a2, a3);  // n3 = q + 4 i: the four d of (n1, n2, n3)
                 idft4(a0, a1, a2, a3);
                 // n = n1 + 16 n2 + 256 n3 + 4096 n4  ->  tile = n >> 6 = (n2 >> 2) + 4 n3 + 64 n4, lane = n & 63.
                 // Uniform (scalar) part of the address + one 32-bit per-thread offset, so that no per-store
@@ -408,7 +489,12 @@ __device__ __forceinline__ void fused_item2(float2* __restrict__ s_d, const floa
                                             int32_t tiles_per_blk, float* __restrict__ vt) {
     constexpr int FB2 = 2 * FB;
     const int tid = threadIdx.x;
-    const float2 w = ld2(tw1, (uint32_t)(1024 + tid));  // pass-1 twiddle base e^{+j 2 pi m2 / 16384}
+    const lds_char* img = (const lds_char*)s_d;
+    const uint32_t img0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)img);
+    const uint32_t wave_u = __builtin_amdgcn_readfirstlane((uint32_t)tid >> 6);
+    const uint32_t m0_x1 = img0 + wave_u * 256u, m0_w = img0 + wave_u * (uint32_t)FP_P1;
+    const uint32_t m2 = fp_m2((uint32_t)tid);            // this thread's pass-1 butterfly (see fp_m2)
+    const float2 w = ld2(tw1, 1024u + m2);  // pass-1 twiddle base e^{+j 2 pi m2 / 16384}
     const float2* xp = xb + (int64_t)blk * FB2;
     float* vt_blk = vt + (int64_t)blk * tiles_per_blk * nhyp * 64;
     const __amdgpu_buffer_rsrc_t rvt = buf_of(uniform_ptr(vt_blk), (uint32_t)tiles_per_blk * (uint32_t)nhyp * 256u);
@@ -421,23 +507,24 @@ __device__ __forceinline__ void fused_item2(float2* __restrict__ s_d, const floa
         wb = make_float2((float)cs, (float)sn);
     }
     const float2* hrow_cur;
-    int sh_cur;  // shift in parity-major elements (= half the 32768-point shift)
+    uint32_t hb_cur;  // as in fused_item, with the shift in parity-major elements (= half the 32768-point shift)
     auto row_of = [&](int h) {
         if (table_mode) {
             hrow_cur = hc + (int64_t)h * FB2;
-            sh_cur = 0;
+            hb_cur = (uint32_t)tid;
         } else {
             const int t = h / nfreq;
-            sh_cur = *((const CAF_AS1 int32_t*)shifts + (h - t * nfreq)) >> 1;
+            const int32_t sh = *((const CAF_AS1 int32_t*)shifts + (h - t * nfreq)) >> 1;
             hrow_cur = hc + (int64_t)t * FB2;
+            hb_cur = fp_hbase(m2, sh);
         }
     };
     float2 xn[16], hn[16];  // inputs of the NEXT half-transform
     row_of(h0);
 #pragma unroll
     for (int a = 0; a < 16; ++a) {
-        xn[a] = ld2(xp, (uint32_t)(1024 * a + tid));
-        hn[a] = ld2(hrow_cur, (uint32_t)((1024 * a + tid - sh_cur) & (FB - 1)));
+        xn[a] = ld2(xp, 1024u * a + m2);
+        hn[a] = ld2(hrow_cur, (1024u * a + hb_cur) & (FB - 1));
     }
     float2 e[16];  // E's outputs (register 4 i + n4 <-> n3 = q + 4 i, n4)
 
@@ -464,30 +551,27 @@ __device__ __forceinline__ void fused_item2(float2* __restrict__ s_d, const floa
                     v1[n1] = cmul(v1[n1], p);
                 }
                 __syncthreads();  // the previous half-transform's pass-4 reads are done
-                const int off = (tid >> 6) * F_ROW + (tid & 63);
-#pragma unroll
-                for (int n1 = 0; n1 < 16; ++n1) s_d[n1 * F_N1 + off] = v1[n1];
+                lds_rows16c<FP_P1>(m0_x1, v1);
             }
             __syncthreads();
             // ---- pass 2 ----
             {
                 float2 v[16];
-                const int base = (tid >> 6) * F_N1 + (tid & 63);
+                const uint32_t rd2 = fp_rd2((uint32_t)(tid + lz)), cd = fp_cd2((uint32_t)(tid + lz));
 #pragma unroll
-                for (int b = 0; b < 16; ++b) v[b] = s_d[base + b * F_ROW];
+                for (int bh = 0; bh < 4; ++bh) lds_get4c(img, rd2 + 256u * bh, v[4 * bh], v[4 * bh + 1], v[4 * bh + 2], v[4 * bh + 3]);
                 idft16(v);
 #pragma unroll
-                for (int n2 = 1; n2 < 16; ++n2) v[n2] = cmul(v[n2], s_tw2[n2 * 64 + (tid & 63) + lz]);
-#pragma unroll
-                for (int n2 = 0; n2 < 16; ++n2) s_d[base + n2 * F_ROW] = v[n2];
+                for (int n2 = 1; n2 < 16; ++n2) v[n2] = cmul(v[n2], s_tw2[n2 * 64 + cd]);
+                lds_rows16c_x2(m0_w, v);
             }
             __builtin_amdgcn_wave_barrier();
             if (c == 0) {
                 // inputs of the O half of this hypothesis: issued here, covered by pass 3 and pass 4
 #pragma unroll
                 for (int a = 0; a < 16; ++a) {
-                    xn[a] = ld2(xp, (uint32_t)(FB + 1024 * a + tid + lz));
-                    hn[a] = ld2(hrow_cur, (uint32_t)(FB + ((1024 * a + tid - sh_cur) & (FB - 1)) + lz));
+                    xn[a] = ld2(xp, FB + 1024u * a + m2 + lz);
+                    hn[a] = ld2(hrow_cur, FB + ((1024u * a + hb_cur) & (FB - 1)) + lz);
                 }
             } else {
                 row_of(h + 1 < h1 ? h + 1 : h);  // (the loads of the next E half follow inside pass 4)
@@ -495,28 +579,24 @@ __device__ __forceinline__ void fused_item2(float2* __restrict__ s_d, const floa
             // ---- pass 3 ----
             {
                 float2 v[16];
-                const int base = (tid >> 6) * F_N1 + ((tid >> 2) & 15) * F_ROW + (tid & 3);
+                const uint32_t rd3 = fp_rd3((uint32_t)(tid + lz));
 #pragma unroll
-                for (int cc = 0; cc < 16; ++cc) v[cc] = s_d[base + 4 * cc];
+                for (int ch = 0; ch < 4; ++ch) lds_get4c(img, rd3 + 64u * ch, v[4 * ch], v[4 * ch + 1], v[4 * ch + 2], v[4 * ch + 3]);
                 idft16(v);
 #pragma unroll
                 for (int n3 = 1; n3 < 16; ++n3) v[n3] = cmul(v[n3], s_tw3[n3 * 4 + (tid & 3) + lz]);
-#pragma unroll
-                for (int n3 = 0; n3 < 16; ++n3) s_d[base + 4 * n3] = v[n3];
+                lds_rows16c<256>(m0_w, v);
             }
             __syncthreads();
             // ---- pass 4: DFT4 over d; the E half keeps its outputs, the O half combines and stores ----
-            const int base = n1o * F_N1 + n2o * F_ROW;
+            const uint32_t rd4 = fp_rd4((uint32_t)tid);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int n3 = qo + 4 * i;
-                int lzi = 0;
+                uint32_t lzi = 0;
                 asm volatile("" : "+v"(lzi));
-                const float4 lo = *reinterpret_cast<const float4*>(&s_d[base + 4 * n3 + lzi]);
-                const float4 hi = *reinterpret_cast<const float4*>(&s_d[base + 4 * n3 + 2 + lzi]);
-                float2 a0 = make_float2(lo.x, lo.y), a1 = make_float2(lo.z, lo.w);
-                float2 a2 = make_float2(hi.x, hi.y), a3 = make_float2(hi.z, hi.w);
+                float2 a0, a1, a2, a3;
+                lds_get4c(img, rd4 + 1024u * i + lzi, a0, a1, a2, a3);
                 idft4(a0, a1, a2, a3);
                 const float2 y[4] = {a0, a1, a2, a3};
                 if (c == 0) {
@@ -543,14 +623,23 @@ __device__ __forceinline__ void fused_item2(float2* __restrict__ s_d, const floa
                     // four positions of the next E half's inputs, into the registers the combination just freed
 #pragma unroll
                     for (int a = 4 * i; a < 4 * i + 4; ++a) {
-                        xn[a] = ld2(xp, (uint32_t)(1024 * a + tid + lzi));
-                        hn[a] = ld2(hrow_cur, (uint32_t)(((1024 * a + tid - sh_cur) & (FB - 1)) + lzi));
+                        xn[a] = ld2(xp, 1024u * a + m2 + lzi);
+                        hn[a] = ld2(hrow_cur, ((1024u * a + hb_cur) & (FB - 1)) + lzi);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
+}
+
+// natural order -> butterfly order, chunk by chunk of 1024 elements (see fp_tid_of)
+__global__ __launch_bounds__(256) void k_butterfly_order(const float2* __restrict__ in, float2* __restrict__ out, int64_t nchunks) {
+    for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x)
+        for (int j = threadIdx.x; j < 1024; j += 256) out[c * 1024 + j] = in[c * 1024 + fp_m2((uint32_t)j)];
+}
+void launch_butterfly_order(const float2* in, float2* out, int64_t nchunks, hipStream_t st) {
+    hipLaunchKernelGGL(k_butterfly_order, dim3((unsigned)std::min<int64_t>(nchunks, 65535)), dim3(256), 0, st, in, out, nchunks);
 }
 
 // rows of B = 2 * half complex samples -> parity-major: out[r][c][m'] = in[r][2 m' + c]
@@ -1480,17 +1569,8 @@ void launch_fused_caf(const float2* xb, const float2* hc, const int32_t* shifts,
                       int32_t nblk, int32_t tiles_per_blk, float* vt, hipStream_t st) {
     const int ngroups = (nhyp + hyp_per_wg - 1) / hyp_per_wg;
     const dim3 grid((unsigned)(ngroups * 8 * ((nblk + 7) / 8)));  // 1-D, XCD-aware mapping inside the kernel
-    // CAF_FUSED_THREADS=512 selects the 2-waves/SIMD variant (A/B switch; 1024 measured faster)
-    static const int threads = [] {
-        const char* e = getenv("CAF_FUSED_THREADS");
-        return (e && atoi(e) == 512) ? 512 : 1024;
-    }();
-    if (threads == 512)
-        hipLaunchKernelGGL(k_fused_caf<512>, grid, dim3(512), 0, st, xb, hc, shifts, tw1, tw23, table_mode, nfreq,
-                           nhyp, hyp_per_wg, nblk, tiles_per_blk, vt);
-    else
-        hipLaunchKernelGGL(k_fused_caf<1024>, grid, dim3(1024), 0, st, xb, hc, shifts, tw1, tw23, table_mode, nfreq,
-                           nhyp, hyp_per_wg, nblk, tiles_per_blk, vt);
+    hipLaunchKernelGGL(k_fused_caf<1024>, grid, dim3(1024), 0, st, xb, hc, shifts, tw1, tw23, table_mode, nfreq, nhyp,
+                       hyp_per_wg, nblk, tiles_per_blk, vt);
 }
 
 void launch_transpose_norm_argmax(const float* vt, int32_t ntmpl, int32_t nfreq, const float* tscale,

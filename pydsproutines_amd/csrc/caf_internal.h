@@ -215,6 +215,8 @@ struct PersistParams {
     int32_t* imax;
     int32_t* dbg;  // optional host-mapped progress marks (CAF_PERSIST_DEBUG), 4 ints per workgroup
 };
+// natural order -> the order in which the fused engines read their template-spectrum rows (caf_fused.hip, fp_tid_of)
+void launch_butterfly_order(const float2* in, float2* out, int64_t nchunks, hipStream_t st);
 // copies *h to d_params, clears the queue block and launches n_wgs resident workgroups
 void launch_caf_persistent(const PersistParams* h, PersistParams* d_params, int32_t n_wgs, hipStream_t st);
 

@@ -664,6 +664,17 @@ static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
                 (void)pool_free(tmp);
             }
         }
+        if (rc == CAF_OK && p->fused) {
+            // the in-LDS engines read their rows in butterfly order (caf_fused.hip, fp_tid_of): permuted once, here
+            float2* tmpb = nullptr;
+            rc = pool_alloc((void**)&tmpb, nspec * (int64_t)B * 8);
+            if (rc == CAF_OK) {
+                launch_butterfly_order(p->d_hc, tmpb, nspec * (int64_t)B / 1024, nullptr);
+                if (hipMemcpyAsync(p->d_hc, tmpb, (size_t)nspec * B * 8, hipMemcpyDeviceToDevice, nullptr) != hipSuccess) rc = CAF_ERR_HIP;
+                (void)hipStreamSynchronize(nullptr);
+                (void)pool_free(tmpb);
+            }
+        }
         hipError_t e = hipStreamSynchronize(nullptr);
         fft_plan_release(&tmp);
         free_tmp();
