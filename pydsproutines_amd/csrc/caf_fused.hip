@@ -124,6 +124,15 @@ __device__ __forceinline__ void lds_get4c(const lds_char* img, uint32_t off, flo
     c2 = make_float2(re.z, im.z);
     c3 = make_float2(re.w, im.w);
 }
+// twiddle-table read (LDS), volatile so that it stays one ds_read_b64: the compiler otherwise pairs these reads into
+// ds_read2_b64 / ds_read2st64_b64, which cost 8 LDS cycles per pair against 2 + 2 (MI355X_MICROARCH.md, LDS table);
+// A/B on one box: -1.2 % per transform
+__device__ __forceinline__ float2 tw_ld(const float2* t, uint32_t idx) {
+    const uint64_t u = *(const volatile __attribute__((address_space(3))) uint64_t*)(&t[idx]);
+    float2 r;
+    __builtin_memcpy(&r, &u, 8);
+    return r;
+}
 // Thread <-> data of the four passes (tid = lane + 64 wave):
 //   pass 1: butterfly m2 = 64 b + 4 c + d with b = (lane & 3) + 4 (wave & 3), c = ((lane >> 2) & 3) + 4 (wave >> 2),
 //           d = lane >> 4 -- the four b of a wave are four whole 128-byte lines of the block spectrum / template row,
@@ -217,7 +226,8 @@ struct F1Direct {
     int64_t num_shifts;
     int32_t step, blk_abs;
 };
-template <int FT, int MODE = 0>
+// NV4: output quarters n4 < NV4 of the last (radix-4) pass are computed -- the others hold no valid delay (tiles >= 64 NV4)
+template <int FT, int MODE = 0, int NV4 = 4>
 __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float2* __restrict__ s_tw2,
                                            const float2* __restrict__ s_tw3,
                                            const float2* __restrict__ xb,       // [blocks][FB] spectra
@@ -236,6 +246,10 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
     const uint32_t wave_u = __builtin_amdgcn_readfirstlane((uint32_t)tid >> 6);
     const uint32_t m0_x1 = img0 + wave_u * 256u, m0_w = img0 + wave_u * (uint32_t)FP_P1;
     const uint32_t m2 = fp_m2((uint32_t)tid);
+    // outputs n = n' + 4096 n4 lie in tiles 64 n4 ...: quarters of the last (radix-4) pass that hold no valid delay at
+    // all are not computed (N = 4096 with the step rounded to 12288: n4 = 3; N = 8192: n4 = 2 and 3; -3.3 % per transform
+    // at NV4 = 3)
+    constexpr int nv4 = NV4;  // (compile-time: as a run-time scalar the 16 branches per transform ate the 3 % it saves)
     float bv[16];     // MODE 2: running maxima of this thread's 16 delays ...
     uint32_t bi[4];   // ... and the item-local hypothesis (8 bits each) that produced them
     if (MODE == 2) {
@@ -355,7 +369,7 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
             for (int bh = 0; bh < 4; ++bh) lds_get4c(img, rd2 + 256u * bh, v[4 * bh], v[4 * bh + 1], v[4 * bh + 2], v[4 * bh + 3]);
             idft16(v);
 #pragma unroll
-            for (int n2 = 1; n2 < 16; ++n2) v[n2] = cmul(v[n2], s_tw2[n2 * 64 + cd]);
+            for (int n2 = 1; n2 < 16; ++n2) v[n2] = cmul(v[n2], tw_ld(s_tw2, n2 * 64 + cd));
             lds_rows16c_x2(m0_w, v);  // value n2 -> row n2 of this wave's region, position = lane
         }
         // No workgroup barrier here: plane n1 = idx >> 6 is written in pass 2 and read in pass 3 by the SAME
@@ -379,7 +393,7 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
             for (int ch = 0; ch < 4; ++ch) lds_get4c(img, rd3 + 64u * ch, v[4 * ch], v[4 * ch + 1], v[4 * ch + 2], v[4 * ch + 3]);
             idft16(v);
 #pragma unroll
-            for (int n3 = 1; n3 < 16; ++n3) v[n3] = cmul(v[n3], s_tw3[n3 * 4 + (tid & 3) + lz]);
+            for (int n3 = 1; n3 < 16; ++n3) v[n3] = cmul(v[n3], tw_ld(s_tw3, n3 * 4 + (tid & 3) + lz));
             lds_rows16c<256>(m0_w, v);  // value n3 -> row n3 of this wave's region, position = lane = d + 4 n2
         }
         if (MODE >= 2) {
@@ -407,18 +421,20 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
                 asm volatile("" : "+v"(lzi));
                 float2 a0, a1, a2, a3;
                 lds_get4c(img, rd4 + 1024u * i + lzi, a0, a1, a2, a3);  // n3 = q + 4 i: the four d of (n1, n2, n3)
-                idft4(a0, a1, a2, a3);
+                // inverse DFT4 over d, one output quarter n4 at a time (idft4 spelled out: unused quarters are skipped)
+                const float2 s02 = cadd(a0, a2), d02 = csub(a0, a2), s13 = cadd(a1, a3), d13 = mulj(csub(a1, a3));
                 // n = n1 + 16 n2 + 256 n3 + 4096 n4  ->  tile = n >> 6 = (n2 >> 2) + 4 n3 + 64 n4, lane = n & 63.
                 // Uniform (scalar) part of the address + one 32-bit per-thread offset, so that no per-store
                 // 64-bit address is kept alive across the hypothesis loop.
-                const float2 y[4] = {a0, a1, a2, a3};
 #pragma unroll
                 for (int n4 = 0; n4 < 4; ++n4) {
+                    if (n4 >= nv4) continue;  // (scalar branch)
+                    const float2 yq = n4 == 0 ? cadd(s02, s13) : n4 == 1 ? cadd(d02, d13) : n4 == 2 ? csub(s02, s13) : csub(d02, d13);
                     const int tile_u = 16 * i + 64 * n4;                      // uniform part of the tile index
                     const int tile_t = (n2 >> 2) + 4 * q;                     // per-thread part
                     const uint32_t soff = (uint32_t)tile_u * (uint32_t)nhyp * 256u + hoff;  // uniform (scalar) offset
                     const uint32_t voff = ((uint32_t)tile_t * (uint32_t)nhyp * 64u + (uint32_t)(n1 + 16 * (n2 & 3))) << 2;
-                    const float val = y[n4].x * y[n4].x + y[n4].y * y[n4].y;
+                    const float val = yq.x * yq.x + yq.y * yq.y;
                     if (MODE == 2) {
                         // hypotheses come in increasing order: the first maximum stays (NaN never enters)
                         constexpr int o = 0;  // (placeholder, see below)
@@ -562,7 +578,7 @@ __device__ __forceinline__ void fused_item2(float2* __restrict__ s_d, const floa
                 for (int bh = 0; bh < 4; ++bh) lds_get4c(img, rd2 + 256u * bh, v[4 * bh], v[4 * bh + 1], v[4 * bh + 2], v[4 * bh + 3]);
                 idft16(v);
 #pragma unroll
-                for (int n2 = 1; n2 < 16; ++n2) v[n2] = cmul(v[n2], s_tw2[n2 * 64 + cd]);
+                for (int n2 = 1; n2 < 16; ++n2) v[n2] = cmul(v[n2], tw_ld(s_tw2, n2 * 64 + cd));
                 lds_rows16c_x2(m0_w, v);
             }
             __builtin_amdgcn_wave_barrier();
@@ -584,7 +600,7 @@ __device__ __forceinline__ void fused_item2(float2* __restrict__ s_d, const floa
                 for (int ch = 0; ch < 4; ++ch) lds_get4c(img, rd3 + 64u * ch, v[4 * ch], v[4 * ch + 1], v[4 * ch + 2], v[4 * ch + 3]);
                 idft16(v);
 #pragma unroll
-                for (int n3 = 1; n3 < 16; ++n3) v[n3] = cmul(v[n3], s_tw3[n3 * 4 + (tid & 3) + lz]);
+                for (int n3 = 1; n3 < 16; ++n3) v[n3] = cmul(v[n3], tw_ld(s_tw3, n3 * 4 + (tid & 3) + lz));
                 lds_rows16c<256>(m0_w, v);
             }
             __syncthreads();
@@ -685,7 +701,10 @@ __global__ __launch_bounds__(FT) void k_fused_caf(const float2* __restrict__ xb,
 
     for (int i = tid; i < 1024; i += FT) s_tw2[i] = tw23[i];
     if (tid < 64) s_tw3[tid] = tw23[1024 + tid];
-    fused_item<FT>(s_d, s_tw2, s_tw3, xb, hc, shifts, tw1, table_mode, nfreq, nhyp, blk, h0, h1, tiles_per_blk, vt);
+    if (tiles_per_blk <= 192)  // (see fused_item: quarters of the last pass without a valid delay are skipped)
+        fused_item<FT, 0, 3>(s_d, s_tw2, s_tw3, xb, hc, shifts, tw1, table_mode, nfreq, nhyp, blk, h0, h1, tiles_per_blk, vt);
+    else
+        fused_item<FT, 0, 4>(s_d, s_tw2, s_tw3, xb, hc, shifts, tw1, table_mode, nfreq, nhyp, blk, h0, h1, tiles_per_blk, vt);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -1356,7 +1375,7 @@ __device__ __forceinline__ void pq_mark(const PersistParams* pp, int slot, int v
 // spilled values every hypothesis).  Called ~21 times per workgroup: the call and the callee-saved register
 // traffic are negligible.  Arguments arrive in VGPRs; v_readfirstlane makes them scalar again.
 typedef __attribute__((address_space(3))) float2 lds_float2;
-template <int KIND>  // 0: |y|^2 tiles, 1: running maxima (no surface), 2: finished rows (no frequency scan)
+template <int KIND, int NV4>  // 0: |y|^2 tiles, 1: running maxima (no surface), 2: finished rows (no frequency scan)
 __device__ __attribute__((noinline)) void persistent_fft_item(lds_float2* s_d, const lds_float2* s_tw2,
                                                               const lds_float2* s_tw3, const PersistParams* pp_in,
                                                               int item_in) {
@@ -1382,16 +1401,16 @@ __device__ __attribute__((noinline)) void persistent_fft_item(lds_float2* s_d, c
         f1.num_shifts = P->num_shifts;
         f1.step = P->step;
         f1.blk_abs = P->blk0 + blk;
-        fused_item<1024, 3>((float2*)s_d, (const float2*)s_tw2, (const float2*)s_tw3, P->xb, P->hc, P->shifts, P->tw1,
+        fused_item<1024, 3, NV4>((float2*)s_d, (const float2*)s_tw2, (const float2*)s_tw3, P->xb, P->hc, P->shifts, P->tw1,
                             P->table_mode, P->nfreq, nhyp, blk, h0, h1, P->tiles_per_blk, nullptr, nullptr, &f1);
     } else if (KIND == 1) {
         // no surface wanted: one (maximum, hypothesis) pair per delay and item instead of the |y|^2 tiles
         const int64_t o = ((int64_t)blk * ngroups + grp) * P->tiles_per_blk * 64;
-        fused_item<1024, 2>((float2*)s_d, (const float2*)s_tw2, (const float2*)s_tw3, P->xb, P->hc, P->shifts, P->tw1,
+        fused_item<1024, 2, NV4>((float2*)s_d, (const float2*)s_tw2, (const float2*)s_tw3, P->xb, P->hc, P->shifts, P->tw1,
                             P->table_mode, P->nfreq, nhyp, blk, h0, h1, P->tiles_per_blk, P->vmax + o, P->imax + o);
     } else {
         // the |y|^2 tiles are stored write-through (sc1): device-visible once the store has completed
-        fused_item<1024, 1>((float2*)s_d, (const float2*)s_tw2, (const float2*)s_tw3, P->xb, P->hc, P->shifts, P->tw1,
+        fused_item<1024, 1, NV4>((float2*)s_d, (const float2*)s_tw2, (const float2*)s_tw3, P->xb, P->hc, P->shifts, P->tw1,
                             P->table_mode, P->nfreq, nhyp, blk, h0, h1, P->tiles_per_blk, P->vt);
     }
     // publish: every wave waits for its own stores (workgroup-scope release = s_waitcnt vmcnt(0); an
@@ -1522,12 +1541,21 @@ __global__ __launch_bounds__(1024) void k_caf_persistent(const PersistParams* __
         if (kind == 1) {
             if (__builtin_amdgcn_readfirstlane(params_of(pp)->block_log2) == 15)
                 persistent_fft_item2((lds_float2*)s_d, (const lds_float2*)s_tw2, (const lds_float2*)s_tw3, pp, item);
-            else if (__builtin_amdgcn_readfirstlane(params_of(pp)->f1_direct))
-                persistent_fft_item<2>((lds_float2*)s_d, (const lds_float2*)s_tw2, (const lds_float2*)s_tw3, pp, item);
-            else if (__builtin_amdgcn_readfirstlane(params_of(pp)->nosurf))
-                persistent_fft_item<1>((lds_float2*)s_d, (const lds_float2*)s_tw2, (const lds_float2*)s_tw3, pp, item);
-            else
-                persistent_fft_item<0>((lds_float2*)s_d, (const lds_float2*)s_tw2, (const lds_float2*)s_tw3, pp, item);
+            else {
+                // (kind of output) x (valid quarters of the block: tiles <= 128 / 192 / 256) -> one out-of-line role each
+                const int kind3 = __builtin_amdgcn_readfirstlane(params_of(pp)->f1_direct) ? 2
+                                  : __builtin_amdgcn_readfirstlane(params_of(pp)->nosurf) ? 1 : 0;
+                const int tpb = __builtin_amdgcn_readfirstlane(params_of(pp)->tiles_per_blk);
+#define CAF_FFT_ROLE(K, Q) persistent_fft_item<K, Q>((lds_float2*)s_d, (const lds_float2*)s_tw2, (const lds_float2*)s_tw3, pp, item)
+                if (tpb <= 128) {
+                    if (kind3 == 2) CAF_FFT_ROLE(2, 2); else if (kind3 == 1) CAF_FFT_ROLE(1, 2); else CAF_FFT_ROLE(0, 2);
+                } else if (tpb <= 192) {
+                    if (kind3 == 2) CAF_FFT_ROLE(2, 3); else if (kind3 == 1) CAF_FFT_ROLE(1, 3); else CAF_FFT_ROLE(0, 3);
+                } else {
+                    if (kind3 == 2) CAF_FFT_ROLE(2, 4); else if (kind3 == 1) CAF_FFT_ROLE(1, 4); else CAF_FFT_ROLE(0, 4);
+                }
+#undef CAF_FFT_ROLE
+            }
             if (STATS) {
                 const uint64_t now = wall_clock64();
                 t_fft += (uint32_t)(now - tmark);

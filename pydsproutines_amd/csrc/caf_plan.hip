@@ -468,6 +468,11 @@ static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
     lb = std::max(lb, 9);  // the multiply kernel tiles 512 points per workgroup
     p->B = 1 << lb;
     p->step = p->B - N + 1;
+    // In-LDS engines: delays leave a block in tiles of 64.  A step that is a few delays over a multiple of 64 (N = 4096:
+    // 12289 = 192 * 64 + 1) costs a 193rd tile per block holding one delay -- a tile item of its own for the tile role
+    // (1365 of 17745 items at C2) and, in the FFT role, the whole last quarter of the radix-4 pass for one output.
+    // Giving up those few delays per block (< 0.33 % more blocks) removes both.
+    if (p->fused && p->step % 64 != 0 && (p->step % 64) * 300 <= p->step) p->step -= p->step % 64;
     p->pitch = p->B + 64;  // break the power-of-two stride between hypothesis rows
     const int B = p->B;
 
