@@ -120,7 +120,8 @@ typedef struct caf_plan_desc {
  *           and cannot produce d_cqf.
  *   PERSISTENT: the two FUSED stages as ONE work-queue launch (one resident workgroup per CU): the
  *           HBM-bound transpose runs on some CUs while the others compute FFTs.  Same conditions and
- *           results as FUSED.
+ *           results as FUSED.  d_cqf: supported with 16384-point blocks as the ONLY output of a call
+ *           (the FFT work items write the complex rows themselves).
  *   AUTO  : PERSISTENT when the FUSED conditions hold and log2_block is 0 or 14, else ROCFFT. */
 #define CAF_ENGINE_AUTO 0
 #define CAF_ENGINE_ROCFFT 1

@@ -58,6 +58,7 @@ static_assert(fp_row2(15) + 256 <= FP_P1 && FP_P1 % 256 == 32, "planar image geo
 #define CAF_AS1 __attribute__((address_space(1)))
 typedef float v2f_t __attribute__((ext_vector_type(2)));
 typedef float v4f_t __attribute__((ext_vector_type(4)));
+typedef int v2i_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float2 ld2(const float2* base, uint32_t elem) {
     const uint64_t u = *reinterpret_cast<const CAF_AS1 uint64_t*>((const CAF_AS1 char*)base + (elem << 3));
     float2 r;
@@ -218,8 +219,12 @@ __device__ __forceinline__ void tile_store(__amdgpu_buffer_rsrc_t r, uint32_t vo
 // MODE 3 (no frequency scan, one hypothesis per template: config C3, TemplateCrossCorrelator-style banks): every |y|^2
 // IS a per-delay result, so the FFT item normalises it and writes it where the caller wants it -- row_max (T, S) and / or
 // the (T, S, 1) surface -- instead of a tile that a second role reads back, scales and writes again.
+// MODE 4 (complex QF rows: caf_outputs::d_cqf, TemplateCrossCorrelator.correlate / fastXcorr(absResult=False),
+// xcorrRoutines.py:352-357, :533-548): the hypothesis-major complex plane [T*F][num_shifts] is exactly what an FFT item
+// produces -- one transform = one row segment -- so the item writes y * sqrt(1/energy) * sqrt(1/||t||^2) as complex64
+// itself; no tiles, no tile role, any number of frequencies.
 struct F1Direct {
-    float* out0;          // row_max or surface, [T][num_shifts]
+    float* out0;          // row_max or surface, [T][num_shifts]; MODE 4: the complex plane (2 floats per value)
     float* out1;          // the other one of the two when both are wanted, else nullptr
     const float* inv_e;   // [num_shifts] 1 / window energy
     const float* tscale;  // [T]
@@ -261,7 +266,7 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
     // MODE 3: 1 / window energy of this thread's 16 delays (bv doubles as their storage), the valid extent of the block
     uint32_t f1_bytes = 0;
     int64_t f1_rel0 = 0;
-    if (MODE == 3) {
+    if (MODE >= 3) {
         f1_rel0 = (int64_t)f1->blk_abs * f1->step;
         int64_t nv = f1->num_shifts - f1_rel0;
         if (nv > f1->step) nv = f1->step;
@@ -275,6 +280,10 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
                 bv[4 * i + n4] = __builtin_bit_cast(
                     float, __builtin_amdgcn_raw_buffer_load_b32(rie, (((n2 >> 2) + 4 * q) * 64 + n1 + 16 * (n2 & 3)) * 4,
                                                                 (16 * i + 64 * n4) * 256, 0));
+        if (MODE == 4) {  // amplitudes, not powers: sqrt(1 / energy) per delay
+#pragma unroll
+            for (int o = 0; o < 16; ++o) bv[o] = __builtin_sqrtf(bv[o]);
+        }
     }
 
     // hypothesis-independent per-thread state: the pass-1 twiddle base e^{+j 2 pi m2 / 16384}
@@ -331,6 +340,10 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
             f1_r0 = buf_of(uniform_ptr(f1->out0 + (int64_t)h * f1->num_shifts + f1_rel0), f1_bytes);  // past the block's
             if (f1->out1)                                                                            // delays: dropped
                 f1_r1 = buf_of(uniform_ptr(f1->out1 + (int64_t)h * f1->num_shifts + f1_rel0), f1_bytes);
+        }
+        if (MODE == 4) {
+            f1_ts = __builtin_sqrtf(*((const CAF_AS1 float*)f1->tscale + h / nfreq));
+            f1_r0 = buf_of(uniform_ptr(f1->out0 + 2 * ((int64_t)h * f1->num_shifts + f1_rel0)), 2u * f1_bytes);
         }
         // ---- pass 1: P = X * Hc_h ; DFT16 over a ; twiddle w^n1 ; write A[n1][m2] ----
         // One butterfly at a time (32 live data registers).  pr is dead after this pass and is refilled
@@ -445,6 +458,11 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
                         const uint32_t sh8 = 8u * (uint32_t)(oo & 3);
                         const uint32_t repl = (bi[oo >> 2] & ~(0xffu << sh8)) | ((uint32_t)(h - h0) << sh8);
                         bi[oo >> 2] = up ? repl : bi[oo >> 2];
+                    } else if (MODE == 4) {
+                        const float gq = bv[4 * i + n4] * f1_ts;
+                        const v2f_t ov = {yq.x * gq, yq.y * gq};
+                        const uint32_t v3 = (uint32_t)(tile_t * 64 + n1 + 16 * (n2 & 3)) << 3, s3 = (uint32_t)tile_u * 512u;
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i_t, ov), f1_r0, (int)v3, (int)s3, CAF_AUX_NT);
                     } else if (MODE == 3) {
                         // the finished per-delay value, rounded as the tile roles round it: value * (1/energy * 1/||t||^2)
                         const float outv = val * (bv[4 * i + n4] * f1_ts);
@@ -1375,7 +1393,7 @@ __device__ __forceinline__ void pq_mark(const PersistParams* pp, int slot, int v
 // spilled values every hypothesis).  Called ~21 times per workgroup: the call and the callee-saved register
 // traffic are negligible.  Arguments arrive in VGPRs; v_readfirstlane makes them scalar again.
 typedef __attribute__((address_space(3))) float2 lds_float2;
-template <int KIND, int NV4>  // 0: |y|^2 tiles, 1: running maxima (no surface), 2: finished rows (no frequency scan)
+template <int KIND, int NV4>  // 0: |y|^2 tiles, 1: running maxima (no surface), 2: finished rows (no frequency scan), 3: complex rows
 __device__ __attribute__((noinline)) void persistent_fft_item(lds_float2* s_d, const lds_float2* s_tw2,
                                                               const lds_float2* s_tw3, const PersistParams* pp_in,
                                                               int item_in) {
@@ -1392,7 +1410,18 @@ __device__ __attribute__((noinline)) void persistent_fft_item(lds_float2* s_d, c
         h0 = t * P->nfreq + (grp - t * gpt) * hyp_per_wg;
         h1 = min(h0 + hyp_per_wg, (t + 1) * P->nfreq);
     }
-    if (KIND == 2) {
+    if (KIND == 3) {
+        F1Direct f1;
+        f1.out0 = P->cqf;
+        f1.out1 = nullptr;
+        f1.inv_e = P->inv_e;
+        f1.tscale = P->tscale;
+        f1.num_shifts = P->num_shifts;
+        f1.step = P->step;
+        f1.blk_abs = P->blk0 + blk;
+        fused_item<1024, 4, NV4>((float2*)s_d, (const float2*)s_tw2, (const float2*)s_tw3, P->xb, P->hc, P->shifts, P->tw1,
+                                 P->table_mode, P->nfreq, nhyp, blk, h0, h1, P->tiles_per_blk, nullptr, nullptr, &f1);
+    } else if (KIND == 2) {
         F1Direct f1;
         f1.out0 = P->row_max ? P->row_max : P->surface;
         f1.out1 = (P->row_max && P->surface) ? P->surface : nullptr;
@@ -1543,16 +1572,17 @@ __global__ __launch_bounds__(1024) void k_caf_persistent(const PersistParams* __
                 persistent_fft_item2((lds_float2*)s_d, (const lds_float2*)s_tw2, (const lds_float2*)s_tw3, pp, item);
             else {
                 // (kind of output) x (valid quarters of the block: tiles <= 128 / 192 / 256) -> one out-of-line role each
-                const int kind3 = __builtin_amdgcn_readfirstlane(params_of(pp)->f1_direct) ? 2
+                const int kind3 = params_of(pp)->cqf ? 3
+                                  : __builtin_amdgcn_readfirstlane(params_of(pp)->f1_direct) ? 2
                                   : __builtin_amdgcn_readfirstlane(params_of(pp)->nosurf) ? 1 : 0;
                 const int tpb = __builtin_amdgcn_readfirstlane(params_of(pp)->tiles_per_blk);
 #define CAF_FFT_ROLE(K, Q) persistent_fft_item<K, Q>((lds_float2*)s_d, (const lds_float2*)s_tw2, (const lds_float2*)s_tw3, pp, item)
                 if (tpb <= 128) {
-                    if (kind3 == 2) CAF_FFT_ROLE(2, 2); else if (kind3 == 1) CAF_FFT_ROLE(1, 2); else CAF_FFT_ROLE(0, 2);
+                    if (kind3 == 3) CAF_FFT_ROLE(3, 2); else if (kind3 == 2) CAF_FFT_ROLE(2, 2); else if (kind3 == 1) CAF_FFT_ROLE(1, 2); else CAF_FFT_ROLE(0, 2);
                 } else if (tpb <= 192) {
-                    if (kind3 == 2) CAF_FFT_ROLE(2, 3); else if (kind3 == 1) CAF_FFT_ROLE(1, 3); else CAF_FFT_ROLE(0, 3);
+                    if (kind3 == 3) CAF_FFT_ROLE(3, 3); else if (kind3 == 2) CAF_FFT_ROLE(2, 3); else if (kind3 == 1) CAF_FFT_ROLE(1, 3); else CAF_FFT_ROLE(0, 3);
                 } else {
-                    if (kind3 == 2) CAF_FFT_ROLE(2, 4); else if (kind3 == 1) CAF_FFT_ROLE(1, 4); else CAF_FFT_ROLE(0, 4);
+                    if (kind3 == 3) CAF_FFT_ROLE(3, 4); else if (kind3 == 2) CAF_FFT_ROLE(2, 4); else if (kind3 == 1) CAF_FFT_ROLE(1, 4); else CAF_FFT_ROLE(0, 4);
                 }
 #undef CAF_FFT_ROLE
             }

@@ -877,7 +877,12 @@ int32_t caf_plan_execute(caf_plan p, const float* d_rx, int64_t rx_len, int64_t 
     if (aux) CAF_HIP_TRY(hipStreamWaitEvent(st, p->ev_join, 0));
     bool f1_direct = false;
     if (p->fused) {
-        CAF_REQUIRE(!out->d_cqf, "the fused engine has no complex-QF output (create the plan with CAF_ENGINE_ROCFFT)");
+        // complex QF rows: written by the FFT items of the one-launch engine themselves (fused_item MODE 4), as the only
+        // output of the call
+        const bool cqf_rows = out->d_cqf != nullptr;
+        CAF_REQUIRE(!cqf_rows || (p->persistent && p->B == 16384 && !out->d_surface && !out->d_row_max && !out->d_row_arg && !want_peak),
+                    "the in-LDS engines write the complex-QF plane only from the persistent 16384-point engine and only as the "
+                    "sole output of a call (create the plan with CAF_ENGINE_ROCFFT for the other combinations)");
         // No surface wanted (per-delay traces / peaks only): the FFT items keep running per-delay maxima and
         // write one (value, hypothesis) pair per delay and group instead of the |y|^2 tiles (1/32 of the
         // bytes at 64 hypotheses per group).  Needs groups that do not straddle templates: with at least one
@@ -886,7 +891,7 @@ int32_t caf_plan_execute(caf_plan p, const float* d_rx, int64_t rx_len, int64_t 
         int ns_gpt = 0;
         {
             const char* e = getenv("CAF_PERSIST_NOSURF");  // A/B switch, default on
-            if (p->persistent && p->B == 16384 && !out->d_surface && F >= p->hyp_per_wg && (!e || atoi(e))) {
+            if (p->persistent && p->B == 16384 && !out->d_surface && !cqf_rows && F >= p->hyp_per_wg && (!e || atoi(e))) {
                 const int gpt = (F + p->hyp_per_wg - 1) / p->hyp_per_wg;
                 // the two pair arrays must fit the tile buffer they replace (true for >= 2 hypotheses per group)
                 if (2 * (int64_t)T * gpt <= (int64_t)T * F) ns_gpt = gpt;
@@ -902,7 +907,7 @@ int32_t caf_plan_execute(caf_plan p, const float* d_rx, int64_t rx_len, int64_t 
             const char* e = getenv("CAF_PERSIST_F1DIRECT");  // A/B switch, default on
             return !e || atoi(e);
         }();
-        f1_direct = p->persistent && p->B == 16384 && F == 1 && f1_env && (out->d_row_max || out->d_surface);
+        f1_direct = p->persistent && p->B == 16384 && F == 1 && f1_env && !cqf_rows && (out->d_row_max || out->d_surface);
         const int nb_launch = ns_gpt ? p->nb_nosurf : p->nb;  // blocks per launch
         for (int64_t b0 = 0; p->persistent && b0 < nblk; b0 += nb_launch) {
             const int32_t nbk = (int32_t)std::min<int64_t>(nb_launch, nblk - b0);
@@ -949,6 +954,10 @@ int32_t caf_plan_execute(caf_plan p, const float* d_rx, int64_t rx_len, int64_t 
             h.n_tr = nbk * h.ipb;
             if (f1_direct) {
                 h.f1_direct = 1;
+                h.n_tr = 0;
+            }
+            if (cqf_rows) {
+                h.cqf = out->d_cqf;
                 h.n_tr = 0;
             }
             // both stages are one kernel: its time is booked on the multiply/FFT stage

@@ -387,11 +387,14 @@ class TemplateCrossCorrelator:
     """ref: xcorrRoutines.py:277-371.  T templates, no frequency scan; returns QF (not QF^2):
     complex64 (T, M-L+1), or with returnMax (float32 QF[M-L+1], int64 templateIdx[M-L+1]).
 
-    ``fastMax`` (not upstream, default off): ``correlate(returnMax=True)`` then runs the one-launch engine on
-    per-template QF^2 traces and never forms the complex plane (config C3, 64 templates x 4096 vs 2^24 samples:
-    4.6 ms instead of 17 ms).  Off, the returnMax output is bit-for-bit the column max / argmax of the complex output,
-    the property the reference's unit test asserts (xcorrRoutines.py:2229-2233); on, it agrees with it to
-    float32 rounding (different FFT)."""
+    The complex plane comes from the one-launch in-LDS engine for templates of up to 8192 samples (its FFT work items
+    write the normalised complex rows themselves), from the rocFFT engine beyond.  ``returnMax=True`` is bit-for-bit
+    the column max / argmax of that complex output, the property the reference's unit test asserts
+    (xcorrRoutines.py:2229-2233).
+
+    ``fastMax`` (not upstream, default off): ``correlate(returnMax=True)`` then never forms the complex plane at all
+    (per-template QF^2 traces from the same engine, then the maximum of their square roots): it saves the 8.6 GB
+    round trip of the plane at config C3 and agrees with the default to float32 rounding."""
 
     def __init__(self, templates, inputSize, fastMax=False):
         self._fastMax = bool(fastMax)
@@ -426,7 +429,15 @@ class TemplateCrossCorrelator:
                                                    ct.c_void_p(ti.ptr), None))
             return qf, ti
         if self._plan is None:
-            self._plan = CAFPlan(self._tm, max_rx_len=self._inputSize, bins=[0], grid=self._grid, engine="rocfft")
+            # templates of up to 8192 samples: the one-launch in-LDS engine writes the complex rows itself (one transform
+            # = one row segment; config C3: 3.x ms for 8.6 GB of output); longer ones: multiply -> rocFFT -> normalise
+            if self._templateOrigLength <= 8192:
+                self._plan = CAFPlan(self._tm, max_rx_len=self._inputSize, bins=[0], grid=self._grid)
+                if self._plan.engine_used != "persistent" or self._plan.block != 16384:
+                    self._plan.close()
+                    self._plan = None
+            if self._plan is None:
+                self._plan = CAFPlan(self._tm, max_rx_len=self._inputSize, bins=[0], grid=self._grid, engine="rocfft")
         res = self._plan.run(x, rows=False, peak=False, cqf=True)
         nout = res.cqf.reshape(T, S)
         if not returnMax:

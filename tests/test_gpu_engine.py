@@ -479,3 +479,48 @@ def test_direct_engine_for_templates_with_a_handful_of_samples():
         CAFPlan(qpsk(rng, 100), max_rx_len=5000, bins=[0], grid=100, engine="direct")
     with pytest.raises(ValueError):
         plan.run(d_rx, cqf=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,m,nb", [(1000, 40000, 5), (4096, 70000, 17), (8192, 50000, 3), (300, 3000, 1)])
+def test_complex_qf_rows_from_the_persistent_engine(n, m, nb):
+    """caf_outputs::d_cqf from the one-launch in-LDS engine (its FFT items write the complex rows themselves) against the
+    rocFFT engine (multiply -> rocFFT -> normalise) and against the definition r / (||t|| ||window||) of
+    fastXcorr(absResult=False) / TemplateCrossCorrelator (xcorrRoutines.py:533-548, :352-357); sub-ranges of delays and
+    several templates x bins; the plane is the call's only output, anything else with it is refused."""
+    from pydsproutines_amd import CAFPlan, asarray
+
+    rng = np.random.default_rng(n + nb)
+    T = 3
+    tm = np.stack([qpsk(rng, n) * (0.5 + k) for k in range(T)])
+    rx = cn(rng, m)
+    rx[m // 3 : m // 3 + n] += tm[1]
+    grid = 1 << int(np.ceil(np.log2(n)))
+    bins = np.arange(-(nb // 2), nb - nb // 2)
+    d_rx = asarray(rx)
+    planes = {}
+    for engine in ("persistent", "rocfft"):
+        plan = CAFPlan(tm, max_rx_len=m, bins=bins, grid=grid, engine=engine)
+        assert plan.engine_used == engine
+        planes[engine] = plan.run(d_rx, rows=False, peak=False, cqf=True).cqf.get()
+        lo, cnt = 777, min(1234, m - n + 1 - 777)
+        sub = plan.run(d_rx, shift_start=lo, num_shifts=cnt, rows=False, peak=False, cqf=True).cqf.get()
+        # (another alignment of the overlap-save blocks: equal to float32 rounding, not bit for bit)
+        np.testing.assert_allclose(sub, planes[engine][:, :, lo : lo + cnt], atol=2e-6)
+        if engine == "persistent":
+            with pytest.raises(ValueError):
+                plan.run(d_rx, cqf=True)  # rows / peaks together with the plane: the rocFFT engine's job
+        plan.close()
+    assert planes["persistent"].shape == (T, nb, m - n + 1)
+    assert np.max(np.abs(planes["persistent"] - planes["rocfft"])) <= 2e-5
+    # the definition, on a sample of delays: sum_k rx[d + k] conj(t[k]) e^{-j 2 pi b k / grid} / (||t|| ||rx[d : d + n]||)
+    sel = np.unique(np.concatenate((rng.integers(0, m - n + 1, 40), [0, m - n, m // 3])))
+    k = np.arange(n)
+    for t in range(T):
+        for bi, b in enumerate(bins):
+            u = np.conj(tm[t].astype(np.complex128)) * np.exp(-2j * np.pi * b * k / grid)
+            for d in sel:
+                w = rx[d : d + n].astype(np.complex128)
+                ref = np.dot(w, u) / (np.linalg.norm(tm[t].astype(np.complex128)) * np.linalg.norm(w))
+                assert abs(planes["persistent"][t, bi, d] - ref) <= 2e-5
+    assert abs(abs(planes["persistent"][1, nb // 2, m // 3]) - 1.0) < 0.3  # the planted copy (noise is as strong as it)
