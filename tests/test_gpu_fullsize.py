@@ -98,8 +98,14 @@ def test_c2_engines_agree(c2):
     r = other.run(c2["d_rx"], surface=False, rows=True, peak=True)
     a, b = c2["res"].row_max.get()[0], r.row_max.get()[0]
     assert np.max(np.abs(a - b)) <= 2e-6
-    same = np.mean(c2["res"].row_arg.get()[0] == r.row_arg.get()[0])
-    assert same > 0.9999  # differing rows are float ties in noise-only delays
+    # where the two engines name different bins, the LDS engine's own surface row holds a value within 2 tol of its
+    # maximum at the rocFFT engine's bin: float32 ties in noise-only delays, every one of them checked
+    ia, ib = c2["res"].row_arg.get()[0], r.row_arg.get()[0]
+    diff = np.nonzero(ia != ib)[0]
+    assert diff.size < 4096  # (a handful per million in practice; bounded so that the row reads below stay cheap)
+    for d in diff:
+        row = c2["res"].surface[0][int(d)].get()
+        assert row[ib[d]] >= row[ia[d]] - 2 * 2e-6 and row[ia[d]] == a[d]
     assert int(r.peak_delay.get()[0]) == D0
     other.close()
 

@@ -71,7 +71,12 @@ def test_fused_perdelay_strides_and_out_of_range_rules():
         sh = start + step * np.arange(num)
         rq, rf = O.fastXcorr(cut, rx, freqsearch=True, shifts=sh)
         assert np.max(np.abs(q - rq)) <= 2e-5
-        assert np.mean(fi == rf) > 0.99
+        # the argmax rule: where the reported bin is not the oracle's, the oracle's own row holds a value
+        # within 2 tol of its maximum at the reported bin -- a float32 tie, not a different peak
+        diff = np.nonzero(fi != rf)[0]
+        if diff.size:
+            rows = O.fastXcorr(cut, rx, freqsearch=True, outputCAF=True, shifts=sh[diff])
+            assert np.all(rows[np.arange(diff.size), fi[diff]] >= rows.max(axis=1) - 2 * 2e-5)
     # CyIppXcorrFFT rule: windows that leave rx give (0, 0)
     q, fi, pl, _ = _perdelay(cut.conj(), rx, -40, 1, 3000 - n + 90, zero_oor=True, caf=True)
     inside = (np.arange(-40, 3000 - n + 50) >= 0) & (np.arange(-40, 3000 - n + 50) + n <= 3000)
