@@ -18,7 +18,7 @@ def _taps(rng, n):
     return (t / np.sqrt(n)).astype(np.float32)  # unit-energy filter: outputs stay O(1)
 
 
-@pytest.mark.parametrize("ntaps,n", [(128, 50_000), (300, 50_000), (1024, 70_000), (8192, 100_000), (65_536, 400_000)])
+@pytest.mark.parametrize("ntaps,n", [(128, 50_000), (300, 50_000), (1024, 70_000), (8192, 100_000), (65_536, 150_000)])
 def test_lfilter_long_taps(ntaps, n):
     from pydsproutines_amd import asarray
     from pydsproutines_amd.filterRoutines import CupyKernelFilter
@@ -34,7 +34,7 @@ def test_lfilter_long_taps(ntaps, n):
     # decimated outputs are exactly the kept samples of the full-rate result (same kernel family: tolerance only)
     for dsr, ph in ((3, 1), (16, 15)):
         gd = f.filter_smtaps(asarray(x), asarray(taps), dsr=dsr, dsPhase=ph).get()
-        rd = OK.filter_lfilter(x, taps, dsr=dsr, dsPhase=ph)
+        rd = ref[ph::dsr]  # == OK.filter_lfilter(x, taps, dsr=dsr, dsPhase=ph): one scipy.signal.lfilter pass instead of three
         assert gd.shape == rd.shape
         assert np.max(np.abs(gd - rd)) <= 2e-5 * max(1.0, np.abs(rd).max())
 
