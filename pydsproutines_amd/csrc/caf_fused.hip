@@ -514,9 +514,11 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
 // fetched before pass 3 of the E half (E's outputs do not exist yet), and the inputs of the next E half are fetched
 // inside pass 4 of the O half, four positions at a time, as the combination frees E's registers.
 // Tiles: n -> tile n >> 6 as before (up to 384 tiles for N = 8193).  Write-through stores (MODE 1) or plain (0).
-template <int MODE>
+// NVH: quarters n4 < NVH of the UPPER half y[n' + 16384] hold valid delays (N = 16384: none -- the block's valid delays are
+// exactly the lower half; N = 8193: two); the others are not combined, squared or stored.
+template <int MODE, int NVH = 4>
 __device__ __forceinline__ void fused_item2(float2* __restrict__ s_d, const float2* __restrict__ s_tw2,
-                                            const float2* __restrict__ s_tw3, const float2* __restrict__ xb,  // [blocks][2][16384]
+                                            const float2* __restrict__ s_tw3, const float2* __restrict__ xb,  // [blocks][2][16384], butterfly order
                                             const float2* __restrict__ hc,       // [T][2][16384] or [T*F][2][16384]
                                             const int32_t* __restrict__ shifts, const float2* __restrict__ tw1,
                                             int32_t table_mode, int32_t nfreq, int32_t nhyp, int blk, int h0, int h1,
@@ -557,7 +559,7 @@ __device__ __forceinline__ void fused_item2(float2* __restrict__ s_d, const floa
     row_of(h0);
 #pragma unroll
     for (int a = 0; a < 16; ++a) {
-        xn[a] = ld2(xp, 1024u * a + m2);
+        xn[a] = ld2(xp, 1024u * a + tid);
         hn[a] = ld2(hrow_cur, (1024u * a + hb_cur) & (FB - 1));
     }
     float2 e[16];  // E's outputs (register 4 i + n4 <-> n3 = q + 4 i, n4)
@@ -604,7 +606,7 @@ __device__ __forceinline__ void fused_item2(float2* __restrict__ s_d, const floa
                 // inputs of the O half of this hypothesis: issued here, covered by pass 3 and pass 4
 #pragma unroll
                 for (int a = 0; a < 16; ++a) {
-                    xn[a] = ld2(xp, FB + 1024u * a + m2 + lz);
+                    xn[a] = ld2(xp, FB + 1024u * a + tid + lz);
                     hn[a] = ld2(hrow_cur, FB + ((1024u * a + hb_cur) & (FB - 1)) + lz);
                 }
             } else {
@@ -644,20 +646,23 @@ __device__ __forceinline__ void fused_item2(float2* __restrict__ s_d, const floa
                         const float ck = (float)__builtin_cos(2.0 * M_PI * k / 32.0), sk = (float)__builtin_sin(2.0 * M_PI * k / 32.0);
                         const float2 wn = cmul(wb, make_float2(ck, sk));
                         const float2 t = cmul(y[n4], wn);
-                        const float2 ylo = cadd(e[4 * i + n4], t), yhi = csub(e[4 * i + n4], t);
+                        const float2 ylo = cadd(e[4 * i + n4], t);
                         const int tile_u = 16 * i + 64 * n4;
                         const int tile_t = (n2o >> 2) + 4 * qo;
                         const uint32_t soff = (uint32_t)tile_u * (uint32_t)nhyp * 256u + hoff;  // uniform (scalar) offset
                         const uint32_t voff = ((uint32_t)tile_t * (uint32_t)nhyp * 64u + (uint32_t)(n1o + 16 * (n2o & 3))) << 2;
                         const uint32_t voff_hi = voff + (((uint32_t)256 * (uint32_t)nhyp * 64u) << 2);  // n + 16384: tile + 256
-                        const float vlo = ylo.x * ylo.x + ylo.y * ylo.y, vhi = yhi.x * yhi.x + yhi.y * yhi.y;
+                        const float vlo = ylo.x * ylo.x + ylo.y * ylo.y;
                         tile_store<MODE>(rvt, voff, soff, vlo);      // tiles >= tiles_per_blk: dropped by the range check
-                        tile_store<MODE>(rvt, voff_hi, soff, vhi);
+                        if (n4 < NVH) {
+                            const float2 yhi = csub(e[4 * i + n4], t);
+                            tile_store<MODE>(rvt, voff_hi, soff, yhi.x * yhi.x + yhi.y * yhi.y);
+                        }
                     }
                     // four positions of the next E half's inputs, into the registers the combination just freed
 #pragma unroll
                     for (int a = 4 * i; a < 4 * i + 4; ++a) {
-                        xn[a] = ld2(xp, 1024u * a + m2 + lzi);
+                        xn[a] = ld2(xp, 1024u * a + tid + lzi);
                         hn[a] = ld2(hrow_cur, ((1024u * a + hb_cur) & (FB - 1)) + lzi);
                     }
                 }
@@ -676,20 +681,27 @@ void launch_butterfly_order(const float2* in, float2* out, int64_t nchunks, hipS
     hipLaunchKernelGGL(k_butterfly_order, dim3((unsigned)std::min<int64_t>(nchunks, 65535)), dim3(256), 0, st, in, out, nchunks);
 }
 
-// rows of B = 2 * half complex samples -> parity-major: out[r][c][m'] = in[r][2 m' + c]
+// rows of B = 2 * half complex samples -> parity-major: out[r][c][m'] = in[r][2 m' + c]; BFLY: each parity half also in
+// butterfly order (see fp_tid_of), the order in which fused_item2 reads its block spectra once per half-transform
+template <bool BFLY>
 __global__ __launch_bounds__(256) void k_parity_major(const float2* __restrict__ in, float2* __restrict__ out, int32_t half) {
     const float2* ir = in + (int64_t)blockIdx.y * 2 * half;
     float2* orow = out + (int64_t)blockIdx.y * 2 * half;
-    for (int m = blockIdx.x * 256 + threadIdx.x; m < half; m += gridDim.x * 256) {
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < half; j += gridDim.x * 256) {
+        // (BFLY: output position j holds source element m: consecutive threads write consecutive addresses)
+        const int m = BFLY ? (int)((j & ~1023) + fp_m2((uint32_t)j & 1023u)) : j;
         const float4 v = *reinterpret_cast<const float4*>(&ir[2 * m]);
-        orow[m] = make_float2(v.x, v.y);
-        orow[half + m] = make_float2(v.z, v.w);
+        orow[j] = make_float2(v.x, v.y);
+        orow[half + j] = make_float2(v.z, v.w);
     }
 }
-void launch_parity_major(const float2* in, float2* out, int64_t rows, int32_t half, hipStream_t st) {
+void launch_parity_major(const float2* in, float2* out, int64_t rows, int32_t half, hipStream_t st, bool butterfly) {
     for (int64_t r0 = 0; r0 < rows; r0 += 65535) {
         const int64_t nr = std::min<int64_t>(65535, rows - r0);
-        hipLaunchKernelGGL(k_parity_major, dim3(16, (unsigned)nr), dim3(256), 0, st, in + r0 * 2 * half, out + r0 * 2 * half, half);
+        if (butterfly)
+            hipLaunchKernelGGL(k_parity_major<true>, dim3(16, (unsigned)nr), dim3(256), 0, st, in + r0 * 2 * half, out + r0 * 2 * half, half);
+        else
+            hipLaunchKernelGGL(k_parity_major<false>, dim3(16, (unsigned)nr), dim3(256), 0, st, in + r0 * 2 * half, out + r0 * 2 * half, half);
     }
 }
 
@@ -933,7 +945,9 @@ __global__ __launch_bounds__(256) void k_transpose_norm_argmax(
 // with an sc1 load; workgroup barrier between poll and loads; hipMalloc memory; one workgroup per CU; stores
 // 4-byte sc1; loads 4- or 16-byte sc1".  An agent-scope release fence per item (buffer_wbl2) would make the
 // hand-off model-conformant and was measured at +30 % per FFT item (it writes back the L2 shared by 32 CUs).
-constexpr int PQ_FFT_NEXT = 0, PQ_TR_NEXT = 1, PQ_DONE = 4;  // int32 slots of the queue block
+// int32 slots of the queue block: [0] FFT items claimed so far, [1] next tile item, [2..3] watchdog marks, [4..11] next FFT
+// item of each XCD's own list (see the claim), [12 + b] finished hypothesis groups of block b
+constexpr int PQ_FFT_NEXT = 0, PQ_TR_NEXT = 1, PQ_FFT_XCD = 4, PQ_DONE = 12;
 constexpr int PQ_TILES = 16;  // a tile item = 16 delay tiles of one block, one per wave (~2 MB of HBM traffic at F = 256)
 #define CAF_AS4 __attribute__((address_space(4)))
 
@@ -1452,6 +1466,7 @@ __device__ __attribute__((noinline)) void persistent_fft_item(lds_float2* s_d, c
 }
 
 // FFT role for 32768-point blocks (templates of 8193 .. 16384 samples): fused_item2, same publish sequence
+template <int NVH>
 __device__ __attribute__((noinline)) void persistent_fft_item2(lds_float2* s_d, const lds_float2* s_tw2, const lds_float2* s_tw3,
                                                                const PersistParams* pp_in, int item_in) {
     const PersistParams* pp = uniform_ptr(pp_in);
@@ -1462,8 +1477,8 @@ __device__ __attribute__((noinline)) void persistent_fft_item2(lds_float2* s_d, 
     const int grp = item - blk * ngroups;
     const int h0 = grp * hyp_per_wg;
     const int h1 = min(h0 + hyp_per_wg, nhyp);
-    fused_item2<1>((float2*)s_d, (const float2*)s_tw2, (const float2*)s_tw3, P->xb, P->hc, P->shifts, P->tw1, P->table_mode,
-                   P->nfreq, nhyp, blk, h0, h1, P->tiles_per_blk, P->vt);
+    fused_item2<1, NVH>((float2*)s_d, (const float2*)s_tw2, (const float2*)s_tw3, P->xb, P->hc, P->shifts, P->tw1, P->table_mode,
+                        P->nfreq, nhyp, blk, h0, h1, P->tiles_per_blk, P->vt);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (threadIdx.x == 0)
@@ -1528,12 +1543,34 @@ __global__ __launch_bounds__(1024) void k_caf_persistent(const PersistParams* __
                     }
                 }
                 if (fft_left) {
-                    int i = 0;
-                    if (lane0) i = atomicAdd(&pq[PQ_FFT_NEXT], 1);
-                    i = __builtin_amdgcn_readfirstlane(i);
-                    if (i < n_fft) {
+                    // FFT items are dealt per XCD: workgroup L runs on XCD L % 8, and XCD x owns the blocks b = x (mod 8),
+                    // so the hypothesis groups of one block run on CUs that share an L2 -- its block spectrum (which the
+                    // 32768-point role re-reads for every hypothesis) and the template-spectrum rows are served from
+                    // there instead of the fabric.  A workgroup whose own list is exhausted takes from the others'.
+                    // (Only where a role re-reads the spectrum per hypothesis: with the spectrum register-resident the
+                    // plain order is 0.5 % faster at C2.)
+                    const int nblk = P->nblk;
+                    const int x0 = (int)(blockIdx.x & 7);
+                    int got = -1;
+                    if (P->block_log2 != 15) {
+                        int i = 0;
+                        if (lane0) i = atomicAdd(&pq[PQ_FFT_XCD], 1);
+                        i = __builtin_amdgcn_readfirstlane(i);
+                        if (i < n_fft) got = i;
+                    }
+                    for (int k = 0; k < 8 && got < 0 && P->block_log2 == 15; ++k) {
+                        const int x = (x0 + k) & 7;
+                        const int items_x = ((nblk - x + 7) >> 3) * ngroups;  // blocks x, x + 8, ... < nblk
+                        if (__builtin_amdgcn_readfirstlane(pq_load(&pq[PQ_FFT_XCD + x])) >= items_x) continue;
+                        int j = 0;
+                        if (lane0) j = atomicAdd(&pq[PQ_FFT_XCD + x], 1);
+                        j = __builtin_amdgcn_readfirstlane(j);
+                        if (j < items_x) got = ((j / ngroups) * 8 + x) * ngroups + (j - (j / ngroups) * ngroups);
+                    }
+                    if (got >= 0) {
+                        if (lane0) atomicAdd(&pq[PQ_FFT_NEXT], 1);  // (the count that "FFT items left?" reads)
                         kind = 1;
-                        item = i;
+                        item = got;
                         break;
                     }
                     continue;
@@ -1568,8 +1605,15 @@ __global__ __launch_bounds__(1024) void k_caf_persistent(const PersistParams* __
             break;
         }
         if (kind == 1) {
-            if (__builtin_amdgcn_readfirstlane(params_of(pp)->block_log2) == 15)
-                persistent_fft_item2((lds_float2*)s_d, (const lds_float2*)s_tw2, (const lds_float2*)s_tw3, pp, item);
+            if (__builtin_amdgcn_readfirstlane(params_of(pp)->block_log2) == 15) {
+                const int tpb2 = __builtin_amdgcn_readfirstlane(params_of(pp)->tiles_per_blk);  // tiles >= 256: upper half
+                if (tpb2 <= 256)
+                    persistent_fft_item2<0>((lds_float2*)s_d, (const lds_float2*)s_tw2, (const lds_float2*)s_tw3, pp, item);
+                else if (tpb2 <= 384)
+                    persistent_fft_item2<2>((lds_float2*)s_d, (const lds_float2*)s_tw2, (const lds_float2*)s_tw3, pp, item);
+                else
+                    persistent_fft_item2<4>((lds_float2*)s_d, (const lds_float2*)s_tw2, (const lds_float2*)s_tw3, pp, item);
+            }
             else {
                 // (kind of output) x (valid quarters of the block: tiles <= 128 / 192 / 256) -> one out-of-line role each
                 const int kind3 = params_of(pp)->cqf ? 3

@@ -164,7 +164,7 @@ void launch_fos_scatter(const float2* rows, int64_t b0, int64_t nb, int64_t L, i
                         int32_t phase, float2* out, int64_t nout, hipStream_t st);
 
 // caf_fused.hip
-void launch_parity_major(const float2* in, float2* out, int64_t rows, int32_t half, hipStream_t st);
+void launch_parity_major(const float2* in, float2* out, int64_t rows, int32_t half, hipStream_t st, bool butterfly = false);
 void launch_fused_caf(const float2* xb, const float2* hc, const int32_t* shifts, const float2* tw1,
                       const float2* tw23, int32_t table_mode, int32_t nfreq, int32_t nhyp, int32_t hyp_per_wg,
                       int32_t nblk, int32_t tiles_per_blk, float* vt, hipStream_t st);

@@ -589,7 +589,7 @@ static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
             if (const char* e = getenv("CAF_PERSIST_TR_SLOTS")) p->tr_slots = std::max(0, atoi(e));
             p->tr_slots = std::min(p->tr_slots, 31);  // slot 0 of every XCD never prefers tiles (termination argument)
             if ((rc = p->alloc(&p->d_params, 1))) return rc;
-            if ((rc = p->alloc(&p->d_pq, 4 + std::max(nb, p->nb_nosurf)))) return rc;
+            if ((rc = p->alloc(&p->d_pq, 12 + std::max(nb, p->nb_nosurf)))) return rc;
         }
     } else {
         if ((rc = p->alloc(&p->d_pbuf, (int64_t)nb * T * F * p->pitch))) return rc;
@@ -873,7 +873,7 @@ int32_t caf_plan_execute(caf_plan p, const float* d_rx, int64_t rx_len, int64_t 
         }
     }
     if (p->fused && p->B == 32768)  // block spectra parity-major for the two chained half-transforms
-        launch_parity_major(p->d_xb, p->d_xb2, nfwd * p->fwd_chunk, p->B / 2, st);
+        launch_parity_major(p->d_xb, p->d_xb2, nfwd * p->fwd_chunk, p->B / 2, st, true);
     if (aux) CAF_HIP_TRY(hipStreamWaitEvent(st, p->ev_join, 0));
     bool f1_direct = false;
     if (p->fused) {
