@@ -94,6 +94,12 @@ __global__ __launch_bounds__((1 << LOGN) / 16 > 256 ? (1 << LOGN) / 16 : 256, 4)
     }
 
     const int64_t row0 = (int64_t)blockIdx.x * rows_per_wg * RPW;
+    // Consecutive delays, one row per workgroup and turn, every window of this workgroup's run inside rx: the window
+    // energy of row s is the previous row's minus |y[s - 1]|^2 plus |y[s + N - 1]|^2 -- two samples in float64 instead of
+    // the row's 16 per thread and the cross-lane / cross-wave float64 sums (the first row of the run is summed in full).
+    const bool e_slide = RPW == 1 && step == 1 && row0 + rows_per_wg <= num && start + row0 >= 0 &&
+                         start + row0 + rows_per_wg - 1 + N <= ylen;
+    double e_run = 0.0;
     for (int it = 0; it < rows_per_wg; ++it) {
         const int64_t row = row0 + (int64_t)it * RPW + rl;
         const bool live = row < num;  // (uniform per row slot; dead slots run the barriers with zeros)
@@ -123,19 +129,28 @@ __global__ __launch_bounds__((1 << LOGN) / 16 > 256 ? (1 << LOGN) / 16 : 256, 4)
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             const float2 a = RESIDENT ? xr[RESIDENT ? t : 0] : pd_ld2(x, (uint32_t)(lo + t * NTR)), b = v[t];
-            es += (double)b.x * b.x + (double)b.y * b.y;
+            if (!(e_slide && it > 0)) es += (double)b.x * b.x + (double)b.y * b.y;
             // conj(x * y): the inverse butterflies then deliver conj(FFT(x * y))
             v[t] = make_float2(a.x * b.x - a.y * b.y, -(a.x * b.y + a.y * b.x));
         }
         // window energy: lanes of the wave by shuffles; across the waves of a wide row through LDS, published by the
         // barrier that ends the first pass
-        double e = wave_sum(es);
-        if (WPR > 1 && lane == 0) s_e[it & 1][wave] = e;
-        pd_fft<LOGN>(buf, tw, lo, v);
-        if (WPR > 1) {
-            e = 0.0;
+        double e;
+        if (e_slide && it > 0) {
+            const float2 a = pd_ld2(yrow, (uint32_t)N - 1u), b = yrow[-1];  // (same address in every lane: one request)
+            e_run += ((double)a.x * a.x + (double)a.y * a.y) - ((double)b.x * b.x + (double)b.y * b.y);
+            e = e_run;
+            pd_fft<LOGN>(buf, tw, lo, v);
+        } else {
+            e = wave_sum(es);
+            if (WPR > 1 && lane == 0) s_e[it & 1][wave] = e;
+            pd_fft<LOGN>(buf, tw, lo, v);
+            if (WPR > 1) {
+                e = 0.0;
 #pragma unroll
-            for (int w = 0; w < WPR; ++w) e += s_e[it & 1][(wave / WPR) * WPR + w];
+                for (int w = 0; w < WPR; ++w) e += s_e[it & 1][(wave / WPR) * WPR + w];
+            }
+            e_run = e;
         }
         // normalisation as the unfused path rounds it: inv = (float)(1 / (sqrt(E) * ||x||)), applied to the amplitude
         const float inv = zero ? 0.f : (float)(1.0 / (sqrt(e) * sqrt(xnorm2)));

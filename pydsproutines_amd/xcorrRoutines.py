@@ -506,8 +506,17 @@ def cp_fastXcorr_v2(cutout, rx, startIdx=0, idxlen=None, THREADS_PER_BLOCK=32, n
         d_qf2 = empty(idxlen, np.float32)
     else:
         d_out = empty((idxlen, ncols), np.float32)
-    fi = 0
     lib = _lib.load()
+    n = int(cutout.size)
+    if (flattenCAF and cztObj is None and 64 <= n <= 16384 and n & (n - 1) == 0 and startIdx >= 0
+            and startIdx + idxlen - 1 + n <= rx.size):
+        # power-of-two cutout, every window inside rx: the whole chain (product, row transform, |.|^2, argmax, both norms)
+        # is ONE kernel (caf_perdelay.hip) -- no (idxlen, N) matrix, no batches, nothing to wait for
+        _lib.check(lib.caf_xcorr_perdelay(ct.c_void_p(cutout.ptr), n, ct.c_void_p(rx.ptr), rx.size, int(startIdx), 1,
+                                          int(idxlen), 0, ct.c_void_p(d_qf2.ptr), ct.c_void_p(d_freqIdx.ptr), None, None,
+                                          0, None), "caf_xcorr_perdelay")
+        return d_freqIdx, d_qf2
+    fi = 0
     while fi < idxlen:
         nb = min(BATCH, idxlen - fi)
         d_pdts = multiplySlidesNormalised(cutout, rx, startIdx + fi, nb)
@@ -518,8 +527,7 @@ def cp_fastXcorr_v2(cutout, rx, startIdx=0, idxlen=None, THREADS_PER_BLOCK=32, n
         else:
             _lib.check(lib.caf_complex_magnsq(ct.c_void_p(d_spec.ptr), d_spec.size, 0, ct.c_void_p(d_out[fi : fi + nb].ptr),
                                               0, None))
-        _lib.check(lib.caf_stream_sync(None))
-        fi += nb
+        fi += nb  # (no synchronisation per batch: the scratch of a batch is recycled in stream order)
     if flattenCAF:
         return d_freqIdx, d_qf2
     return d_out

@@ -11,6 +11,12 @@
 //  128 no idft16 arithmetic (passes 1-3 butterflies skipped)
 // Build: hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -std=c++17 -I../../include -I../../pydsproutines_amd/csrc
 #include "caf_fused.hip"
+// (round 3: the product kernel moved to a planar LDS image; this probe keeps the ROUND-2 structure it was written to
+// measure -- complex image, pitches 68 / 1090 -- as a historical harness; its numbers describe that structure only)
+namespace caf {
+constexpr int F_ROW = 68;
+constexpr int F_N1 = 16 * F_ROW + 2;
+}
 
 #include <cstdio>
 #include <type_traits>

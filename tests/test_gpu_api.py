@@ -111,6 +111,20 @@ def test_cp_fastxcorr_v2_and_kernel_chain():
         cp_fastXcorr_v2(d_cut, d_rx, cztObj=CZTCachedGPU(n + 1, -0.05, 0.05, 0.005, 1.0))
     with pytest.raises(TypeError):
         cp_fastXcorr_v2(cut, rx)
+    # power-of-two cutout, flattened: one fused kernel instead of product -> row FFT -> argmax (same results); a run
+    # whose last windows leave rx keeps the chain (zero padding of multiplySlices.cu:147-163)
+    n2 = 256
+    cut2 = rx[700 : 700 + n2].copy()
+    d_cut2 = asarray(cut2.conj())
+    fi2, q2 = cp_fastXcorr_v2(d_cut2, d_rx, 600, 300, flattenCAF=True)
+    ofi2, oq2 = O.cp_fastXcorr_v2(cut2.conj(), rx, 600, 300, flattenCAF=True)
+    assert fi2.dtype == np.uint32 and q2.dtype == np.float32 and fi2.shape == (300,)
+    np.testing.assert_allclose(q2.get(), oq2, atol=TOL)
+    assert int(np.argmax(q2.get())) == 100 and fi2.get()[100] == 0 and abs(q2.get()[100] - 1.0) < 1e-5
+    clear = np.abs(oq2 - np.sort(O.cp_fastXcorr_v2(cut2.conj(), rx, 600, 300), axis=1)[:, -2]) > 4 * TOL
+    np.testing.assert_array_equal(fi2.get()[clear], ofi2[clear])
+    plane2 = cp_fastXcorr_v2(d_cut2, d_rx, 600, 300)  # the plane still comes from the chain
+    np.testing.assert_allclose(q2.get(), plane2.get().max(axis=1), atol=TOL)
 
 
 # ---- grouped templates ----------------------------------------------------------------------

@@ -116,6 +116,10 @@ np.savez(sys.argv[1], **out)
     for k in res["fused"]:
         a, b = res["fused"][k], res["unfused"][k]
         if k.startswith("f"):
-            assert np.mean(a == b) > 0.99, k
+            # where the two forms name different bins, the fused form's own plane holds a value within 2 tol of its row
+            # maximum at the other form's bin: a float32 tie
+            pl = res["fused"]["p" + k[1:]]
+            for r in np.nonzero(a != b)[0]:
+                assert pl[r, b[r]] >= pl[r].max() - 2 * 2e-6, (k, r)
         else:
             assert np.max(np.abs(a - b)) <= 2e-6, k
