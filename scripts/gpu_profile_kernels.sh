@@ -5,7 +5,7 @@
 #   then scripts/summarize_kernels.py -> gpurun_out/prof_<tag>/kernels_summary.{txt,json}
 # usage: bash scripts/gpu_profile_kernels.sh <tag> [workload ...]      (default: all workloads)
 set -e
-TAG=${1:-r02}; shift || true
+TAG=${1:-r03}; shift || true
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -16,9 +16,10 @@ export TMPDIR=/tmp
 for w in $WL; do
   echo "== workload $w" | tee -a $OUT/progress.log
   mkdir -p $OUT/$w
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$w/trace -- python3 scripts/profile_workloads.py $w $OUT/$w/manifest.json > $OUT/$w/trace.log 2>&1 || { tail -20 $OUT/$w/trace.log; exit 1; }
-  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/$w/pmc_fetch -- python3 scripts/profile_workloads.py $w > $OUT/$w/fetch.log 2>&1 || { tail -20 $OUT/$w/fetch.log; exit 1; }
-  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/$w/pmc_write -- python3 scripts/profile_workloads.py $w > $OUT/$w/write.log 2>&1 || { tail -20 $OUT/$w/write.log; exit 1; }
+  # (the trace pass repeats the workload so that the dominant kernel has >= 10 dispatches: median + minimum are reported)
+  PROFILE_REPS_SCALE=${PROFILE_REPS_SCALE:-5} rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$w/trace -- python3 scripts/profile_workloads.py $w $OUT/$w/manifest.json > $OUT/$w/trace.log 2>&1 || { tail -20 $OUT/$w/trace.log; exit 1; }
+  PROFILE_REPS_SCALE=1 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/$w/pmc_fetch -- python3 scripts/profile_workloads.py $w $OUT/$w/manifest_pmc.json > $OUT/$w/fetch.log 2>&1 || { tail -20 $OUT/$w/fetch.log; exit 1; }
+  PROFILE_REPS_SCALE=1 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/$w/pmc_write -- python3 scripts/profile_workloads.py $w > $OUT/$w/write.log 2>&1 || { tail -20 $OUT/$w/write.log; exit 1; }
 done
 python3 scripts/summarize_kernels.py $OUT > $OUT/kernels_summary.txt
 cat $OUT/kernels_summary.txt

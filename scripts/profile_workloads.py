@@ -106,6 +106,24 @@ def w_c3():
     return caf("persistent", False, T=64, F=1)
 
 
+def w_c3_complex_rows():
+    """Config C3 through the reference's literal call: TemplateCrossCorrelator.correlate(x) -> complex64 (64, S): the FFT items
+    of the one-launch engine write the complex rows themselves (8 B written per template and delay)."""
+    from pydsproutines_amd.xcorrRoutines import TemplateCrossCorrelator
+
+    T = 64
+    tm = np.stack([qpsk(rng, N) for _ in range(T)])
+    _, d_rx = c2_inputs()
+    tcc = TemplateCrossCorrelator(asarray(tm), M)
+    for _ in range(2):
+        out = tcc.correlate(d_rx)
+    sync()
+    del out
+    nblk = -(-S // tcc._plan.step)
+    return [("k_caf_persistent", "one-launch engine, T=64 F=1, complex QF rows (8 B written per value, block spectra read once "
+             "per 32 templates)", T * S * 8.0 + nblk * 8.0 * 16384 * (T / 32.0), nblk * T * (5.0 * 16384 * 14 + 6.0 * 16384 + 4.0 * tcc._plan.step), 2)]
+
+
 def w_c4_share():
     return caf("persistent", False, T=64, F=512, reps=1, rows=False)
 
@@ -299,9 +317,15 @@ if __name__ == "__main__":
         print(" ".join(WORKLOADS))
         sys.exit(0)
     name = sys.argv[1]
-    man = WORKLOADS[name]()
-    sync()
-    out = [{"kernel": k, "what": w, "alg_bytes_per_call": b, "alg_flops_per_call": fl, "calls": c} for k, w, b, fl, c in man]
+    # PROFILE_REPS_SCALE=k: the workload is run k times in this process (>= 10 dispatches of its dominant kernel for the
+    # timing statistics of the trace pass; the counter passes keep k = 1, traffic per call does not vary)
+    import os
+
+    scale = max(1, int(os.environ.get("PROFILE_REPS_SCALE", "1")))
+    for _ in range(scale):
+        man = WORKLOADS[name]()
+        sync()
+    out = [{"kernel": k, "what": w, "alg_bytes_per_call": b, "alg_flops_per_call": fl, "calls": c * scale} for k, w, b, fl, c in man]
     if len(sys.argv) > 2:
         json.dump({"workload": name, "kernels": out}, open(sys.argv[2], "w"), indent=1)
     print("workload %s done: %d kernels declared" % (name, len(out)))

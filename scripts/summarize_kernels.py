@@ -30,13 +30,15 @@ def short(name):
 
 
 def load_trace(path):
-    d = defaultdict(lambda: [0, 0.0])
+    d = defaultdict(lambda: [0, 0.0, []])  # dispatches, total us, the individual durations
     if path:
         with open(path) as f:
             for row in csv.DictReader(f):
                 k = short(row["Kernel_Name"])
+                us = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3
                 d[k][0] += 1
-                d[k][1] += (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3
+                d[k][1] += us
+                d[k][2].append(us)
     return d
 
 
@@ -65,6 +67,8 @@ def main(out):
         wdir = os.path.dirname(mpath)
         man = json.load(open(mpath))
         name = man["workload"]
+        pmc_path = os.path.join(wdir, "manifest_pmc.json")  # the counter passes run the workload once (their own call counts)
+        pmc_calls = {e["kernel"]: e["calls"] for e in json.load(open(pmc_path))["kernels"]} if os.path.exists(pmc_path) else {}
         trace = load_trace(find(os.path.join(wdir, "trace"), "*kernel_trace.csv"))
         fetch = load_pmc(find(os.path.join(wdir, "pmc_fetch"), "*counter_collection.csv"), "FETCH_SIZE")
         write = load_pmc(find(os.path.join(wdir, "pmc_write"), "*counter_collection.csv"), "WRITE_SIZE")
@@ -87,22 +91,28 @@ def main(out):
             gbs = ab / (per_call_us * 1e-6) / 1e9 if per_call_us > 0 else 0.0
             tfs = af / (per_call_us * 1e-6) / 1e12 if per_call_us > 0 else 0.0
             # KiB counters -> bytes per call; FETCH doubled
-            fb = sum(fetch.get(k, 0.0) for k in ks) * 1024.0 * 2.0 / calls
-            wb = sum(write.get(k, 0.0) for k in ks) * 1024.0 / calls
+            pc = max(int(pmc_calls.get(e["kernel"], calls)), 1)
+            fb = sum(fetch.get(k, 0.0) for k in ks) * 1024.0 * 2.0 / pc
+            wb = sum(write.get(k, 0.0) for k in ks) * 1024.0 / pc
+            durs = sorted(u for k in ks for u in trace[k][2])
+            med_us = durs[len(durs) // 2] if durs else 0.0
+            min_us = durs[0] if durs else 0.0
             ratio = (fb + wb) / ab if ab > 0 and (fb + wb) > 0 else None
             print("%-34s %6d %10.3f %10.1f | %9.3f %8.1f %7.3f | %8.2f %6.3f | %9.3f %9.3f %6s" % (
                 e["kernel"][:34], disp, tus / 1e3, tus / max(disp, 1), ab / 1e9, gbs, gbs / HBM_PEAK, tfs, tfs / F32_PEAK,
                 fb / 1e9, wb / 1e9, ("%.2f" % ratio) if ratio else "-"))
             print("      %s" % e["what"])
+            print("      per dispatch: median %.1f us, minimum %.1f us over %d dispatches" % (med_us, min_us, disp))
             wres["kernels"].append({"kernel": e["kernel"], "what": e["what"], "matched": ks, "dispatches": disp, "calls": calls,
-                                    "total_ms": tus / 1e3, "avg_launch_us": tus / max(disp, 1), "per_call_us": per_call_us,
+                                    "total_ms": tus / 1e3, "avg_launch_us": tus / max(disp, 1), "median_launch_us": med_us,
+                                    "min_launch_us": min_us, "per_call_us": per_call_us,
                                     "alg_bytes_per_call": ab, "achieved_GBs": gbs, "frac_hbm_peak": gbs / HBM_PEAK,
                                     "alg_flops_per_call": af, "achieved_TFLOPs": tfs, "frac_f32_peak": tfs / F32_PEAK,
                                     "fetch_bytes_per_call_x2": fb, "write_bytes_per_call": wb, "measured_over_algorithmic": ratio})
         rest = sorted(((k, v) for k, v in trace.items() if k not in used), key=lambda kv: -kv[1][1])
         if rest:
             print("   other kernels of the run (library transforms, copies, set-up):")
-            for k, (n, t) in rest[:12]:
+            for k, (n, t, _) in rest[:12]:
                 print("      %-90s %6d disp %10.3f ms  %5.1f %%" % (k, n, t / 1e3, 100 * t / total_us))
                 wres["others"].append({"kernel": k, "dispatches": n, "total_ms": t / 1e3, "share": t / total_us})
         result["workloads"][name] = wres
