@@ -531,17 +531,15 @@ __device__ __forceinline__ void fused_item2(float2* __restrict__ s_d, const floa
     const uint32_t m0_x1 = img0 + wave_u * 256u, m0_w = img0 + wave_u * (uint32_t)FP_P1;
     const uint32_t m2 = fp_m2((uint32_t)tid);            // this thread's pass-1 butterfly (see fp_m2)
     const float2 w = ld2(tw1, 1024u + m2);  // pass-1 twiddle base e^{+j 2 pi m2 / 16384}
+    // The combination twiddle of the odd half, W^{n'} with n' = n1 + 16 n2 + 256 n3 + 4096 n4, is a product of one factor
+    // per output digit: each pass applies the factor of the digit it produces -- pass 1 through its base (2 m2 + 1
+    // instead of 2 m2 in 32768ths), passes 2 and 3 through the second halves of the twiddle tables, pass 4 as the
+    // constants W_8^{n4} -- so E and O' = W^{n'} O combine with an addition and a subtraction only.
+    const float2 w_odd = cmul(w, make_float2(0.99999998161642933f, 1.9174759731070330e-4f));  // * e^{+j 2 pi / 32768}
     const float2* xp = xb + (int64_t)blk * FB2;
     float* vt_blk = vt + (int64_t)blk * tiles_per_blk * nhyp * 64;
     const __amdgpu_buffer_rsrc_t rvt = buf_of(uniform_ptr(vt_blk), (uint32_t)tiles_per_blk * (uint32_t)nhyp * 256u);
-    // combination twiddle base e^{+j 2 pi nb / 32768}, nb = n1 + 16 n2 + 256 q (the thread's pass-4 position, < 1024)
-    const int n1o = tid & 15, n2o = (tid >> 4) & 15, qo = tid >> 8;
-    float2 wb;
-    {
-        double sn, cs;
-        sincos(2.0 * M_PI * (double)(n1o + 16 * n2o + 256 * qo) / 32768.0, &sn, &cs);
-        wb = make_float2((float)cs, (float)sn);
-    }
+    const int n1o = tid & 15, n2o = (tid >> 4) & 15, qo = tid >> 8;  // this thread's pass-4 position
     const float2* hrow_cur;
     uint32_t hb_cur;  // as in fused_item, with the shift in parity-major elements (= half the 32768-point shift)
     auto row_of = [&](int h) {
@@ -577,7 +575,7 @@ __device__ __forceinline__ void fused_item2(float2* __restrict__ s_d, const floa
 #pragma unroll
                 for (int a = 0; a < 16; ++a) v1[a] = cmul(xn[a], hn[a]);
                 idft16(v1);
-                float2 p = w;
+                float2 p = c == 0 ? w : w_odd;
                 asm volatile("" : "+v"(p.x), "+v"(p.y));
                 const float2 wj = p;
                 v1[1] = cmul(v1[1], p);
@@ -598,7 +596,7 @@ __device__ __forceinline__ void fused_item2(float2* __restrict__ s_d, const floa
                 for (int bh = 0; bh < 4; ++bh) lds_get4c(img, rd2 + 256u * bh, v[4 * bh], v[4 * bh + 1], v[4 * bh + 2], v[4 * bh + 3]);
                 idft16(v);
 #pragma unroll
-                for (int n2 = 1; n2 < 16; ++n2) v[n2] = cmul(v[n2], tw_ld(s_tw2, n2 * 64 + cd));
+                for (int n2 = 1; n2 < 16; ++n2) v[n2] = cmul(v[n2], tw_ld(s_tw2, 1024 * c + n2 * 64 + cd));
                 lds_rows16c_x2(m0_w, v);
             }
             __builtin_amdgcn_wave_barrier();
@@ -620,7 +618,7 @@ __device__ __forceinline__ void fused_item2(float2* __restrict__ s_d, const floa
                 for (int ch = 0; ch < 4; ++ch) lds_get4c(img, rd3 + 64u * ch, v[4 * ch], v[4 * ch + 1], v[4 * ch + 2], v[4 * ch + 3]);
                 idft16(v);
 #pragma unroll
-                for (int n3 = 1; n3 < 16; ++n3) v[n3] = cmul(v[n3], tw_ld(s_tw3, n3 * 4 + (tid & 3) + lz));
+                for (int n3 = 1; n3 < 16; ++n3) v[n3] = cmul(v[n3], tw_ld(s_tw3, 64 * c + n3 * 4 + (tid & 3) + lz));
                 lds_rows16c<256>(m0_w, v);
             }
             __syncthreads();
@@ -641,11 +639,12 @@ __device__ __forceinline__ void fused_item2(float2* __restrict__ s_d, const floa
                 } else {
 #pragma unroll
                     for (int n4 = 0; n4 < 4; ++n4) {
-                        // W^{n'} = wb * e^{j 2 pi (i + 4 n4) / 32}  (n' = nb + 1024 i + 4096 n4)
-                        const int k = i + 4 * n4;
-                        const float ck = (float)__builtin_cos(2.0 * M_PI * k / 32.0), sk = (float)__builtin_sin(2.0 * M_PI * k / 32.0);
-                        const float2 wn = cmul(wb, make_float2(ck, sk));
-                        const float2 t = cmul(y[n4], wn);
+                        // O' = O * W_8^{n4} (the last factor of the combination twiddle)
+                        constexpr float R2 = 0.70710678118654752f;
+                        const float2 t = n4 == 0   ? y[0]
+                                         : n4 == 1 ? make_float2((y[1].x - y[1].y) * R2, (y[1].x + y[1].y) * R2)
+                                         : n4 == 2 ? mulj(y[2])
+                                                   : make_float2((-y[3].x - y[3].y) * R2, (y[3].x - y[3].y) * R2);
                         const float2 ylo = cadd(e[4 * i + n4], t);
                         const int tile_u = 16 * i + 64 * n4;
                         const int tile_t = (n2o >> 2) + 4 * qo;
@@ -1489,15 +1488,19 @@ template <bool STATS>
 __global__ __launch_bounds__(1024) void k_caf_persistent(const PersistParams* __restrict__ pp) {
     static_assert(16 * TW_LDS * 4 <= F_LDS_DATA * 8, "transposer patches must fit the FFT image");
     __shared__ __attribute__((aligned(16))) float2 s_d[F_LDS_DATA];
-    __shared__ float2 s_tw2[16 * 64];
-    __shared__ float2 s_tw3[16 * 4];
+    __shared__ float2 s_tw2[2 * 16 * 64];  // [0]: every 16384-point transform; [1]: the odd half of a 32768-point block
+    __shared__ float2 s_tw3[2 * 16 * 4];
     __shared__ int32_t s_cmd[2];
     const int tid = threadIdx.x;
     {
         const CAF_AS4 PersistParams* P = params_of(pp);
         const float2* tw23 = P->tw23;
         s_tw2[tid] = tw23[tid];
-        if (tid < 64) s_tw3[tid] = tw23[1024 + tid];
+        s_tw2[1024 + tid] = tw23[1088 + tid];
+        if (tid < 64) {
+            s_tw3[tid] = tw23[1024 + tid];
+            s_tw3[64 + tid] = tw23[1088 + 1024 + tid];
+        }
     }
     __syncthreads();
     // The claim runs on wave 0 as SCALAR control flow (uniform values, scalar branches); only the atomic

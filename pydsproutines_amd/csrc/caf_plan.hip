@@ -183,7 +183,7 @@ static int fused_twiddles(int device, float2** tw1_out, float2** tw23_out) {
     std::lock_guard<std::mutex> lk(mu);
     if ((int)per_dev.size() <= device) per_dev.resize(device + 1, {nullptr, nullptr});
     if (!per_dev[device].first) {
-        std::vector<std::complex<float>> tw1(16 * 1024), tw23(16 * 64 + 16 * 4);
+        std::vector<std::complex<float>> tw1(16 * 1024), tw23(2 * (16 * 64 + 16 * 4));
         auto cis = [](double num, double den) {
             const double ph = 2.0 * M_PI * std::fmod(num, den) / den;
             return std::complex<float>((float)std::cos(ph), (float)std::sin(ph));
@@ -194,6 +194,12 @@ static int fused_twiddles(int device, float2** tw1_out, float2** tw23_out) {
             for (int c = 0; c < 64; ++c) tw23[n2 * 64 + c] = cis((double)n2 * c, 1024.0);
         for (int n3 = 0; n3 < 16; ++n3)
             for (int dd = 0; dd < 4; ++dd) tw23[1024 + n3 * 4 + dd] = cis((double)n3 * dd, 64.0);
+        // the same two tables for the ODD half-transform of a 32768-point block (fused_item2): its outputs carry the
+        // combination twiddle W_32768^{n'}, factor by factor in the pass that produces each output digit
+        for (int n2 = 0; n2 < 16; ++n2)
+            for (int c = 0; c < 64; ++c) tw23[1088 + n2 * 64 + c] = cis((double)n2 * (2 * c + 1), 2048.0);
+        for (int n3 = 0; n3 < 16; ++n3)
+            for (int dd = 0; dd < 4; ++dd) tw23[1088 + 1024 + n3 * 4 + dd] = cis((double)n3 * (2 * dd + 1), 128.0);
         float2 *a = nullptr, *b = nullptr;
         CAF_HIP_TRY(hipMalloc((void**)&a, tw1.size() * 8));
         hipError_t e = hipMalloc((void**)&b, tw23.size() * 8);
