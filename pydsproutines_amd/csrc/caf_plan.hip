@@ -345,7 +345,7 @@ static int32_t plan_build_direct(caf_plan p, const caf_plan_desc* d, const std::
     p->direct = true;
     p->dir_k = K;
     p->B = p->step = p->nb = 0;
-    p->partial_per_tmpl = (d->max_rx_len - N + 1 + 255) / 256;
+    p->partial_per_tmpl = (d->max_rx_len - N + 1 + 127) / 128;  // one record per workgroup of 128 delays (caf_direct.hip)
     std::vector<double> nu(F);
     for (int f = 0; f < F; ++f) {
         if (d->freq_mode == CAF_FREQ_BINS) {
@@ -816,7 +816,7 @@ int32_t caf_plan_execute(caf_plan p, const float* d_rx, int64_t rx_len, int64_t 
         p->stage_end(st);
         if (want_peak) {
             p->stage_begin(6, st);
-            launch_peak_reduce(p->d_partial, (num_shifts + 255) / 256, p->partial_per_tmpl, T,
+            launch_peak_reduce(p->d_partial, (num_shifts + 127) / 128, p->partial_per_tmpl, T,
                                p->d_partial + (int64_t)T * p->partial_per_tmpl, out->d_peak_val, out->d_peak_delay,
                                out->d_peak_freq, st);
             p->stage_end(st);
