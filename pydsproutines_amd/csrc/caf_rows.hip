@@ -325,21 +325,24 @@ __global__ __launch_bounds__(256) void k_moving_from_prefix(const double* __rest
 // Causal moving sum / mean in ONE launch for windows up to MAT_MAXL: a workgroup stages its MAT_TILE outputs' inputs
 // (tile + L - 1 samples, zeros before the start) in LDS, builds their float64 prefix there and writes differences.
 // No global prefix array, no scratch allocation, 4 B read + 4 B written per sample (plus the halo).
-constexpr int MAT_TILE = 4096;
+constexpr int MAT_TILE = 2048;
 constexpr int MAT_MAXL = 1024;  // (tile + window in LDS as float32 + float64 prefix: 64 KB of dynamic LDS)
 
-__global__ __launch_bounds__(256) void k_moving_tile(const float* __restrict__ x, int64_t n, int32_t L, int32_t sum_instead,
-                                                     float* __restrict__ out) {
+// MAT_NT threads: with 256 the three serial per-thread loops ran 17 dependent steps each (L = 100) and a workgroup's
+// critical path was latency, not bandwidth (58 us for 2^24 samples); 1024 threads own 5 samples each
+constexpr int MAT_NT = 512;
+__global__ __launch_bounds__(MAT_NT) void k_moving_tile(const float* __restrict__ x, int64_t n, int32_t L, int32_t sum_instead,
+                                                        float* __restrict__ out) {
     extern __shared__ double s_mat[];
     const int W = MAT_TILE + L - 1;                 // samples i0 - L + 1 .. i0 + MAT_TILE - 1
-    const int per = ((W + 255) / 256) | 1;          // samples per thread, odd (LDS banks)
-    double* s_p = s_mat;                            // exclusive prefix, 256 * per + 1 entries
-    float* s_x = reinterpret_cast<float*>(s_mat + 256 * per + 1);
-    __shared__ double s_wave[4];
+    const int per = ((W + MAT_NT - 1) / MAT_NT) | 1;  // samples per thread, odd (LDS banks)
+    double* s_p = s_mat;                            // exclusive prefix, MAT_NT * per + 1 entries
+    float* s_x = reinterpret_cast<float*>(s_mat + MAT_NT * per + 1);
+    __shared__ double s_wave[MAT_NT / 64];
     const float* xr = x + (int64_t)blockIdx.y * n;
     float* outr = out + (int64_t)blockIdx.y * n;
     const int64_t i0 = (int64_t)blockIdx.x * MAT_TILE;
-    for (int t = threadIdx.x; t < 256 * per; t += 256) {
+    for (int t = threadIdx.x; t < MAT_NT * per; t += MAT_NT) {
         const int64_t j = i0 - (L - 1) + t;
         s_x[t] = (t < W && j >= 0 && j < n) ? xr[j] : 0.f;
     }
@@ -362,9 +365,9 @@ __global__ __launch_bounds__(256) void k_moving_tile(const float* __restrict__ x
         s_p[e0 + j] = run;
         run += (double)s_x[e0 + j];
     }
-    if (threadIdx.x == 255) s_p[256 * per] = run;
+    if (threadIdx.x == MAT_NT - 1) s_p[MAT_NT * per] = run;
     __syncthreads();
-    for (int l = threadIdx.x; l < MAT_TILE; l += 256) {
+    for (int l = threadIdx.x; l < MAT_TILE; l += MAT_NT) {
         const int64_t i = i0 + l;
         if (i >= n) break;
         // window of output i: samples i - L + 1 .. i  ->  tile-local l .. l + L - 1
@@ -1493,9 +1496,9 @@ int moving_tile_max_window() { return MAT_MAXL; }
 void launch_moving_tile(const float* x, int64_t rows, int64_t n, int32_t L, int32_t sum_instead, float* out,
                         hipStream_t st) {
     const int W = MAT_TILE + L - 1;
-    const int per = ((W + 255) / 256) | 1;
-    const size_t sm = (size_t)(256 * per + 1) * sizeof(double) + (size_t)(256 * per) * sizeof(float);
-    hipLaunchKernelGGL(k_moving_tile, dim3(cdiv(n, MAT_TILE), (unsigned)rows), dim3(256), sm, st, x, n, L, sum_instead, out);
+    const int per = ((W + MAT_NT - 1) / MAT_NT) | 1;
+    const size_t sm = (size_t)(MAT_NT * per + 1) * sizeof(double) + (size_t)(MAT_NT * per) * sizeof(float);
+    hipLaunchKernelGGL(k_moving_tile, dim3(cdiv(n, MAT_TILE), (unsigned)rows), dim3(MAT_NT), sm, st, x, n, L, sum_instead, out);
 }
 
 bool fir_decim_ok(int32_t ntaps, int32_t dsr) { return dsr >= 1 && dsr <= FIRD_MAXDSR && ntaps <= 2048; }
