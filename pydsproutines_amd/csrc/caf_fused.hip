@@ -116,10 +116,11 @@ __device__ __forceinline__ void lds_rows16c_x2(uint32_t m0, const float2 (&v)[16
     lds_rows8<fp_row2(8), fp_row2(9), fp_row2(10), fp_row2(11), fp_row2(12), fp_row2(13), fp_row2(14), fp_row2(15)>(
         m0 + FP_IM, v[8].y, v[9].y, v[10].y, v[11].y, v[12].y, v[13].y, v[14].y, v[15].y);
 }
-// four consecutive values of both planes at byte offset `off` of the image -> four complex numbers
-__device__ __forceinline__ void lds_get4c(const lds_char* img, uint32_t off, float2& c0, float2& c1, float2& c2, float2& c3) {
+// four consecutive values of both planes at byte offsets `off` / `off_im` (= fp_im(base) + the same constant) -> four complex numbers
+__device__ __forceinline__ void lds_get4c(const lds_char* img, uint32_t off, uint32_t off_im, float2& c0, float2& c1, float2& c2,
+                                          float2& c3) {
     const v4f_t re = *reinterpret_cast<const lds_v4f*>(img + off);
-    const v4f_t im = *reinterpret_cast<const lds_v4f*>(img + off + FP_IM);
+    const v4f_t im = *reinterpret_cast<const lds_v4f*>(img + off_im);
     c0 = make_float2(re.x, im.x);
     c1 = make_float2(re.y, im.y);
     c2 = make_float2(re.z, im.z);
@@ -128,8 +129,22 @@ __device__ __forceinline__ void lds_get4c(const lds_char* img, uint32_t off, flo
 // twiddle-table read (LDS), volatile so that it stays one ds_read_b64: the compiler otherwise pairs these reads into
 // ds_read2_b64 / ds_read2st64_b64, which cost 8 LDS cycles per pair against 2 + 2 (MI355X_MICROARCH.md, LDS table);
 // A/B on one box: -1.2 % per transform
-__device__ __forceinline__ float2 tw_ld(const float2* t, uint32_t idx) {
-    const uint64_t u = *(const volatile __attribute__((address_space(3))) uint64_t*)(&t[idx]);
+typedef const volatile __attribute__((address_space(3))) uint64_t* lds_tw_ptr;
+__device__ __forceinline__ lds_tw_ptr tw_base(const float2* t, uint32_t first) {  // &t[first]: the per-thread part
+    // as an opaque register: the table lies beyond the 16-bit immediate range of the DS instructions, and left to itself
+    // the compiler forms every element's address with an instruction of its own (15 v_or per pass)
+    uint32_t a = (uint32_t)(uintptr_t)(lds_tw_ptr)(&t[first]);
+    asm volatile("" : "+v"(a));
+    return (lds_tw_ptr)(uintptr_t)a;
+}
+// the imaginary plane's copy of a read base (FP_IM is beyond the immediate range too: one add per pass, not per read)
+__device__ __forceinline__ uint32_t fp_im(uint32_t off) {
+    uint32_t a = off + (uint32_t)FP_IM;
+    asm volatile("" : "+v"(a));
+    return a;
+}
+__device__ __forceinline__ float2 tw_ld(lds_tw_ptr b, int k) {  // b[k], k a compile-time constant: an immediate offset
+    const uint64_t u = b[k];
     float2 r;
     __builtin_memcpy(&r, &u, 8);
     return r;
@@ -377,12 +392,13 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
         // arithmetic of butterfly j (they touch disjoint addresses)
         {
             float2 v[16];
-            const uint32_t rd2 = fp_rd2((uint32_t)(tid + lz)), cd = fp_cd2((uint32_t)(tid + lz));
+            const uint32_t rd2 = fp_rd2((uint32_t)(tid + lz)), rd2i = fp_im(rd2);
+            const lds_tw_ptr t2 = tw_base(s_tw2, fp_cd2((uint32_t)(tid + lz)));
 #pragma unroll
-            for (int bh = 0; bh < 4; ++bh) lds_get4c(img, rd2 + 256u * bh, v[4 * bh], v[4 * bh + 1], v[4 * bh + 2], v[4 * bh + 3]);
+            for (int bh = 0; bh < 4; ++bh) lds_get4c(img, rd2 + 256u * bh, rd2i + 256u * bh, v[4 * bh], v[4 * bh + 1], v[4 * bh + 2], v[4 * bh + 3]);
             idft16(v);
 #pragma unroll
-            for (int n2 = 1; n2 < 16; ++n2) v[n2] = cmul(v[n2], tw_ld(s_tw2, n2 * 64 + cd));
+            for (int n2 = 1; n2 < 16; ++n2) v[n2] = cmul(v[n2], tw_ld(t2, n2 * 64));
             lds_rows16c_x2(m0_w, v);  // value n2 -> row n2 of this wave's region, position = lane
         }
         // No workgroup barrier here: plane n1 = idx >> 6 is written in pass 2 and read in pass 3 by the SAME
@@ -396,17 +412,18 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
             for (int j = 0; j < BPT; ++j)
 #pragma unroll
                 for (int a = 0; a < 16; ++a)
-                    hn[j][a] = ld2(hrow_cur, ((1024u * a + hb_cur) & (FB - 1)) + lz);
+                    hn[j][a] = ld2(hrow_cur, (1024u * a + hb_cur) & (FB - 1));  // (hb_cur changes per hypothesis: nothing to hoist)
         }
         // ---- pass 3: DFT16 over c, in place (n1 = idx >> 6, n2 = (idx >> 2) & 15, d = idx & 3) ----
         {
             float2 v[16];
-            const uint32_t rd3 = fp_rd3((uint32_t)(tid + lz));
+            const uint32_t rd3 = fp_rd3((uint32_t)(tid + lz)), rd3i = fp_im(rd3);
 #pragma unroll
-            for (int ch = 0; ch < 4; ++ch) lds_get4c(img, rd3 + 64u * ch, v[4 * ch], v[4 * ch + 1], v[4 * ch + 2], v[4 * ch + 3]);
+            for (int ch = 0; ch < 4; ++ch) lds_get4c(img, rd3 + 64u * ch, rd3i + 64u * ch, v[4 * ch], v[4 * ch + 1], v[4 * ch + 2], v[4 * ch + 3]);
             idft16(v);
+            const lds_tw_ptr t3 = tw_base(s_tw3, (uint32_t)((tid & 3) + lz));
 #pragma unroll
-            for (int n3 = 1; n3 < 16; ++n3) v[n3] = cmul(v[n3], tw_ld(s_tw3, n3 * 4 + (tid & 3) + lz));
+            for (int n3 = 1; n3 < 16; ++n3) v[n3] = cmul(v[n3], tw_ld(t3, n3 * 4));
             lds_rows16c<256>(m0_w, v);  // value n3 -> row n3 of this wave's region, position = lane = d + 4 n2
         }
         if (MODE >= 2) {
@@ -416,7 +433,7 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
             for (int j = 0; j < BPT; ++j)
 #pragma unroll
                 for (int a = 0; a < 16; ++a)
-                    hn[j][a] = ld2(hrow_cur, ((1024u * a + hb_cur) & (FB - 1)) + lz);
+                    hn[j][a] = ld2(hrow_cur, (1024u * a + hb_cur) & (FB - 1));  // (hb_cur changes per hypothesis: nothing to hoist)
         }
         __syncthreads();
         // ---- pass 4: DFT4 over d ; |y|^2 -> vt tiles (lanes <-> consecutive delays) ----
@@ -424,7 +441,7 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
         for (int j = 0; j < BPT; ++j) {
             const int idx = tid + j * FT;
             const int n1 = idx & 15, n2 = (idx >> 4) & 15, q = idx >> 8;
-            const uint32_t rd4 = fp_rd4((uint32_t)idx);
+            const uint32_t rd4 = fp_rd4((uint32_t)idx), rd4i = fp_im(rd4);
             // next hypothesis' template-spectrum row for butterfly j: the loads fly while this butterfly's
             // pass-4 work runs
             __builtin_amdgcn_sched_barrier(0);
@@ -433,7 +450,7 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
                 uint32_t lzi = 0;
                 asm volatile("" : "+v"(lzi));
                 float2 a0, a1, a2, a3;
-                lds_get4c(img, rd4 + 1024u * i + lzi, a0, a1, a2, a3);  // n3 = q + 4 i: the four d of (n1, n2, n3)
+                lds_get4c(img, rd4 + 1024u * i + lzi, rd4i + 1024u * i + lzi, a0, a1, a2, a3);  // n3 = q + 4 i: the four d of (n1, n2, n3)
                 // inverse DFT4 over d, one output quarter n4 at a time (idft4 spelled out: unused quarters are skipped)
                 const float2 s02 = cadd(a0, a2), d02 = csub(a0, a2), s13 = cadd(a1, a3), d13 = mulj(csub(a1, a3));
                 // n = n1 + 16 n2 + 256 n3 + 4096 n4  ->  tile = n >> 6 = (n2 >> 2) + 4 n3 + 64 n4, lane = n & 63.
@@ -591,12 +608,13 @@ __device__ __forceinline__ void fused_item2(float2* __restrict__ s_d, const floa
             // ---- pass 2 ----
             {
                 float2 v[16];
-                const uint32_t rd2 = fp_rd2((uint32_t)(tid + lz)), cd = fp_cd2((uint32_t)(tid + lz));
+                const uint32_t rd2 = fp_rd2((uint32_t)(tid + lz)), rd2i = fp_im(rd2);
+                const lds_tw_ptr t2 = tw_base(s_tw2, fp_cd2((uint32_t)(tid + lz)));
 #pragma unroll
-                for (int bh = 0; bh < 4; ++bh) lds_get4c(img, rd2 + 256u * bh, v[4 * bh], v[4 * bh + 1], v[4 * bh + 2], v[4 * bh + 3]);
+                for (int bh = 0; bh < 4; ++bh) lds_get4c(img, rd2 + 256u * bh, rd2i + 256u * bh, v[4 * bh], v[4 * bh + 1], v[4 * bh + 2], v[4 * bh + 3]);
                 idft16(v);
 #pragma unroll
-                for (int n2 = 1; n2 < 16; ++n2) v[n2] = cmul(v[n2], tw_ld(s_tw2, 1024 * c + n2 * 64 + cd));
+                for (int n2 = 1; n2 < 16; ++n2) v[n2] = cmul(v[n2], tw_ld(t2, 1024 * c + n2 * 64));
                 lds_rows16c_x2(m0_w, v);
             }
             __builtin_amdgcn_wave_barrier();
@@ -613,24 +631,24 @@ __device__ __forceinline__ void fused_item2(float2* __restrict__ s_d, const floa
             // ---- pass 3 ----
             {
                 float2 v[16];
-                const uint32_t rd3 = fp_rd3((uint32_t)(tid + lz));
+                const uint32_t rd3 = fp_rd3((uint32_t)(tid + lz)), rd3i = fp_im(rd3);
 #pragma unroll
-                for (int ch = 0; ch < 4; ++ch) lds_get4c(img, rd3 + 64u * ch, v[4 * ch], v[4 * ch + 1], v[4 * ch + 2], v[4 * ch + 3]);
+                for (int ch = 0; ch < 4; ++ch) lds_get4c(img, rd3 + 64u * ch, rd3i + 64u * ch, v[4 * ch], v[4 * ch + 1], v[4 * ch + 2], v[4 * ch + 3]);
                 idft16(v);
 #pragma unroll
-                for (int n3 = 1; n3 < 16; ++n3) v[n3] = cmul(v[n3], tw_ld(s_tw3, 64 * c + n3 * 4 + (tid & 3) + lz));
+                for (int n3 = 1; n3 < 16; ++n3) v[n3] = cmul(v[n3], tw_ld(tw_base(s_tw3, (uint32_t)((tid & 3) + lz)), 64 * c + n3 * 4));
                 lds_rows16c<256>(m0_w, v);
             }
             __syncthreads();
             // ---- pass 4: DFT4 over d; the E half keeps its outputs, the O half combines and stores ----
-            const uint32_t rd4 = fp_rd4((uint32_t)tid);
+            const uint32_t rd4 = fp_rd4((uint32_t)tid), rd4i = fp_im(rd4);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 uint32_t lzi = 0;
                 asm volatile("" : "+v"(lzi));
                 float2 a0, a1, a2, a3;
-                lds_get4c(img, rd4 + 1024u * i + lzi, a0, a1, a2, a3);
+                lds_get4c(img, rd4 + 1024u * i + lzi, rd4i + 1024u * i + lzi, a0, a1, a2, a3);
                 idft4(a0, a1, a2, a3);
                 const float2 y[4] = {a0, a1, a2, a3};
                 if (c == 0) {
