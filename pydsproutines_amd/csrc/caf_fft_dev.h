@@ -7,8 +7,10 @@ namespace caf {
 
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+// (spelled with explicit fused multiply-adds: left to the contraction pass, the same source line rounds differently in
+// different surroundings, and the engines' modes -- surface, no surface, rows -- must agree bit for bit)
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
-    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+    return make_float2(__builtin_fmaf(a.x, b.x, -(a.y * b.y)), __builtin_fmaf(a.x, b.y, a.y * b.x));
 }
 __device__ __forceinline__ float2 mulj(float2 a) { return make_float2(-a.y, a.x); }  // * (+j)
 // inverse 4-point DFT (kernel e^{+j 2 pi m n / 4}), in place

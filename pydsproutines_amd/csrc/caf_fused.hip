@@ -442,15 +442,27 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
             const int idx = tid + j * FT;
             const int n1 = idx & 15, n2 = (idx >> 4) & 15, q = idx >> 8;
             const uint32_t rd4 = fp_rd4((uint32_t)idx), rd4i = fp_im(rd4);
-            // next hypothesis' template-spectrum row for butterfly j: the loads fly while this butterfly's
-            // pass-4 work runs
+            // The next hypothesis' products X * Hc (its row arrived during pass 3) fill the wait for the first LDS reads of
+            // this pass -- right after the barrier every wave of the SIMD would otherwise be waiting for data.  (Modes 2+
+            // fetch the row after pass 3: there the products stay at the end of the pass.)
             __builtin_amdgcn_sched_barrier(0);
+            float2 pf0, pf1, pf2, pf3;
+            if (MODE < 2) {
+                lds_get4c(img, rd4, rd4i, pf0, pf1, pf2, pf3);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int a = 0; a < 16; ++a) pr[j][a] = cmul(xr[j][a], hn[j][a]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 uint32_t lzi = 0;
                 asm volatile("" : "+v"(lzi));
                 float2 a0, a1, a2, a3;
-                lds_get4c(img, rd4 + 1024u * i + lzi, rd4i + 1024u * i + lzi, a0, a1, a2, a3);  // n3 = q + 4 i: the four d of (n1, n2, n3)
+                if (MODE < 2 && i == 0)
+                    a0 = pf0, a1 = pf1, a2 = pf2, a3 = pf3;
+                else
+                    lds_get4c(img, rd4 + 1024u * i + lzi, rd4i + 1024u * i + lzi, a0, a1, a2, a3);  // n3 = q + 4 i: the four d of (n1, n2, n3)
                 // inverse DFT4 over d, one output quarter n4 at a time (idft4 spelled out: unused quarters are skipped)
                 const float2 s02 = cadd(a0, a2), d02 = csub(a0, a2), s13 = cadd(a1, a3), d13 = mulj(csub(a1, a3));
                 // n = n1 + 16 n2 + 256 n3 + 4096 n4  ->  tile = n >> 6 = (n2 >> 2) + 4 n3 + 64 n4, lane = n & 63.
@@ -464,7 +476,7 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
                     const int tile_t = (n2 >> 2) + 4 * q;                     // per-thread part
                     const uint32_t soff = (uint32_t)tile_u * (uint32_t)nhyp * 256u + hoff;  // uniform (scalar) offset
                     const uint32_t voff = ((uint32_t)tile_t * (uint32_t)nhyp * 64u + (uint32_t)(n1 + 16 * (n2 & 3))) << 2;
-                    const float val = yq.x * yq.x + yq.y * yq.y;
+                    const float val = __builtin_fmaf(yq.x, yq.x, yq.y * yq.y);  // (explicit: every mode must round it the same way)
                     if (MODE == 2) {
                         // hypotheses come in increasing order: the first maximum stays (NaN never enters)
                         constexpr int o = 0;  // (placeholder, see below)
@@ -493,8 +505,10 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
                 }
                 __builtin_amdgcn_sched_barrier(0);  // keep the four sub-steps from being co-scheduled (registers)
             }
+            if (MODE >= 2) {
 #pragma unroll
-            for (int a = 0; a < 16; ++a) pr[j][a] = cmul(xr[j][a], hn[j][a]);
+                for (int a = 0; a < 16; ++a) pr[j][a] = cmul(xr[j][a], hn[j][a]);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -669,11 +683,11 @@ __device__ __forceinline__ void fused_item2(float2* __restrict__ s_d, const floa
                         const uint32_t soff = (uint32_t)tile_u * (uint32_t)nhyp * 256u + hoff;  // uniform (scalar) offset
                         const uint32_t voff = ((uint32_t)tile_t * (uint32_t)nhyp * 64u + (uint32_t)(n1o + 16 * (n2o & 3))) << 2;
                         const uint32_t voff_hi = voff + (((uint32_t)256 * (uint32_t)nhyp * 64u) << 2);  // n + 16384: tile + 256
-                        const float vlo = ylo.x * ylo.x + ylo.y * ylo.y;
+                        const float vlo = __builtin_fmaf(ylo.x, ylo.x, ylo.y * ylo.y);
                         tile_store<MODE>(rvt, voff, soff, vlo);      // tiles >= tiles_per_blk: dropped by the range check
                         if (n4 < NVH) {
                             const float2 yhi = csub(e[4 * i + n4], t);
-                            tile_store<MODE>(rvt, voff_hi, soff, yhi.x * yhi.x + yhi.y * yhi.y);
+                            tile_store<MODE>(rvt, voff_hi, soff, __builtin_fmaf(yhi.x, yhi.x, yhi.y * yhi.y));
                         }
                     }
                     // four positions of the next E half's inputs, into the registers the combination just freed
