@@ -445,7 +445,13 @@ static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
     }
     // the LDS-resident engines: 16384-point blocks for templates up to 8192 samples, 32768-point blocks (two chained
     // 16384-point transforms per hypothesis, persistent engine only) up to 16384
-    const int fused_lb = N <= 8192 ? 14 : 15;
+    // (CAF_FUSED_LB15=1: 32768-point blocks for the shorter templates too -- A/B switch: 87.5 % valid outputs per block at
+    //  N = 4096 instead of 75 %, against the dearer half-transforms of the 32768-point role)
+    static const bool lb15_env = [] {
+        const char* e = getenv("CAF_FUSED_LB15");
+        return e && atoi(e);
+    }();
+    const int fused_lb = (N <= 8192 && !lb15_env) ? 14 : 15;
     const bool fused_ok = N <= 16384 && (d->freq_mode != CAF_FREQ_BINS || (d->grid >= 1 && 16384 % d->grid == 0)) &&
                           (d->log2_block == 0 || d->log2_block == fused_lb);
     CAF_REQUIRE(d->engine != CAF_ENGINE_PERSISTENT || fused_ok,
