@@ -365,6 +365,13 @@ int main(int argc, char** argv) {
             alone[v] = ms(e[0], e[1]);
             printf("FFT model alone (%s): %.3f ms = %.2f us per transform\n", names[v], alone[v], alone[v] * 1e3 / nt);
         }
+        for (int wgs : {512, 1024, 2048}) {
+            CK(hipEventRecord(e[2], s2));
+            hipLaunchKernelGGL(k_tile<true>, dim3(wgs), dim3(256), 0, s2, ta);
+            CK(hipEventRecord(e[3], s2));
+            CK(hipEventSynchronize(e[3]));
+            printf("tile streamer alone, %d workgroups, plain (write-back) stores: %.3f ms = %.2f TB/s (read + write)\n", wgs, ms(e[2], e[3]), tile_bytes / ms(e[2], e[3]) / 1e9);
+        }
         {
             CK(hipEventRecord(e[2], s2));
             hipLaunchKernelGGL(k_tile<true>, dim3(256), dim3(256), 0, s2, ta);
