@@ -84,4 +84,17 @@ __device__ __forceinline__ void idft8(float2 (&v)[8]) {
     v[7] = csub(e3, o3);
 }
 
+// Lane mapping of the planar in-LDS engines (caf_fused.hip, "Thread <-> data of the four passes"): the pass-1 butterfly
+// of thread tid, and its inverse (the "butterfly order" in which template-spectrum rows and 32768-point block spectra
+// are stored: element m at (m & ~1023) + fp_tid_of(m & 1023)).
+__device__ __forceinline__ uint32_t fp_m2(uint32_t tid) {
+    const uint32_t lane = tid & 63, wave = tid >> 6;
+    const uint32_t b = (lane & 3) + 4 * (wave & 3), c = ((lane >> 2) & 3) + 4 * (wave >> 2), d = lane >> 4;
+    return 64 * b + 4 * c + d;
+}
+__host__ __device__ __forceinline__ uint32_t fp_tid_of(uint32_t m2) {
+    const uint32_t b = m2 >> 6, c = (m2 >> 2) & 15, d = m2 & 3;
+    return (b & 3) | ((c & 3) << 2) | (d << 4) | ((b >> 2) << 6) | ((c >> 2) << 8);
+}
+
 }  // namespace caf

@@ -155,21 +155,13 @@ __device__ __forceinline__ float2 tw_ld(lds_tw_ptr b, int k) {  // b[k], k a com
 //           and the low lane bits carry the digit pass 2 transforms (its 16-byte reads);
 //   pass 2: wave = n1, lane = (c & 3) + 4 d + 16 (c >> 2);   pass 3: wave = n1, lane = d + 4 n2;
 //   pass 4: n1 = tid & 15, n2 = (tid >> 4) & 15, n3 = (tid >> 8) + 4 i  (lanes <-> consecutive delays, as before).
-__device__ __forceinline__ uint32_t fp_m2(uint32_t tid) {
-    const uint32_t lane = tid & 63, wave = tid >> 6;
-    const uint32_t b = (lane & 3) + 4 * (wave & 3), c = ((lane >> 2) & 3) + 4 * (wave >> 2), d = lane >> 4;
-    return 64 * b + 4 * c + d;
-}
+// (fp_m2 / fp_tid_of themselves: caf_fft_dev.h -- the 32768-point block-spectra kernel writes this order too)
 // ... and the thread whose pass-1 butterfly is m2 (the inverse of fp_m2).  The template-spectrum rows are STORED in this
 // "butterfly order" -- element m of a row at (m & ~1023) + fp_tid_of(m & 1023), k_butterfly_order below -- so that the
 // lanes of a wave, whose butterflies are not consecutive, still read consecutive addresses (an unshifted row: 512
 // contiguous bytes per load; a row shifted by the hypothesis: a few pieces of whole quads).  In natural order the same
 // loads touched 64 separate 8-byte pieces and the launch took 18.4 instead of 15.0 ms.  The block spectrum stays in
 // natural order: it is read once per work item, not once per transform.
-__host__ __device__ __forceinline__ uint32_t fp_tid_of(uint32_t m2) {
-    const uint32_t b = m2 >> 6, c = (m2 >> 2) & 15, d = m2 & 3;
-    return (b & 3) | ((c & 3) << 2) | (d << 4) | ((b >> 2) << 6) | ((c >> 2) << 8);
-}
 // index of element (1024 a + m2 - shift) mod 16384 of a butterfly-ordered row, as hb + 1024 a (mod 16384)
 __device__ __forceinline__ uint32_t fp_hbase(uint32_t m2, int32_t shift) {
     const uint32_t t = m2 - (uint32_t)shift;

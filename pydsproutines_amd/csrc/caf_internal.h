@@ -128,6 +128,8 @@ int lds_fft_twiddles(int device, const float2** out);
 int launch_block_spectra(const float2* rx, int64_t rx_len, int64_t src0, int32_t step, int64_t nblk, float2* xb,
                          hipStream_t st, float* inv_e = nullptr, int64_t num_shifts = 0, const int32_t* gstart = nullptr,
                          const int32_t* glen = nullptr, int32_t ngroups = 0);
+// the same for the 32768-point blocks of the chained role, written parity-major and butterfly-ordered ([block][2][16384])
+int launch_block_spectra32(const float2* rx, int64_t rx_len, int64_t src0, int32_t step, int64_t nblk, float2* xb2, hipStream_t st);
 
 // what caf_zoom_czt needs from a plan (caf_plan.hip)
 struct PlanZoomView {

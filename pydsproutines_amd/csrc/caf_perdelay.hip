@@ -379,6 +379,91 @@ int launch_block_spectra(const float2* rx, int64_t rx_len, int64_t src0, int32_t
     return CAF_OK;
 }
 
+// ----------------------------------------------------------------------------------------
+// The same for the 32768-point blocks of fused_item2 (templates of 8193 ... 16384 samples), written directly in the
+// layout that role reads: [block][parity c][16384], element m of a half (= X[2 m + c]) at (m & ~1023) + fp_tid_of(m & 1023)
+// ("butterfly order", caf_fft_dev.h).  One decimation-in-frequency step in registers, then the shared 16384-point
+// transform per half:
+//     X[2 m]     = DFT_16384( x[n] + x[n + 16384] )[m]
+//     X[2 m + 1] = DFT_16384( (x[n] - x[n + 16384]) e^{-j 2 pi n / 32768} )[m]
+// Work item = (block, parity); thread tid takes the logical butterfly l = fp_m2(tid) of the transform, so that its
+// outputs m = l + 1024 q' land on positions 1024 q' + tid: 512 contiguous bytes per wave and store.  Its loads are the
+// four whole 128-byte lines per wave of fp_m2's mapping.  Replaces k_gather_blocks + batched rocFFT + k_parity_major.
+// ----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_block_spectra32(const float2* __restrict__ rx, int64_t rx_len, int64_t src0,
+                                                          int32_t step, int64_t nblk, const float2* __restrict__ tw,
+                                                          float2* __restrict__ xb2) {
+    constexpr int LOGN = 14, N = 1 << LOGN, NTR = N / 16;
+    extern __shared__ __attribute__((aligned(16))) float2 s_bs[];
+    constexpr float C32[16] = {1.0f, 0.98078528f, 0.923879533f, 0.831469612f, 0.707106781f, 0.555570233f, 0.382683432f, 0.195090322f, 0.0f, -0.195090322f, -0.382683432f, -0.555570233f, -0.707106781f, -0.831469612f, -0.923879533f, -0.98078528f};
+    constexpr float S32[16] = {0.0f, 0.195090322f, 0.382683432f, 0.555570233f, 0.707106781f, 0.831469612f, 0.923879533f, 0.98078528f, 1.0f, 0.98078528f, 0.923879533f, 0.831469612f, 0.707106781f, 0.555570233f, 0.382683432f, 0.195090322f};
+    const int l0 = (int)fp_m2(threadIdx.x);
+    float sn, cs;
+    sincospif((float)l0 * (1.0f / 16384.0f), &sn, &cs);  // e^{+j 2 pi l / 32768}
+    const float2 wl = make_float2(cs, sn);
+    for (int64_t it = blockIdx.x; it < 2 * nblk; it += gridDim.x) {
+        const int64_t b = it >> 1;
+        const int c = (int)(it & 1);
+        int lo = l0;
+        asm volatile("" : "+v"(lo));  // (as in k_block_spectra: keeps the passes' addresses out of the item loop's invariants)
+        const int64_t s0 = src0 + b * step;
+        float2 v[16];
+        if (s0 + 2 * N <= rx_len) {
+            const float2* p = rx + s0;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const float2 a = p[lo + t * NTR], h = p[N + lo + t * NTR];
+                v[t] = c ? make_float2(a.x - h.x, h.y - a.y) : make_float2(a.x + h.x, -(a.y + h.y));  // conj(a -+ h)
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int64_t i = s0 + lo + t * NTR;
+                float2 a = make_float2(0.f, 0.f), h = a;
+                if (i < rx_len) a = rx[i];
+                if (i + N < rx_len) h = rx[i + N];
+                v[t] = c ? make_float2(a.x - h.x, h.y - a.y) : make_float2(a.x + h.x, -(a.y + h.y));
+            }
+        }
+        if (c) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) v[t] = cmul(v[t], cmul(wl, make_float2(C32[t], S32[t])));  // * e^{+j 2 pi (l + 1024 t) / 32768}
+        }
+        pd_fft<LOGN>(s_bs, tw, lo, v);
+        float2* o = xb2 + b * (2 * N) + c * N + threadIdx.x;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[pd_out_index<LOGN>(0, r)] = make_float2(v[r].x, -v[r].y);
+        // (pd_fft's last pass ends with a barrier and writes nothing after it: the next item may overwrite the image)
+    }
+}
+
+int launch_block_spectra32(const float2* rx, int64_t rx_len, int64_t src0, int32_t step, int64_t nblk, float2* xb2, hipStream_t st) {
+    int dev = 0;
+    CAF_HIP_TRY(hipGetDevice(&dev));
+    const float2* tw = nullptr;
+    const int rc = lds_fft_twiddles(dev, &tw);
+    if (rc) return rc;
+    const size_t lds = (size_t)(16384 + 1024) * sizeof(float2);
+    static std::mutex mu;
+    static std::vector<char> attr_set;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if ((int)attr_set.size() <= dev) attr_set.resize(dev + 1, 0);
+        if (!attr_set[dev]) {
+            CAF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_block_spectra32),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set[dev] = 1;
+        }
+    }
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const unsigned grid = (unsigned)std::min<int64_t>(2 * nblk, std::max(cus, 1));
+    if (grid == 0) return CAF_OK;
+    hipLaunchKernelGGL(k_block_spectra32, dim3(grid), dim3(1024), lds, st, rx, rx_len, src0, step, nblk, tw, xb2);
+    CAF_HIP_TRY(hipGetLastError());
+    return CAF_OK;
+}
+
 namespace {
 
 template <int LOGN>

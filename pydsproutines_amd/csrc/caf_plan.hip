@@ -865,7 +865,13 @@ int32_t caf_plan_execute(caf_plan p, const float* d_rx, int64_t rx_len, int64_t 
         p->stage_end(se);
         if (aux) CAF_HIP_TRY(hipEventRecord(p->ev_join, p->s_aux));
     }
-    if (lds_fwd) {
+    const bool lds_fwd32 = p->fused && p->B == 32768 && !fwd_rocfft;
+    if (lds_fwd32) {
+        p->stage_begin(2, st);
+        const int rc = launch_block_spectra32(rx, rx_len, shift_start, p->step, nfwd * p->fwd_chunk, p->d_xb2, st);
+        p->stage_end(st);
+        if (rc) return rc;
+    } else if (lds_fwd) {
         p->stage_begin(2, st);
         const int rc = energy_in_fwd
                            ? launch_block_spectra(rx, rx_len, shift_start, p->step, nfwd * p->fwd_chunk, p->d_xb, st, p->d_inv_e,
@@ -884,7 +890,7 @@ int32_t caf_plan_execute(caf_plan p, const float* d_rx, int64_t rx_len, int64_t 
             if (rc) return rc;
         }
     }
-    if (p->fused && p->B == 32768)  // block spectra parity-major for the two chained half-transforms
+    if (p->fused && p->B == 32768 && !lds_fwd32)  // block spectra parity-major for the two chained half-transforms
         launch_parity_major(p->d_xb, p->d_xb2, nfwd * p->fwd_chunk, p->B / 2, st, true);
     if (aux) CAF_HIP_TRY(hipStreamWaitEvent(st, p->ev_join, 0));
     bool f1_direct = false;

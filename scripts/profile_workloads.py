@@ -148,7 +148,8 @@ def w_c2_long_template():
     flops = nblk * 256 * (2 * 5.0 * 16384 * 14 + 6.0 * B + 10.0 * 16384 + 3.0 * step)
     plan.close()
     return [("k_caf_persistent", "one-launch engine, N=16384 (B=32768 as 2 x 16384), F=256, surface", alg, flops, 2),
-            ("k_parity_major", "block spectra -> parity-major (8 B read + 8 B written per point)", nblk * B * 16.0, 0.0, 2)]
+            ("k_block_spectra32", "32768-point block spectra, parity-major + butterfly order: gather, one DIF step, two in-LDS "
+             "16384-point transforms (8 B read + 8 B written per point)", nblk * B * 16.0, nblk * (2 * 5.0 * 16384 * 14 + 10.0 * B), 2)]
 
 
 def w_c5_zoom():
