@@ -55,8 +55,7 @@ __global__ __launch_bounds__((1 << LOGN) / 16 > 256 ? (1 << LOGN) / 16 : 256, 4)
     constexpr int WPR = NTR > 64 ? NTR / 64 : 1;  // waves per row
     extern __shared__ __attribute__((aligned(16))) float2 s_buf[];  // RPW rows of N + N/16 elements
     __shared__ double s_e[2][NW];     // cross-wave partial sums / maxima of rows wider than a wave, double-buffered
-    __shared__ float s_bv[2][NW];     // over consecutive rows so that a slot is rewritten only two barriers later
-    __shared__ uint32_t s_bi[2][NW];
+    __shared__ unsigned long long s_key[2][NW];  // over consecutive rows so that a slot is rewritten only two barriers later
     const int tid = threadIdx.x;
     const int rl = tid / NTR, l = tid - rl * NTR;  // row slot of this thread, row-local id
     float2* buf = s_buf + rl * (N + N / 16);
@@ -154,59 +153,62 @@ __global__ __launch_bounds__((1 << LOGN) / 16 > 256 ? (1 << LOGN) / 16 : 256, 4)
         }
         // normalisation as the unfused path rounds it: inv = (float)(1 / (sqrt(E) * ||x||)), applied to the amplitude
         const float inv = zero ? 0.f : (float)(1.0 / (sqrt(e) * sqrt(xnorm2)));
-        float bv = -1.f;
-        uint32_t bi = 0;
-        float* prow = (plane && live) ? plane + row * N : nullptr;
-        float2* crow = (cplane && live) ? cplane + row * N : nullptr;
+        // (explicit fma: the planes and the row maximum must see the same bits whatever the compiler contracts where)
+        if (plane || cplane) {
+            float* prow = (plane && live) ? plane + row * N : nullptr;
+            float2* crow = (cplane && live) ? cplane + row * N : nullptr;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int idx = pd_out_index<LOGN>(lo, r);  // (from the opaque copy: 16 loop-invariant indices otherwise)
-            const float zr = v[r].x * inv, zi = v[r].y * inv;
-            const float val = zr * zr + zi * zi;
-            if (prow) prow[idx] = val;
-            if (crow) crow[idx] = make_float2(zr, -zi);
-            if (val > bv || (val == bv && (uint32_t)idx < bi)) {  // first index of the maximum; NaN never wins
-                bv = val;
-                bi = (uint32_t)idx;
+            for (int r = 0; r < 16; ++r) {
+                const int idx = pd_out_index<LOGN>(lo, r);  // (from the opaque copy: 16 loop-invariant indices otherwise)
+                const float zr = v[r].x * inv, zi = v[r].y * inv;
+                if (prow) prow[idx] = __builtin_fmaf(zr, zr, zi * zi);
+                if (crow) crow[idx] = make_float2(zr, -zi);
+            }
+        }
+        // First index of the row maximum; NaN never wins.  Within the thread the registers are visited in ascending
+        // index order (pd_out_index: t-major), so a strict comparison keeps the first; across lanes and waves one
+        // unsigned maximum of the key (value bits, ~index): values are >= +0, whose bit patterns order like the numbers.
+        constexpr int RLE = (LOGN % 4) ? (1 << (LOGN % 4)) : 16, NQE = 16 / RLE;
+        float bv = -1.f;
+        uint32_t br = 0;
+#pragma unroll
+        for (int t = 0; t < RLE; ++t) {
+#pragma unroll
+            for (int q = 0; q < NQE; ++q) {
+                const int r = q * RLE + t;
+                const float zr = v[r].x * inv, zi = v[r].y * inv;
+                const float val = __builtin_fmaf(zr, zr, zi * zi);
+                if (val > bv) {
+                    bv = val;
+                    br = (uint32_t)r;
+                }
             }
         }
         if (qf2 || fidx) {
+            const uint32_t bi = (uint32_t)lo + (br / RLE) * NTR + (br % RLE) * (N / RLE);  // = pd_out_index(lo, br)
+            // (a thread that saw only NaNs offers key 0: it loses against every real value, and an all-NaN row -- a
+            // zero-energy window -- reports (0, 0), the reference's zero-initialised workspace)
+            unsigned long long key = bv < 0.f ? 0ull : (((unsigned long long)__float_as_uint(bv) << 32) | (uint32_t)~bi);
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
                 if (o < NTR) {
-                    const float ov = __shfl_xor(bv, o, 64);
-                    const uint32_t oi = __shfl_xor(bi, o, 64);
-                    if (ov > bv || (ov == bv && oi < bi)) {
-                        bv = ov;
-                        bi = oi;
-                    }
+                    const unsigned long long ok = __shfl_xor(key, o, 64);
+                    key = ok > key ? ok : key;
                 }
             }
             if (WPR > 1) {
-                if (lane == 0) {
-                    s_bv[it & 1][wave] = bv;
-                    s_bi[it & 1][wave] = bi;
-                }
+                if (lane == 0) s_key[it & 1][wave] = key;
                 __syncthreads();
-                bv = -1.f;
-                bi = 0;
+                key = 0ull;
 #pragma unroll
                 for (int w = 0; w < WPR; ++w) {
-                    const float ov = s_bv[it & 1][(wave / WPR) * WPR + w];
-                    const uint32_t oi = s_bi[it & 1][(wave / WPR) * WPR + w];
-                    if (ov > bv || (ov == bv && oi < bi)) {
-                        bv = ov;
-                        bi = oi;
-                    }
+                    const unsigned long long ok = s_key[it & 1][(wave / WPR) * WPR + w];
+                    key = ok > key ? ok : key;
                 }
             }
             if (live && l == 0) {
-                if (bv < 0.f) {  // all-NaN row (zero-energy window): the reference's zero-initialised workspace
-                    bv = 0.f;
-                    bi = 0;
-                }
-                if (qf2) qf2[row] = bv;
-                if (fidx) fidx[row] = bi;
+                if (qf2) qf2[row] = key ? __uint_as_float((uint32_t)(key >> 32)) : 0.f;
+                if (fidx) fidx[row] = key ? ~(uint32_t)key : 0u;
             }
         }
         // (no barrier here: the last pass wrote nothing after its barrier, so the next row may overwrite the image)
