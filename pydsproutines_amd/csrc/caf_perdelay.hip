@@ -61,18 +61,15 @@ __global__ __launch_bounds__((1 << LOGN) / 16 > 256 ? (1 << LOGN) / 16 : 256, 4)
     float2* buf = s_buf + rl * (N + N / 16);
     const int lane = tid & 63, wave = tid >> 6;
 
-    // ||x||^2 in float64 from the thread's 16 cutout points (pass-1 positions).  The cutout stays in registers across
-    // rows where that fits (measured faster for N <= 1024 and N = 16384); for N = 2048 .. 8192 it spilled ~60 registers
-    // per thread to scratch together with the row data, twiddle powers and butterfly temporaries (28 GB of HBM
-    // traffic for 1e6 rows of N = 4096; 12.5 -> 10.9 ms without), so there it is re-read per row -- a few tens of KB
-    // shared by every workgroup, L1/L2-resident.
-    constexpr bool RESIDENT = LOGN <= 10 || LOGN == 14;
-    float2 xr[RESIDENT ? 16 : 1];
+    // ||x||^2 in float64 from the thread's 16 cutout points (pass-1 positions); the cutout stays in registers across
+    // the workgroup's rows (since the row epilogue shrank it fits at every size: 4096 x 1e6 rows 7.1 -> 6.4 ms against
+    // re-reading it per row from L1/L2; two sizes keep 28 / 40 bytes of scratch outside the row loop)
+    float2 xr[16];
     double xs = 0.0;
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
         const float2 a = x[l + t * NTR];
-        if (RESIDENT) xr[t] = a;
+        xr[t] = a;
         xs += (double)a.x * a.x + (double)a.y * a.y;
     }
     // sum over the lanes of the row slot that share this wave
@@ -93,12 +90,6 @@ __global__ __launch_bounds__((1 << LOGN) / 16 > 256 ? (1 << LOGN) / 16 : 256, 4)
     }
 
     const int64_t row0 = (int64_t)blockIdx.x * rows_per_wg * RPW;
-    // Consecutive delays, one row per workgroup and turn, every window of this workgroup's run inside rx: the window
-    // energy of row s is the previous row's minus |y[s - 1]|^2 plus |y[s + N - 1]|^2 -- two samples in float64 instead of
-    // the row's 16 per thread and the cross-lane / cross-wave float64 sums (the first row of the run is summed in full).
-    const bool e_slide = RPW == 1 && step == 1 && row0 + rows_per_wg <= num && start + row0 >= 0 &&
-                         start + row0 + rows_per_wg - 1 + N <= ylen;
-    double e_run = 0.0;
     for (int it = 0; it < rows_per_wg; ++it) {
         const int64_t row = row0 + (int64_t)it * RPW + rl;
         const bool live = row < num;  // (uniform per row slot; dead slots run the barriers with zeros)
@@ -127,32 +118,31 @@ __global__ __launch_bounds__((1 << LOGN) / 16 > 256 ? (1 << LOGN) / 16 : 256, 4)
         }
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
-            const float2 a = RESIDENT ? xr[RESIDENT ? t : 0] : pd_ld2(x, (uint32_t)(lo + t * NTR)), b = v[t];
-            if (!(e_slide && it > 0)) es += (double)b.x * b.x + (double)b.y * b.y;
+            const float2 a = xr[t], b = v[t];
+            es += (double)b.x * b.x + (double)b.y * b.y;
             // conj(x * y): the inverse butterflies then deliver conj(FFT(x * y))
             v[t] = make_float2(a.x * b.x - a.y * b.y, -(a.x * b.y + a.y * b.x));
         }
         // window energy: lanes of the wave by shuffles; across the waves of a wide row through LDS, published by the
         // barrier that ends the first pass
-        double e;
-        if (e_slide && it > 0) {
-            const float2 a = pd_ld2(yrow, (uint32_t)N - 1u), b = yrow[-1];  // (same address in every lane: one request)
-            e_run += ((double)a.x * a.x + (double)a.y * a.y) - ((double)b.x * b.x + (double)b.y * b.y);
-            e = e_run;
-            pd_fft<LOGN>(buf, tw, lo, v);
-        } else {
-            e = wave_sum(es);
-            if (WPR > 1 && lane == 0) s_e[it & 1][wave] = e;
-            pd_fft<LOGN>(buf, tw, lo, v);
-            if (WPR > 1) {
-                e = 0.0;
+        double e = wave_sum(es);
+        if (WPR > 1 && lane == 0) s_e[it & 1][wave] = e;
+        pd_fft<LOGN>(buf, tw, lo, v);
+        if (WPR > 1) {
+            e = 0.0;
 #pragma unroll
-                for (int w = 0; w < WPR; ++w) e += s_e[it & 1][(wave / WPR) * WPR + w];
-            }
-            e_run = e;
+            for (int w = 0; w < WPR; ++w) e += s_e[it & 1][(wave / WPR) * WPR + w];
         }
-        // normalisation as the unfused path rounds it: inv = (float)(1 / (sqrt(E) * ||x||)), applied to the amplitude
-        const float inv = zero ? 0.f : (float)(1.0 / (sqrt(e) * sqrt(xnorm2)));
+        // normalisation as the unfused path applies it: inv = (float)(1 / (sqrt(E) * ||x||)) on the amplitude.  Evaluated as
+        // rsq(E ||x||^2) + one Newton step (2^-45 or better before the rounding to float32) instead of a float64 square root
+        // and a float64 division per row and thread: those two were ~40 half-rate instructions of the ~1350 of a row.
+        // E = 0 (all-zero window): rsq = inf, 0 * inf = NaN -> NaN row, as before.
+        float inv = 0.f;
+        if (!zero) {
+            const double a = e * xnorm2;
+            const double y0 = __builtin_amdgcn_rsq(a);
+            inv = (float)__builtin_fma(__builtin_fma(-(a * y0), 0.5 * y0, 0.5), y0, y0);
+        }
         // (explicit fma: the planes and the row maximum must see the same bits whatever the compiler contracts where)
         if (plane || cplane) {
             float* prow = (plane && live) ? plane + row * N : nullptr;
@@ -185,6 +175,7 @@ __global__ __launch_bounds__((1 << LOGN) / 16 > 256 ? (1 << LOGN) / 16 : 256, 4)
             }
         }
         if (qf2 || fidx) {
+            asm volatile("" : "+v"(br));  // (the selects above on 0 .. 15 -- inline constants -- and ONE index computation)
             const uint32_t bi = (uint32_t)lo + (br / RLE) * NTR + (br % RLE) * (N / RLE);  // = pd_out_index(lo, br)
             // (a thread that saw only NaNs offers key 0: it loses against every real value, and an all-NaN row -- a
             // zero-energy window -- reports (0, 0), the reference's zero-initialised workspace)

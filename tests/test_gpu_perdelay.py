@@ -90,6 +90,55 @@ def test_fused_perdelay_strides_and_out_of_range_rules():
     assert np.all(q == 0) and np.all(fi == 0) and np.all(np.isnan(pl))
 
 
+def test_4096_rules_and_long_runs():
+    """N = 4096 (one row per workgroup and turn): odd row counts, strides, the out-of-range rule at both ends, an all-zero
+    window, and a run long enough for several rows per workgroup (rows_per_wg = 4)."""
+    n = 4096
+    rng = np.random.default_rng(17)
+    rx = cn(rng, 30000)
+    cut = cn(rng, n)
+    tol = 2e-5
+
+    def check(q, fi, sh, zero_rule=False):
+        inside = (sh >= 0) & (sh + n <= rx.size)
+        if zero_rule:
+            assert np.all(q[~inside] == 0) and np.all(fi[~inside] == 0)
+            q, fi, sh = q[inside], fi[inside], sh[inside]
+        rq, rf = O.fastXcorr(cut, rx, freqsearch=True, shifts=sh)
+        assert np.max(np.abs(q - rq)) <= tol
+        diff = np.nonzero(fi != rf)[0]
+        if diff.size:  # float32 ties only (DESIGN 5)
+            rows = O.fastXcorr(cut, rx, freqsearch=True, outputCAF=True, shifts=sh[diff])
+            assert np.all(rows[np.arange(diff.size), fi[diff]] >= rows.max(axis=1) - 2 * tol)
+
+    for start, step, num in ((3, 1, 301), (11, 3, 77), (25000, -7, 501), (0, 1, 17001)):
+        q, fi, _, _ = _perdelay(cut.conj(), rx, start, step, num)
+        check(q, fi, start + step * np.arange(num))
+    # planes of an odd run: the row results are the planes' own maxima, bit for bit
+    q, fi, pl, cp = _perdelay(cut.conj(), rx, 100, 1, 33, caf=True, ccaf=True)
+    np.testing.assert_array_equal(q, pl.max(axis=1))
+    np.testing.assert_array_equal(fi, np.argmax(pl, axis=1))
+    ref = O.fastXcorr(cut, rx, freqsearch=True, outputCAF=True, shifts=np.arange(100, 133), absResult=False)
+    assert np.max(np.abs(cp - ref)) <= 1e-4 * max(1.0, np.abs(ref).max())
+    # CyIppXcorrFFT rule: zero rows outside rx (IppXcorrFFT.cpp:125-130), at both ends
+    sh = np.arange(-20, -20 + 151)
+    q, fi, _, _ = _perdelay(cut.conj(), rx, -20, 1, 151, zero_oor=True)
+    check(q, fi, sh, zero_rule=True)
+    sh = np.arange(rx.size - n - 30, rx.size - n + 31)
+    q, fi, _, _ = _perdelay(cut.conj(), rx, int(sh[0]), 1, sh.size, zero_oor=True)
+    check(q, fi, sh, zero_rule=True)
+    with pytest.raises(ValueError):  # without the rule such a run is refused (include/caf.h)
+        _perdelay(cut.conj(), rx, rx.size - n - 3, 1, 8)
+    # an all-zero window inside a sliding run: NaN plane, (0, 0) row results, and the rows after it are right again
+    rz = rx.copy()
+    rz[9000 : 9000 + n + 5] = 0
+    q, fi, pl, _ = _perdelay(cut.conj(), rz, 8990, 1, 40, caf=True)
+    dead = (np.arange(8990, 9030) >= 9000) & (np.arange(8990, 9030) <= 9005)
+    assert np.all(q[dead] == 0) and np.all(fi[dead] == 0) and np.all(np.isnan(pl[dead]))
+    rq, _ = O.fastXcorr(cut, rz, freqsearch=True, shifts=np.arange(8990, 9030)[~dead])
+    assert np.max(np.abs(q[~dead] - rq)) <= tol
+
+
 def test_fused_equals_three_kernel_form():
     """The same calls through the path it replaces (rocFFT rows), in a child process because the switch is read once."""
     code = r"""
