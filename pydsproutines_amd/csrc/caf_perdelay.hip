@@ -379,7 +379,7 @@ int launch_block_spectra(const float2* rx, int64_t rx_len, int64_t src0, int32_t
 // transform per half:
 //     X[2 m]     = DFT_16384( x[n] + x[n + 16384] )[m]
 //     X[2 m + 1] = DFT_16384( (x[n] - x[n + 16384]) e^{-j 2 pi n / 32768} )[m]
-// Work item = (block, parity); thread tid takes the logical butterfly l = fp_m2(tid) of the transform, so that its
+// One block per turn, both parities from one read of its samples; thread tid takes the logical butterfly l = fp_m2(tid), so that its
 // outputs m = l + 1024 q' land on positions 1024 q' + tid: 512 contiguous bytes per wave and store.  Its loads are the
 // four whole 128-byte lines per wave of fp_m2's mapping.  Replaces k_gather_blocks + batched rocFFT + k_parity_major.
 // ----------------------------------------------------------------------------------------
@@ -394,19 +394,18 @@ __global__ __launch_bounds__(1024) void k_block_spectra32(const float2* __restri
     float sn, cs;
     sincospif((float)l0 * (1.0f / 16384.0f), &sn, &cs);  // e^{+j 2 pi l / 32768}
     const float2 wl = make_float2(cs, sn);
-    for (int64_t it = blockIdx.x; it < 2 * nblk; it += gridDim.x) {
-        const int64_t b = it >> 1;
-        const int c = (int)(it & 1);
+    for (int64_t b = blockIdx.x; b < nblk; b += gridDim.x) {
         int lo = l0;
-        asm volatile("" : "+v"(lo));  // (as in k_block_spectra: keeps the passes' addresses out of the item loop's invariants)
+        asm volatile("" : "+v"(lo));  // (as in k_block_spectra: keeps the passes' addresses out of the block loop's invariants)
         const int64_t s0 = src0 + b * step;
-        float2 v[16];
+        float2 v[16], d[16];  // conj(x_lo + x_hi), conj(x_lo - x_hi): the block is read once for both parities
         if (s0 + 2 * N <= rx_len) {
             const float2* p = rx + s0;
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
                 const float2 a = p[lo + t * NTR], h = p[N + lo + t * NTR];
-                v[t] = c ? make_float2(a.x - h.x, h.y - a.y) : make_float2(a.x + h.x, -(a.y + h.y));  // conj(a -+ h)
+                v[t] = make_float2(a.x + h.x, -(a.y + h.y));
+                d[t] = make_float2(a.x - h.x, h.y - a.y);
             }
         } else {
 #pragma unroll
@@ -415,18 +414,22 @@ __global__ __launch_bounds__(1024) void k_block_spectra32(const float2* __restri
                 float2 a = make_float2(0.f, 0.f), h = a;
                 if (i < rx_len) a = rx[i];
                 if (i + N < rx_len) h = rx[i + N];
-                v[t] = c ? make_float2(a.x - h.x, h.y - a.y) : make_float2(a.x + h.x, -(a.y + h.y));
+                v[t] = make_float2(a.x + h.x, -(a.y + h.y));
+                d[t] = make_float2(a.x - h.x, h.y - a.y);
             }
         }
-        if (c) {
 #pragma unroll
-            for (int t = 0; t < 16; ++t) v[t] = cmul(v[t], cmul(wl, make_float2(C32[t], S32[t])));  // * e^{+j 2 pi (l + 1024 t) / 32768}
+        for (int c = 0; c < 2; ++c) {
+            if (c) {
+#pragma unroll
+                for (int t = 0; t < 16; ++t) v[t] = cmul(d[t], cmul(wl, make_float2(C32[t], S32[t])));  // * e^{+j 2 pi (l + 1024 t) / 32768}
+            }
+            pd_fft<LOGN>(s_bs, tw, lo, v);
+            float2* o = xb2 + b * (2 * N) + c * N + threadIdx.x;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[pd_out_index<LOGN>(0, r)] = make_float2(v[r].x, -v[r].y);
+            // (pd_fft's last pass ends with a barrier and writes nothing after it: the next transform may overwrite the image)
         }
-        pd_fft<LOGN>(s_bs, tw, lo, v);
-        float2* o = xb2 + b * (2 * N) + c * N + threadIdx.x;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[pd_out_index<LOGN>(0, r)] = make_float2(v[r].x, -v[r].y);
-        // (pd_fft's last pass ends with a barrier and writes nothing after it: the next item may overwrite the image)
     }
 }
 
@@ -450,7 +453,7 @@ int launch_block_spectra32(const float2* rx, int64_t rx_len, int64_t src0, int32
     }
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const unsigned grid = (unsigned)std::min<int64_t>(2 * nblk, std::max(cus, 1));
+    const unsigned grid = (unsigned)std::min<int64_t>(nblk, std::max(cus, 1));
     if (grid == 0) return CAF_OK;
     hipLaunchKernelGGL(k_block_spectra32, dim3(grid), dim3(1024), lds, st, rx, rx_len, src0, step, nblk, tw, xb2);
     CAF_HIP_TRY(hipGetLastError());
