@@ -5,6 +5,7 @@
 //   C0  the shipped structure: 1024 threads x 16 points, 16.16.16.4, complex ds_write_b64 exchange, 3 barriers
 //   C0v C0 with unmerged LDS reads (volatile: ds_read_b64 instead of ds_read2_b64 / ds_read2st64_b64)
 //   C1  C0 with planar exchanges: ds_write_addtid_b32 rows + ds_read_b128
+//   C1w C1 with the first exchange wave-local as well (two workgroup barriers per transform instead of three)
 //   A1  512 threads x 32 points (256 VGPRs), 32.32.16, complex exchange, 3 barriers (second pass in place)
 //   A2  A1 with planar addtid exchanges (4 barriers)
 //   B2  two co-resident 512-thread workgroups (128 VGPRs), 32.32.16, block spectrum streamed, planar exchange one plane
@@ -122,7 +123,7 @@ struct Args {
 };
 
 // ------------------------------------------------------------------ C0 / C1: 1024 threads x 16 points
-template <bool PLANAR, bool VOL>
+template <bool PLANAR, bool VOL, bool WAVE1 = false>
 __global__ __launch_bounds__(1024) void k_c0(Args a) {
     __shared__ __attribute__((aligned(16))) float2 s_d[16 * 1090];
     __shared__ float2 s_tw[16 * 64];
@@ -157,7 +158,12 @@ __global__ __launch_bounds__(1024) void k_c0(Args a) {
         } else {
             wr_c64<16>(s_d, 1090, wave * 68 + lane, v);
         }
-        __syncthreads();
+        // WAVE1: the first exchange wave-local too (16384 = 1024 per wave x 16 across waves: passes 1-3 and both of their
+        // exchanges inside one barrier-free stretch, the only workgroup-wide exchange in front of the last pass)
+        if (WAVE1)
+            __builtin_amdgcn_wave_barrier();
+        else
+            __syncthreads();
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
             float cf[30];
@@ -412,6 +418,7 @@ int main(int argc, char** argv) {
         if (run("C0", k_c0<false, false>, 1024, 1, 1.0, a, reps)) return 1;
         if (run("C0v", k_c0<false, true>, 1024, 1, 1.0, a, reps)) return 1;
         if (run("C1", k_c0<true, false>, 1024, 1, 1.0, a, reps)) return 1;
+        if (run("C1w", k_c0<true, false, true>, 1024, 1, 1.0, a, reps)) return 1;
         if (run("A1", k_a<false>, 512, 1, 1.0, a, reps)) return 1;
         if (run("A2", k_a<true>, 512, 1, 1.0, a, reps)) return 1;
         if (run("B2", k_b2, 512, 2, 1.0, a, reps)) return 1;
