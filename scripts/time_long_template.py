@@ -27,5 +27,15 @@ for n in (4096, 8192, 8193, 16384, 16385):
         _lib.check(_lib.load().caf_stream_sync(None))
         dt = (time.perf_counter() - t0) / 3
         print("N=%6d engine=%-10s block=%6d  %8.2f ms per pass  %7.1f Mdelays/s" % (n, plan.engine_used, plan.block, dt * 1e3, (M - n + 1) / dt / 1e6), flush=True)
+        # the same plan without the surface: per-delay maxima + the peak only
+        res2 = plan.run(d_rx, surface=False, rows=True, peak=True)
+        _lib.check(_lib.load().caf_stream_sync(None))
+        t0 = time.perf_counter()
+        for _ in range(3):
+            res2 = plan.run(d_rx, surface=False, rows=True, peak=True, out=res2)
+        _lib.check(_lib.load().caf_stream_sync(None))
+        dt = (time.perf_counter() - t0) / 3
+        print("N=%6d engine=%-10s block=%6d  %8.2f ms per pass without the surface (per-delay maxima + peak)" % (n, plan.engine_used, plan.block, dt * 1e3), flush=True)
+        del res2
         plan.close()
         del res
