@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void k_direct_caf(const float2* __restrict__ r
                 e1 += (double)x1[u].x * (double)x1[u].x + (double)x1[u].y * (double)x1[u].y;
             }
     }
-    const float inv0 = (float)(1.0 / e0), inv1 = (float)(1.0 / e1);
+    const float inv0 = e0 > 0.0 ? (float)(1.0 / e0) : __builtin_nanf(""), inv1 = e1 > 0.0 ? (float)(1.0 / e1) : __builtin_nanf("");
     for (int t = 0; t < ntmpl; ++t) {
         const float ts = tscale[t];
         const float g0 = inv0 * ts, g1 = inv1 * ts;  // the engines' rounding: value * (1/energy * 1/||t||^2)
@@ -137,9 +137,9 @@ __global__ __launch_bounds__(256) void k_direct_caf(const float2* __restrict__ r
             if (ov > bv1 || (ov == bv1 && oi < bi1)) bv1 = ov, bi1 = oi;
         }
         if (cg == 0) {
-            if (live0 && row_max) row_max[(int64_t)t * num_shifts + i0] = bv0;
+            if (live0 && row_max) row_max[(int64_t)t * num_shifts + i0] = bv0 < 0.f ? __builtin_nanf("") : bv0;  // (zero-energy window)
             if (live0 && row_arg) row_arg[(int64_t)t * num_shifts + i0] = bi0;
-            if (live1 && row_max) row_max[(int64_t)t * num_shifts + i1] = bv1;
+            if (live1 && row_max) row_max[(int64_t)t * num_shifts + i1] = bv1 < 0.f ? __builtin_nanf("") : bv1;
             if (live1 && row_arg) row_arg[(int64_t)t * num_shifts + i1] = bi1;
         }
         if (partial) {

@@ -237,9 +237,13 @@ struct F1Direct {
     const float* tscale;  // [T]
     int64_t num_shifts;
     int32_t step, blk_abs;
+    // PK: one peak record per (template, block, wave) from the finished values themselves (no pass over the rows)
+    PeakRec* partial;      // [T][ppt]; this item's records at [h][16 blk_abs + wave]
+    int64_t ppt, shift_start;
 };
 // NV4: output quarters n4 < NV4 of the last (radix-4) pass are computed -- the others hold no valid delay (tiles >= 64 NV4)
-template <int FT, int MODE = 0, int NV4 = 4>
+// PK (MODE 3): the item also leaves the peak of every row segment it writes -- value and first delay of the maximum
+template <int FT, int MODE = 0, int NV4 = 4, bool PK = false>
 __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float2* __restrict__ s_tw2,
                                            const float2* __restrict__ s_tw3,
                                            const float2* __restrict__ xb,       // [blocks][FB] spectra
@@ -293,6 +297,13 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
         }
     }
 
+    // PK: this thread's part of the block-local delay index of its outputs (the rest is 64 (16 i + 64 n4)), valid extent
+    uint32_t pk_d0 = 0, pk_nv = 0;
+    if (PK) {
+        const int n1 = tid & 15, n2 = (tid >> 4) & 15, q = tid >> 8;
+        pk_d0 = (uint32_t)(((n2 >> 2) + 4 * q) * 64 + n1 + 16 * (n2 & 3));
+        pk_nv = f1_bytes >> 2;
+    }
     // hypothesis-independent per-thread state: the pass-1 twiddle base e^{+j 2 pi m2 / 16384}
     float2 w[BPT];
     const float2* xp = xb + (int64_t)blk * FB;  // uniform base; per-thread offsets stay 32-bit (saddr loads)
@@ -344,10 +355,12 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
         float f1_ts = 0.f;
         if (MODE == 3) {
             f1_ts = *((const CAF_AS1 float*)f1->tscale + h);
-            f1_r0 = buf_of(uniform_ptr(f1->out0 + (int64_t)h * f1->num_shifts + f1_rel0), f1_bytes);  // past the block's
+            f1_r0 = buf_of(uniform_ptr(f1->out0 + (int64_t)h * f1->num_shifts + f1_rel0), f1->out0 ? f1_bytes : 0u);  // past the block's
             if (f1->out1)                                                                            // delays: dropped
                 f1_r1 = buf_of(uniform_ptr(f1->out1 + (int64_t)h * f1->num_shifts + f1_rel0), f1_bytes);
         }
+        float pk_v[4] = {-1.f, -1.f, -1.f, -1.f};
+        uint32_t pk_i[4] = {0u, 0u, 0u, 0u};
         if (MODE == 4) {
             f1_ts = __builtin_sqrtf(*((const CAF_AS1 float*)f1->tscale + h / nfreq));
             f1_r0 = buf_of(uniform_ptr(f1->out0 + 2 * ((int64_t)h * f1->num_shifts + f1_rel0)), 2u * f1_bytes);
@@ -487,6 +500,13 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
                     } else if (MODE == 3) {
                         // the finished per-delay value, rounded as the tile roles round it: value * (1/energy * 1/||t||^2)
                         const float outv = val * (bv[4 * i + n4] * f1_ts);
+                        if (PK) {
+                            // delays of one output quarter n4 are visited in increasing order (i): a strict comparison keeps
+                            // the first maximum; NaN (zero-energy window) and delays past the block's valid extent never enter
+                            const bool up = ((uint32_t)(pk_d0 + (16 * i + 64 * n4) * 64) < pk_nv) & (outv > pk_v[n4]);
+                            pk_v[n4] = up ? outv : pk_v[n4];
+                            pk_i[n4] = up ? (uint32_t)i : pk_i[n4];
+                        }
                         const uint32_t v3 = (uint32_t)(tile_t * 64 + n1 + 16 * (n2 & 3)) << 2, s3 = (uint32_t)tile_u * 256u;
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, outv), f1_r0, (int)v3, (int)s3, CAF_AUX_NT);
                         if (f1->out1)
@@ -502,6 +522,33 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
                 for (int a = 0; a < 16; ++a) pr[j][a] = cmul(xr[j][a], hn[j][a]);
             }
             __builtin_amdgcn_sched_barrier(0);
+        }
+        if (PK) {
+            // quarters in increasing delay order (strict: the lower quarter keeps a tie), then one unsigned maximum of
+            // (value bits, ~delay) over the wave: values are >= +0, whose bit patterns order like the numbers
+            float bvv = pk_v[0];
+            uint32_t bq = 0, bii = pk_i[0];
+#pragma unroll
+            for (int n4 = 1; n4 < NV4; ++n4) {
+                const bool up = pk_v[n4] > bvv;
+                bvv = up ? pk_v[n4] : bvv;
+                bq = up ? (uint32_t)n4 : bq;
+                bii = up ? pk_i[n4] : bii;
+            }
+            const uint32_t dloc = pk_d0 + (16u * bii + 64u * bq) * 64u;
+            unsigned long long key = bvv < 0.f ? 0ull : (((unsigned long long)__float_as_uint(bvv) << 32) | (uint32_t)~dloc);
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned long long ok = __shfl_xor(key, o, 64);
+                key = ok > key ? ok : key;
+            }
+            if ((tid & 63) == 0) {
+                PeakRec r;
+                r.v = key ? __uint_as_float((uint32_t)(key >> 32)) : -1.f;
+                r.delay = key ? (int32_t)(f1->shift_start + f1_rel0 + (int64_t)(uint32_t)~(uint32_t)key) : 0x7fffffff;
+                r.f = 0;
+                f1->partial[(int64_t)h * f1->ppt + (int64_t)f1->blk_abs * 16 + (tid >> 6)] = r;
+            }
         }
     }
     if (MODE == 2) {
@@ -893,7 +940,7 @@ __global__ __launch_bounds__(256) void k_transpose_norm_argmax(
         if (lane < nrows) {
             v = s_rowv[lane];
             const int64_t o = (int64_t)t * num_shifts + rel0 + lane;
-            if (row_max) row_max[o] = v;
+            if (row_max) row_max[o] = v < 0.f ? __builtin_nanf("") : v;  // (nothing beat the initial value: a zero-energy window, all NaN)
             if (row_arg) row_arg[o] = s_rowi[lane];
         }
         if (partial) {
@@ -1122,7 +1169,7 @@ __device__ __forceinline__ void transpose_wave(float* __restrict__ lds, const Pe
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if (s4 + k < nrows) {
-                    if (row_max) row_max[o + k] = bv[k];
+                    if (row_max) row_max[o + k] = bv[k] < 0.f ? __builtin_nanf("") : bv[k];  // (zero-energy window: all NaN, as the reference's 0 / 0)
                     if (row_arg) row_arg[o + k] = bi[k];
                     if (bv[k] > best) {  // increasing delay: first maximum wins
                         best = bv[k];
@@ -1317,8 +1364,10 @@ __device__ __attribute__((noinline)) void reduce_wave_nosurf(const PersistParams
         if (live) {
             const int64_t o = (int64_t)t * num_shifts + rel0 + lane;
             const float xv = bv < 0.f ? -1.f : x;  // (no hypothesis beat the initial value: all NaN)
-            if (row_max) row_max[o] = xv;
-            if (row_arg) row_arg[o] = bv < 0.f ? 0 : f;
+            // zero-energy window (the factor is NaN) or all-NaN inputs: NaN and hypothesis 0, as every other engine reports it
+            const bool dead = bv < 0.f || x != x;
+            if (row_max) row_max[o] = dead ? __builtin_nanf("") : x;
+            if (row_arg) row_arg[o] = dead ? 0 : f;
             if (xv > best) {
                 best = xv;
                 bdel = lane;
@@ -1451,6 +1500,9 @@ __device__ __attribute__((noinline)) void persistent_fft_item(lds_float2* s_d, c
         F1Direct f1;
         f1.out0 = P->cqf;
         f1.out1 = nullptr;
+        f1.partial = nullptr;
+        f1.ppt = 0;
+        f1.shift_start = 0;
         f1.inv_e = P->inv_e;
         f1.tscale = P->tscale;
         f1.num_shifts = P->num_shifts;
@@ -1458,17 +1510,20 @@ __device__ __attribute__((noinline)) void persistent_fft_item(lds_float2* s_d, c
         f1.blk_abs = P->blk0 + blk;
         fused_item<1024, 4, NV4>((float2*)s_d, (const float2*)s_tw2, (const float2*)s_tw3, P->xb, P->hc, P->shifts, P->tw1,
                                  P->table_mode, P->nfreq, nhyp, blk, h0, h1, P->tiles_per_blk, nullptr, nullptr, &f1);
-    } else if (KIND == 2) {
+    } else if (KIND == 2 || KIND == 4) {
         F1Direct f1;
-        f1.out0 = P->row_max ? P->row_max : P->surface;
+        f1.out0 = P->row_max ? P->row_max : P->surface;  // (neither: peak records only -- the row stores are dropped)
         f1.out1 = (P->row_max && P->surface) ? P->surface : nullptr;
         f1.inv_e = P->inv_e;
         f1.tscale = P->tscale;
         f1.num_shifts = P->num_shifts;
         f1.step = P->step;
         f1.blk_abs = P->blk0 + blk;
-        fused_item<1024, 3, NV4>((float2*)s_d, (const float2*)s_tw2, (const float2*)s_tw3, P->xb, P->hc, P->shifts, P->tw1,
-                            P->table_mode, P->nfreq, nhyp, blk, h0, h1, P->tiles_per_blk, nullptr, nullptr, &f1);
+        f1.partial = P->partial;
+        f1.ppt = P->partial_per_tmpl;
+        f1.shift_start = P->shift_start;
+        fused_item<1024, 3, NV4, KIND == 4>((float2*)s_d, (const float2*)s_tw2, (const float2*)s_tw3, P->xb, P->hc, P->shifts, P->tw1,
+                                            P->table_mode, P->nfreq, nhyp, blk, h0, h1, P->tiles_per_blk, nullptr, nullptr, &f1);
     } else if (KIND == 1) {
         // no surface wanted: one (maximum, hypothesis) pair per delay and item instead of the |y|^2 tiles
         const int64_t o = ((int64_t)blk * ngroups + grp) * P->tiles_per_blk * 64;
@@ -1644,16 +1699,16 @@ __global__ __launch_bounds__(1024) void k_caf_persistent(const PersistParams* __
             else {
                 // (kind of output) x (valid quarters of the block: tiles <= 128 / 192 / 256) -> one out-of-line role each
                 const int kind3 = params_of(pp)->cqf ? 3
-                                  : __builtin_amdgcn_readfirstlane(params_of(pp)->f1_direct) ? 2
+                                  : __builtin_amdgcn_readfirstlane(params_of(pp)->f1_direct) ? (params_of(pp)->partial ? 4 : 2)
                                   : __builtin_amdgcn_readfirstlane(params_of(pp)->nosurf) ? 1 : 0;
                 const int tpb = __builtin_amdgcn_readfirstlane(params_of(pp)->tiles_per_blk);
 #define CAF_FFT_ROLE(K, Q) persistent_fft_item<K, Q>((lds_float2*)s_d, (const lds_float2*)s_tw2, (const lds_float2*)s_tw3, pp, item)
                 if (tpb <= 128) {
-                    if (kind3 == 3) CAF_FFT_ROLE(3, 2); else if (kind3 == 2) CAF_FFT_ROLE(2, 2); else if (kind3 == 1) CAF_FFT_ROLE(1, 2); else CAF_FFT_ROLE(0, 2);
+                    if (kind3 == 4) CAF_FFT_ROLE(4, 2); else if (kind3 == 3) CAF_FFT_ROLE(3, 2); else if (kind3 == 2) CAF_FFT_ROLE(2, 2); else if (kind3 == 1) CAF_FFT_ROLE(1, 2); else CAF_FFT_ROLE(0, 2);
                 } else if (tpb <= 192) {
-                    if (kind3 == 3) CAF_FFT_ROLE(3, 3); else if (kind3 == 2) CAF_FFT_ROLE(2, 3); else if (kind3 == 1) CAF_FFT_ROLE(1, 3); else CAF_FFT_ROLE(0, 3);
+                    if (kind3 == 4) CAF_FFT_ROLE(4, 3); else if (kind3 == 3) CAF_FFT_ROLE(3, 3); else if (kind3 == 2) CAF_FFT_ROLE(2, 3); else if (kind3 == 1) CAF_FFT_ROLE(1, 3); else CAF_FFT_ROLE(0, 3);
                 } else {
-                    if (kind3 == 3) CAF_FFT_ROLE(3, 4); else if (kind3 == 2) CAF_FFT_ROLE(2, 4); else if (kind3 == 1) CAF_FFT_ROLE(1, 4); else CAF_FFT_ROLE(0, 4);
+                    if (kind3 == 4) CAF_FFT_ROLE(4, 4); else if (kind3 == 3) CAF_FFT_ROLE(3, 4); else if (kind3 == 2) CAF_FFT_ROLE(2, 4); else if (kind3 == 1) CAF_FFT_ROLE(1, 4); else CAF_FFT_ROLE(0, 4);
                 }
 #undef CAF_FFT_ROLE
             }

@@ -14,6 +14,10 @@ constexpr int MAG_THREADS = 256;  // |.|^2/normalise/argmax: 4 waves
 constexpr int MAG_S = 64;         // delays per tile (one wave-row of 8-byte loads = 512 B)
 constexpr int MAG_F = 128;        // frequency hypotheses per LDS chunk (512 B store rows)
 
+// window energies below this fraction of the float64 prefix they are differences of are reported as zero-energy windows
+// (NaN results): k_inv_energy, k_block_spectra
+constexpr double CAF_ENERGY_FLOOR = 9.094947017729282e-13;  // 2^-40
+
 struct PeakRec {
     float v;
     int32_t delay;

@@ -124,12 +124,18 @@ __global__ __launch_bounds__(256) void k_inv_energy(const double* __restrict__ p
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= num_shifts) return;
     const int64_t s = shift_start + i;
-    double e = 0.0;
+    double e = 0.0, ptop = 0.0;
     for (int g = 0; g < ngroups; ++g) {
         const int64_t a = s + gstart[g];
-        e += prefix[a + glen[g]] - prefix[a];
+        const double pb = prefix[a + glen[g]];
+        e += pb - prefix[a];
+        ptop = pb > ptop ? pb : ptop;
     }
-    inv_e[i] = (float)(1.0 / e);
+    // A window of zeros (a gap in a recording) is the reference's 0 / 0 = NaN.  Here the energy is a difference of float64
+    // prefix values from a parallel scan -- 0 up to a few units in the last place of the prefix, not exactly 0 -- and the
+    // in-LDS engines multiply |y|^2, which is FFT rounding noise there, by this factor: 1 / (almost 0) would make that noise the
+    // row's maximum.  Anything below the resolution of the prefix it was taken from (2^-40 of it) is reported as NaN.
+    inv_e[i] = e > CAF_ENERGY_FLOOR * ptop ? (float)(1.0 / e) : __builtin_nanf("");
 }
 
 // ----------------------------------------------------------------------------------------
@@ -357,7 +363,7 @@ __global__ __launch_bounds__(MAG_THREADS) void k_magsq_norm_argmax(
             v = s_rowv[lane];
             fi = s_rowi[lane];
             const int64_t o = (int64_t)t * num_shifts + rel0 + lane;
-            if (row_max) row_max[o] = v;
+            if (row_max) row_max[o] = v < 0.f ? __builtin_nanf("") : v;  // (nothing beat the initial value: a zero-energy window, all NaN)
             if (row_arg) row_arg[o] = fi;
         }
         if (partial) {

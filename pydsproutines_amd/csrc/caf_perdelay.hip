@@ -322,12 +322,15 @@ __global__ __launch_bounds__(1024) void k_block_spectra(const float2* __restrict
             for (int k = lo; k < step; k += 1024) {
                 const int64_t i = i0 + k;
                 if (i < num_shifts) {
-                    double e = 0.0;
+                    double e = 0.0, ptop = 0.0;
                     for (int g = 0; g < ngroups; ++g) {
                         const int a = k + gstart[g];
-                        e += P(a + glen[g]) - P(a);
+                        const double pb = P(a + glen[g]);
+                        e += pb - P(a);
+                        ptop = pb > ptop ? pb : ptop;
                     }
-                    inv_e[i] = (float)(1.0 / e);
+                    // (a window of zeros, or one below the resolution of the block's prefix: NaN -- see k_inv_energy)
+                    inv_e[i] = e > CAF_ENERGY_FLOOR * ptop ? (float)(1.0 / e) : __builtin_nanf("");
                 }
             }
             __syncthreads();  // the image is overwritten by the transform's first pass

@@ -893,7 +893,7 @@ int32_t caf_plan_execute(caf_plan p, const float* d_rx, int64_t rx_len, int64_t 
     if (p->fused && p->B == 32768 && !lds_fwd32)  // block spectra parity-major for the two chained half-transforms
         launch_parity_major(p->d_xb, p->d_xb2, nfwd * p->fwd_chunk, p->B / 2, st, true);
     if (aux) CAF_HIP_TRY(hipStreamWaitEvent(st, p->ev_join, 0));
-    bool f1_direct = false;
+    bool f1_direct = false, f1_item_peaks = false;
     if (p->fused) {
         // complex QF rows: written by the FFT items of the one-launch engine themselves (fused_item MODE 4), as the only
         // output of the call
@@ -925,7 +925,14 @@ int32_t caf_plan_execute(caf_plan p, const float* d_rx, int64_t rx_len, int64_t 
             const char* e = getenv("CAF_PERSIST_F1DIRECT");  // A/B switch, default on
             return !e || atoi(e);
         }();
-        f1_direct = p->persistent && p->B == 16384 && F == 1 && f1_env && !cqf_rows && (out->d_row_max || out->d_surface);
+        // (CAF_F1_ITEM_PEAKS=0: the peak records from a pass over the finished rows instead of from the items -- A/B switch)
+        static const bool f1_pk_env = [] {
+            const char* e = getenv("CAF_F1_ITEM_PEAKS");
+            return !e || atoi(e);
+        }();
+        f1_direct = p->persistent && p->B == 16384 && F == 1 && f1_env && !cqf_rows &&
+                    (out->d_row_max || out->d_surface || (want_peak && f1_pk_env));
+        f1_item_peaks = f1_direct && want_peak && f1_pk_env;
         const int nb_launch = ns_gpt ? p->nb_nosurf : p->nb;  // blocks per launch
         for (int64_t b0 = 0; p->persistent && b0 < nblk; b0 += nb_launch) {
             const int32_t nbk = (int32_t)std::min<int64_t>(nb_launch, nblk - b0);
@@ -954,7 +961,7 @@ int32_t caf_plan_execute(caf_plan p, const float* d_rx, int64_t rx_len, int64_t 
             h.surface = out->d_surface;
             h.row_max = out->d_row_max;
             h.row_arg = out->d_row_arg;
-            h.partial = want_peak ? p->d_partial : nullptr;
+            h.partial = want_peak ? p->d_partial : nullptr;  // (f1_direct: set only if the items write the records)
             h.partial_per_tmpl = p->partial_per_tmpl;
             h.pq = p->d_pq;
             h.tr_slots = p->tr_slots;
@@ -973,6 +980,7 @@ int32_t caf_plan_execute(caf_plan p, const float* d_rx, int64_t rx_len, int64_t 
             if (f1_direct) {
                 h.f1_direct = 1;
                 h.n_tr = 0;
+                if (!f1_item_peaks) h.partial = nullptr;
             }
             if (cqf_rows) {
                 h.cqf = out->d_cqf;
@@ -1103,7 +1111,9 @@ int32_t caf_plan_execute(caf_plan p, const float* d_rx, int64_t rx_len, int64_t 
     if (want_peak) {
         p->stage_begin(6, st);
         int64_t nrec = (p->fused ? nblk : nblk_pad) * p->tiles_per_blk;  // only the records of the blocks touched by this call
-        if (f1_direct) {
+        if (f1_direct && f1_item_peaks) {
+            nrec = nblk * 16;  // one record per (template, block, wave), written by the FFT items (fused_item PK)
+        } else if (f1_direct) {
             launch_rows_peak(out->d_row_max ? out->d_row_max : out->d_surface, T, num_shifts, shift_start, p->d_partial,
                              p->partial_per_tmpl, st);
             nrec = rows_peak_chunks(num_shifts);

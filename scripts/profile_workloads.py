@@ -9,6 +9,7 @@ benchmark shapes) and declares, per kernel, the ALGORITHMIC bytes (SURVEY 8d's p
 processes) and/or flops of one launch; scripts/summarize_kernels.py divides them by the traced durations.
 `list` prints the workload names."""
 import json
+import os
 import sys
 
 import numpy as np
@@ -71,7 +72,8 @@ def caf(engine, surface, T=1, F=256, reps=2, rows=True):
         Bc = plan.block
         man.append(("k_spectral_mul", "X * conj(H_h) for all hypotheses (8(1+2/F) B per point)", nblk * 8.0 * Bc * (T * F + 2), 0.0, reps))
         man.append(("k_magsq_norm_argmax", "|.|^2 + normalise + argmax (8 B read + 4 B write per cell)", cells * (8.0 + (4.0 if surface else 0.0)) + T * S * 12.0, 0.0, reps))
-    if plan.engine_used == "persistent" and F == 1 and not surface:
+    if plan.engine_used == "persistent" and F == 1 and not surface and os.environ.get("CAF_F1_ITEM_PEAKS") == "0":
+        # (default: the FFT items leave the peak records themselves and this pass over the rows does not run)
         man.append(("k_rows_peak", "peak records from the finished rows (4 B read per template and delay)", T * S * 4.0, 0.0, reps))
     if plan.engine_used in ("persistent", "fused") and B == 16384:
         # gather + in-LDS forward transform + sliding energies in one launch: rx samples read once per block, spectra

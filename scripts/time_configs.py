@@ -23,6 +23,7 @@ def sync():
 
 
 cases = [("C3 64 templates x 1 bin, rows+peak", dict(bins=[0]), dict(rows=True, peak=True)),
+         ("C3 64 templates x 1 bin, peak only", dict(bins=[0]), dict(rows=False, peak=True)),
          ("C4/GPU 64 templates x 512 bins, peak only", dict(bins=np.arange(-256, 256)), dict(rows=False, peak=True))]
 for name, pk, rk in cases:
     for engine in [a for a in sys.argv[1:] if a != "tcc"] or ["persistent", "fused", "rocfft"]:

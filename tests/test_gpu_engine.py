@@ -524,3 +524,75 @@ def test_complex_qf_rows_from_the_persistent_engine(n, m, nb):
                 ref = np.dot(w, u) / (np.linalg.norm(tm[t].astype(np.complex128)) * np.linalg.norm(w))
                 assert abs(planes["persistent"][t, bi, d] - ref) <= 2e-5
     assert abs(abs(planes["persistent"][1, nb // 2, m // 3]) - 1.0) < 0.3  # the planted copy (noise is as strong as it)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,m", [(1000, 60000), (4096, 90000), (8192, 70000)])
+def test_no_frequency_scan_peaks_come_from_the_work_items(n, m):
+    """F = 1 on the one-launch engine (config C3: GroupXcorrFFT-style banks, per-template argmax): the FFT items write the
+    finished rows AND one peak record per (template, block, wave); the peak of a template must be the maximum of its own
+    row and the FIRST delay that holds it, bit for bit -- with ties planted (two identical copies of a template, a
+    periodic rx), with zero-energy windows (NaN rows never win), on sub-ranges, and in a call that asks for the peaks only."""
+    from pydsproutines_amd import CAFPlan, asarray
+
+    rng = np.random.default_rng(n)
+    T = 5
+    tm = np.stack([qpsk(rng, n) for _ in range(T)])
+    rx = cn(rng, m)
+    # template 1: two identical, noise-free copies -> QF^2 = 1 twice, the first one must be reported
+    rx[5000 : 5000 + n] = tm[1]
+    rx[5000 + 3 * n : 5000 + 4 * n] = tm[1]
+    # template 2: planted inside a stretch of zeros (zero-energy windows around it: NaN rows)
+    rx[30000 - 2 * n : 30000 + 3 * n] = 0
+    rx[30000 : 30000 + n] = 0.5 * tm[2]
+    d_rx = asarray(rx)
+    plan = CAFPlan(tm, max_rx_len=m, bins=[0], grid=1 << int(np.ceil(np.log2(n))), engine="persistent")
+    for lo, cnt in ((0, None), (123, 40000), (4999, 3 * n + 2)):
+        kw = dict(shift_start=lo) if cnt is None else dict(shift_start=lo, num_shifts=cnt)
+        res = plan.run(d_rx, rows=True, peak=True, **kw)
+        rows = res.row_max.get()
+        assert np.all(res.row_arg.get() == 0)
+        pv, pd = res.peak_val.get(), res.peak_delay.get()
+        for t in range(T):
+            r = np.where(np.isnan(rows[t]), -1.0, rows[t])
+            assert pv[t] == r.max(), (t, lo)
+            assert pd[t] == lo + int(np.argmax(r)), (t, lo)  # first index of the maximum
+        only = plan.run(d_rx, rows=False, peak=True, **kw)
+        np.testing.assert_array_equal(only.peak_val.get(), pv)
+        np.testing.assert_array_equal(only.peak_delay.get(), pd)
+        assert np.all(only.peak_freq.get() == 0)
+    res = plan.run(d_rx, rows=True, peak=True)
+    assert res.peak_delay.get()[1] == 5000 and abs(res.peak_val.get()[1] - 1.0) < 1e-5
+    assert res.peak_delay.get()[2] == 30000 and abs(res.peak_val.get()[2] - 1.0) < 1e-5
+    assert np.isnan(res.row_max.get()[2][30000 - n - 5])  # a window of zeros: 0 / 0
+    plan.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("engine", ["persistent", "fused", "rocfft"])
+def test_zero_energy_windows_are_nan_and_never_win(engine):
+    """A stretch of exact zeros in rx longer than the template (a gap in a recording): the reference's 0 / 0.  Every engine
+    must report NaN on the surface and in the per-delay maxima (hypothesis 0) for those windows -- not the overlap-save
+    transform's rounding noise times 1 / 0 -- and must not let them near the peak."""
+    from pydsproutines_amd import CAFPlan, asarray
+
+    rng = np.random.default_rng(1)
+    n, m = 1000, 40000
+    t = qpsk(rng, n)
+    rx = cn(rng, m)
+    rx[20000:24000] = 0
+    rx[9000 : 9000 + n] += t
+    d_rx = asarray(rx)
+    z = slice(20000, 24000 - n + 1)
+    for F in (1, 8):
+        plan = CAFPlan(t, max_rx_len=m, bins=np.arange(F) - F // 2, grid=1024, engine=engine)
+        for surf in (True, False):
+            res = plan.run(d_rx, surface=surf, rows=True, peak=True)
+            rm, ra = res.row_max.get()[0], res.row_arg.get()[0]
+            assert np.all(np.isnan(rm[z])) and np.all(ra[z] == 0), (F, surf)
+            assert not np.any(np.isnan(rm[: 20000 - n])) and not np.any(np.isnan(rm[24000:]))
+            if surf:
+                assert np.all(np.isnan(res.surface.get()[0][z]))
+            assert int(res.peak_delay.get()[0]) == 9000 and int(res.peak_freq.get()[0]) == F // 2
+            assert res.peak_val.get()[0] == np.nanmax(rm)
+        plan.close()
