@@ -144,7 +144,9 @@ CAF_EXPORT int32_t caf_plan_info(caf_plan plan, int32_t* block, int32_t* step, i
 /* Engine actually selected by the plan: CAF_ENGINE_ROCFFT, _FUSED, _PERSISTENT or _DIRECT. */
 CAF_EXPORT int32_t caf_plan_engine(caf_plan plan, int32_t* engine);
 
-/* Outputs of one execute (any pointer may be NULL = not wanted). */
+/* Outputs of one execute (any pointer may be NULL = not wanted).
+ * A delay whose rx window holds no energy (a stretch of exact zeros: the reference's 0 / 0) is reported as NaN on the
+ * surface and in d_row_max, with d_row_arg = 0, and never becomes a peak. */
 typedef struct caf_outputs {
     float* d_surface;      /* [T][num_shifts][F] float32 QF2 (reference CAF layout: delay-major)  */
     float* d_row_max;      /* [T][num_shifts] float32: max over f of QF2                           */
