@@ -147,8 +147,13 @@ def fastXcorr(cutout, rx, freqsearch=False, outputCAF=False, shifts=None, absRes
         if ns == 0:
             return out
         lo, cnt, rel = _engine_range(shifts)
+        # (the complex QF plane comes from the one-launch in-LDS engine's own work items for cutouts of up to 8192 samples --
+        #  fused_item MODE 4 -- and from the rocFFT engine beyond)
         plan = CAFPlan(_c64(cutout), max_rx_len=len(rx), bins=[0], grid=1 << int(np.ceil(np.log2(max(n, 2)))),
-                       engine="auto" if absResult else "rocfft")  # complex QF needs the rocFFT engine
+                       engine="auto" if absResult or n <= 8192 else "rocfft")
+        if not absResult and plan.engine_used != "persistent":
+            plan.close()
+            plan = CAFPlan(_c64(cutout), max_rx_len=len(rx), bins=[0], grid=1 << int(np.ceil(np.log2(max(n, 2)))), engine="rocfft")
         res = plan.run(d_rx, shift_start=lo, num_shifts=cnt, rows=absResult, peak=False, cqf=not absResult)
         if absResult:
             out[:] = res.row_max.get()[0][rel]
