@@ -120,6 +120,11 @@ void launch_argmax3d_u32(const uint32_t* x, int64_t items, int32_t d1, int32_t d
 
 // caf_perdelay.hip: fused per-delay correlator (product -> LDS FFT -> |.|^2 -> argmax), power-of-two n in [64, 16384]
 bool perdelay_fused_ok(int32_t n);
+// cutouts of 100 / 1000 / 10000 samples: radix-10 in-LDS transform (energies from the caller's prefix, ||x|| from launch_cutout_norm)
+bool perdelay_decimal_ok(int32_t n);
+int launch_perdelay_decimal(const float2* x, int32_t n, const float2* y, int64_t ylen, const double* prefix, const double* xnorm,
+                            int64_t start, int64_t step, int64_t num, int32_t zero_oor, float* qf2, uint32_t* fidx, float* plane,
+                            float2* cplane, hipStream_t st);
 int launch_perdelay_fused(const float2* x, int32_t n, const float2* y, int64_t ylen, int64_t start, int64_t step,
                           int64_t num, int32_t zero_oor, float* qf2, uint32_t* fidx, float* plane, float2* cplane,
                           hipStream_t st);

@@ -310,6 +310,21 @@ int32_t caf_xcorr_perdelay(const float* d_cutout, int32_t n, const float* d_rx, 
     double* d_cnorm = nullptr;
     if ((rc = sc.get(&d_cnorm, cutout_norm_scratch_doubles()))) return rc;
     const double* d_norm = launch_cutout_norm((const float2*)d_cutout, n, d_cnorm, st);
+    // cutouts of 100 / 1000 / 10000 samples: one fused kernel with radix-10 passes in LDS (CAF_PERDELAY_UNFUSED=1: the chain below)
+    {
+        static const bool unfused10 = [] {
+            const char* e = getenv("CAF_PERDELAY_UNFUSED");
+            return e && atoi(e) != 0;
+        }();
+        if (!unfused10 && perdelay_decimal_ok(n)) {
+            rc = launch_perdelay_decimal((const float2*)d_cutout, n, yv, ylen_v, prefix, d_norm, start_v, step, num, zero_oor ? 1 : 0,
+                                         d_qf2, (uint32_t*)d_fidx, d_caf, (float2*)d_ccaf, st);
+            if (rc) return rc;
+            CAF_HIP_TRY(hipStreamSynchronize(st));  // scratch (prefix, norm) is freed on return
+            CAF_HIP_TRY(hipGetLastError());
+            return CAF_OK;
+        }
+    }
     // rows per batch: up to 2^28 product elements (2 GiB of the 288) in flight, so that even 1e7-sample cutouts go
     // through rocFFT and the argmax a few dozen rows at a time
     if (batch_rows <= 0) batch_rows = std::max<int64_t>(1, std::min<int64_t>(num, ((int64_t)1 << 28) / n));

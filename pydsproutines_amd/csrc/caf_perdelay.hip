@@ -486,6 +486,216 @@ int pd_launch(const float2* x, const float2* y, int64_t ylen, const float2* tw, 
     return CAF_OK;
 }
 
+// ----------------------------------------------------------------------------------------
+// Cutouts of 100 / 1000 / 10000 samples (benchmark_xcorrs.py's default cutout is 1000): the same per-delay algorithm with
+// radix-10 Stockham passes -- N / 10 threads per row, ten points each, two / three / four passes through a padded LDS image
+// (one extra element per ten: the stride-10 stores of the first pass fall into disjoint banks) -- instead of the product
+// matrix -> rocFFT rows -> argmax chain (>= 32 B of HBM traffic per element).  Rows are not wave-aligned (100 threads), so
+// the row-wide results go through LDS: the window energy comes from the float64 prefix the caller has anyway (as in the
+// three-kernel form, same normalisation: 1 / (sqrt(E) ||x||)), the (value, first index) maximum through one 64-bit
+// `ds_max` per thread into the row's slot (values are >= +0: the key orders like the pair).
+// ----------------------------------------------------------------------------------------
+template <int P>
+struct R10 {
+    static constexpr int N = P == 2 ? 100 : (P == 3 ? 1000 : 10000);
+    static constexpr int NTR = N / 10;
+    static constexpr int WG = P == 2 ? 256 : (P == 3 ? 512 : 1024);
+    static constexpr int RPW = WG / NTR;            // 25 / 5 / 1 rows per workgroup (250 / 500 / 1000 active threads)
+    static constexpr int IMG = N + N / 10;          // padded row image
+};
+__device__ __forceinline__ int r10_pad(int a) { return a + a / 10; }
+
+// inverse 5-point DFT (kernel e^{+j 2 pi n k / 5})
+__device__ __forceinline__ void idft5(float2& x0, float2& x1, float2& x2, float2& x3, float2& x4) {
+    constexpr float C1 = 0.30901699437494742f, C2 = -0.80901699437494742f;  // cos(2 pi / 5), cos(4 pi / 5)
+    constexpr float S1 = 0.95105651629515357f, S2 = 0.58778525229247313f;   // sin(2 pi / 5), sin(4 pi / 5)
+    const float2 t1 = cadd(x1, x4), t2 = cadd(x2, x3), t3 = csub(x1, x4), t4 = csub(x2, x3);
+    const float2 a1 = make_float2(x0.x + C1 * t1.x + C2 * t2.x, x0.y + C1 * t1.y + C2 * t2.y);
+    const float2 a2 = make_float2(x0.x + C2 * t1.x + C1 * t2.x, x0.y + C2 * t1.y + C1 * t2.y);
+    const float2 b1 = make_float2(S1 * t3.x + S2 * t4.x, S1 * t3.y + S2 * t4.y);
+    const float2 b2 = make_float2(S2 * t3.x - S1 * t4.x, S2 * t3.y - S1 * t4.y);
+    x0 = make_float2(x0.x + t1.x + t2.x, x0.y + t1.y + t2.y);
+    x1 = make_float2(a1.x - b1.y, a1.y + b1.x);  // a1 + j b1
+    x4 = make_float2(a1.x + b1.y, a1.y - b1.x);  // a1 - j b1
+    x2 = make_float2(a2.x - b2.y, a2.y + b2.x);
+    x3 = make_float2(a2.x + b2.y, a2.y - b2.x);
+}
+// inverse 10-point DFT in place: X[k] = E[k mod 5] + W10^k O[k mod 5]
+__device__ __forceinline__ void idft10(float2 (&v)[10]) {
+    float2 e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6], e4 = v[8];
+    float2 o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7], o4 = v[9];
+    idft5(e0, e1, e2, e3, e4);
+    idft5(o0, o1, o2, o3, o4);
+    // W10^k = e^{+j 2 pi k / 10}, k = 1 .. 4
+    o1 = cmul(o1, make_float2(0.80901699437494742f, 0.58778525229247313f));
+    o2 = cmul(o2, make_float2(0.30901699437494742f, 0.95105651629515357f));
+    o3 = cmul(o3, make_float2(-0.30901699437494742f, 0.95105651629515357f));
+    o4 = cmul(o4, make_float2(-0.80901699437494742f, 0.58778525229247313f));
+    v[0] = cadd(e0, o0), v[5] = csub(e0, o0);
+    v[1] = cadd(e1, o1), v[6] = csub(e1, o1);
+    v[2] = cadd(e2, o2), v[7] = csub(e2, o2);
+    v[3] = cadd(e3, o3), v[8] = csub(e3, o3);
+    v[4] = cadd(e4, o4), v[9] = csub(e4, o4);
+}
+// one Stockham pass of radix 10 with Ns = 10^(pass index): butterfly j = l of the row; tw10 = W_N^q, q < N
+template <int P, int NS, bool FIRST, bool LAST>
+__device__ __forceinline__ void r10_pass(float2* __restrict__ buf, const float2* __restrict__ tw10, int l, bool active, float2 (&v)[10]) {
+    constexpr int N = R10<P>::N, NTR = R10<P>::NTR;
+    if (!FIRST) {
+        if (active) {
+            const float2* src = buf + r10_pad(l);
+#pragma unroll
+            for (int t = 0; t < 10; ++t) v[t] = src[t * (NTR + NTR / 10)];  // pad(l + t NTR) = pad(l) + 11 t NTR / 10 (NTR is a multiple of 10)
+        }
+        __syncthreads();  // every butterfly has its inputs: the image may be overwritten
+    }
+    const int k = l % NS;
+    if (NS > 1) {
+        const float2 w1 = tw10[k * (N / (NS * 10))];  // W_{10 NS}^k
+        float2 p = w1;
+        v[1] = cmul(v[1], p);
+#pragma unroll
+        for (int t = 2; t < 10; ++t) {
+            p = cmul(p, w1);
+            v[t] = cmul(v[t], p);
+        }
+    }
+    idft10(v);
+    if (!LAST) {
+        if (active) {
+            float2* dst = buf + r10_pad((l - k) * 10 + k);
+#pragma unroll
+            for (int t = 0; t < 10; ++t) dst[NS == 1 ? t : t * (NS + NS / 10)] = v[t];  // (NS == 1: 10 l + t stays inside one padded decade)
+        }
+        __syncthreads();
+    }
+}
+template <int P>
+__device__ __forceinline__ void r10_fft(float2* __restrict__ buf, const float2* __restrict__ tw10, int l, bool active, float2 (&v)[10]) {
+    if constexpr (P == 2) {
+        r10_pass<P, 1, true, false>(buf, tw10, l, active, v);
+        r10_pass<P, 10, false, true>(buf, tw10, l, active, v);
+    } else if constexpr (P == 3) {
+        r10_pass<P, 1, true, false>(buf, tw10, l, active, v);
+        r10_pass<P, 10, false, false>(buf, tw10, l, active, v);
+        r10_pass<P, 100, false, true>(buf, tw10, l, active, v);
+    } else {
+        r10_pass<P, 1, true, false>(buf, tw10, l, active, v);
+        r10_pass<P, 10, false, false>(buf, tw10, l, active, v);
+        r10_pass<P, 100, false, false>(buf, tw10, l, active, v);
+        r10_pass<P, 1000, false, true>(buf, tw10, l, active, v);
+    }
+}
+
+template <int P>
+__global__ __launch_bounds__(R10<P>::WG, 4) void k_perdelay_r10(  // (4 waves per SIMD: 128 VGPRs)
+    const float2* __restrict__ x, const float2* __restrict__ y, int64_t ylen, const float2* __restrict__ tw10,
+    const double* __restrict__ prefix, const double* __restrict__ xnorm, int64_t start, int64_t step, int64_t num,
+    int32_t rows_per_wg, int32_t zero_oor, float* __restrict__ qf2, uint32_t* __restrict__ fidx, float* __restrict__ plane,
+    float2* __restrict__ cplane) {
+    constexpr int N = R10<P>::N, NTR = R10<P>::NTR, RPW = R10<P>::RPW, IMG = R10<P>::IMG;
+    extern __shared__ __attribute__((aligned(16))) float2 s_buf[];  // RPW row images
+    __shared__ unsigned long long s_key[2][RPW];
+    const int tid = threadIdx.x;
+    const bool active = tid < RPW * NTR;            // (the last threads of the workgroup only keep the barriers company)
+    const int rl = active ? tid / NTR : 0, l = active ? tid - rl * NTR : 0;
+    float2* buf = s_buf + rl * IMG;
+    float2 xr[10];
+#pragma unroll
+    for (int t = 0; t < 10; ++t) xr[t] = x[l + t * NTR];
+    const double xn = *xnorm;
+    if (tid < 2 * RPW) s_key[tid / RPW][tid % RPW] = 0ull;
+    __syncthreads();
+    const int64_t row0 = (int64_t)blockIdx.x * rows_per_wg * RPW;
+    for (int it = 0; it < rows_per_wg; ++it) {
+        const int64_t row = row0 + (int64_t)it * RPW + rl;
+        const bool live = active && row < num;
+        const int64_t s = start + row * step;
+        const bool oor = (s < 0) || (s + N > ylen);
+        const bool zero = !live || (oor && zero_oor);
+        float2 v[10];
+        if (!zero && !oor) {
+            const float2* yrow = y + s;
+#pragma unroll
+            for (int t = 0; t < 10; ++t) v[t] = yrow[l + t * NTR];
+        } else {
+#pragma unroll
+            for (int t = 0; t < 10; ++t) {
+                const int64_t j = s + l + t * NTR;
+                v[t] = (!zero && j >= 0 && j < ylen) ? y[j] : make_float2(0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 10; ++t) {
+            const float2 a = xr[t], b = v[t];
+            v[t] = make_float2(a.x * b.x - a.y * b.y, -(a.x * b.y + a.y * b.x));  // conj(x y): see k_perdelay_fused
+        }
+        // normalisation exactly as the three-kernel form computes it (k_sliding_multiply): window energy from the prefix
+        float inv = 0.f;
+        if (!zero) {
+            const int64_t a = s < 0 ? 0 : (s > ylen ? ylen : s);
+            int64_t b = s + N;
+            b = b < 0 ? 0 : (b > ylen ? ylen : b);
+            inv = (float)(1.0 / (sqrt(prefix[b] - prefix[a]) * xn));
+        }
+        r10_fft<P>(buf, tw10, l, active, v);
+        // outputs: register t <-> spectrum index l + t NTR (ascending in t)
+        if ((plane || cplane) && live) {
+            float* prow = plane ? plane + row * N : nullptr;
+            float2* crow = cplane ? cplane + row * N : nullptr;
+#pragma unroll
+            for (int t = 0; t < 10; ++t) {
+                const float zr = v[t].x * inv, zi = v[t].y * inv;
+                if (prow) prow[l + t * NTR] = __builtin_fmaf(zr, zr, zi * zi);
+                if (crow) crow[l + t * NTR] = make_float2(zr, -zi);
+            }
+        }
+        if (qf2 || fidx) {
+            float bv = -1.f;
+            uint32_t bt = 0;
+#pragma unroll
+            for (int t = 0; t < 10; ++t) {
+                const float zr = v[t].x * inv, zi = v[t].y * inv;
+                const float val = __builtin_fmaf(zr, zr, zi * zi);
+                if (val > bv) {
+                    bv = val;
+                    bt = (uint32_t)t;
+                }
+            }
+            const uint32_t bi = (uint32_t)l + bt * NTR;
+            const unsigned long long key = bv < 0.f ? 0ull : (((unsigned long long)__float_as_uint(bv) << 32) | (uint32_t)~bi);
+            if (live && key) atomicMax(&s_key[it & 1][rl], key);
+            __syncthreads();
+            if (live && l == 0) {
+                const unsigned long long kk = s_key[it & 1][rl];
+                if (qf2) qf2[row] = kk ? __uint_as_float((uint32_t)(kk >> 32)) : 0.f;  // (all-NaN row: the reference's zero-initialised workspace)
+                if (fidx) fidx[row] = kk ? ~(uint32_t)kk : 0u;
+                s_key[it & 1][rl] = 0ull;  // (next used two rows from now, behind the barriers of the row in between)
+            }
+        }
+    }
+}
+
+template <int P>
+int r10_launch(const float2* x, const float2* y, int64_t ylen, const float2* tw10, const double* prefix, const double* xnorm,
+               int64_t start, int64_t step, int64_t num, int32_t zero_oor, float* qf2, uint32_t* fidx, float* plane,
+               float2* cplane, hipStream_t st) {
+    constexpr int WG = R10<P>::WG, RPW = R10<P>::RPW;
+    const size_t lds = (size_t)RPW * R10<P>::IMG * sizeof(float2);
+    static bool attr_set = false;
+    if (!attr_set) {
+        CAF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_perdelay_r10<P>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const int64_t groups = (num + RPW - 1) / RPW;
+    const int32_t rows_per_wg = (int32_t)std::max<int64_t>(1, std::min<int64_t>(16, groups / 4096));
+    const int64_t nwg = (groups + rows_per_wg - 1) / rows_per_wg;
+    CAF_REQUIRE(nwg <= 0x7fffffff, "caf_xcorr_perdelay: too many delays for one launch");
+    hipLaunchKernelGGL(k_perdelay_r10<P>, dim3((unsigned)nwg), dim3(WG), lds, st, x, y, ylen, tw10, prefix, xnorm, start, step, num,
+                       rows_per_wg, zero_oor, qf2, fidx, plane, cplane);
+    return CAF_OK;
+}
+
 }  // namespace
 
 bool perdelay_fused_ok(int32_t n) { return n >= 64 && n <= 16384 && (n & (n - 1)) == 0; }
@@ -510,6 +720,52 @@ int launch_perdelay_fused(const float2* x, int32_t n, const float2* y, int64_t y
         case 16384: return pd_launch<14>(x, y, ylen, tw, start, step, num, zero_oor, qf2, fidx, plane, cplane, st);
     }
     set_error("launch_perdelay_fused: unsupported length");
+    return CAF_ERR_INVALID;
+}
+
+bool perdelay_decimal_ok(int32_t n) { return n == 100 || n == 1000 || n == 10000; }
+
+// e^{+j 2 pi q / n}, q < n, for the radix-10 transforms (built once per device and length)
+static int r10_twiddles(int device, int32_t n, const float2** out) {
+    static std::mutex mu;
+    static std::vector<std::pair<std::pair<int, int32_t>, float2*>> tabs;
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto& e : tabs)
+        if (e.first.first == device && e.first.second == n) {
+            *out = e.second;
+            return CAF_OK;
+        }
+    std::vector<std::complex<float>> t(n);
+    for (int q = 0; q < n; ++q) {
+        const double ph = 2.0 * M_PI * (double)q / (double)n;
+        t[q] = std::complex<float>((float)std::cos(ph), (float)std::sin(ph));
+    }
+    float2* d = nullptr;
+    CAF_HIP_TRY(hipMalloc((void**)&d, (size_t)n * 8));
+    const hipError_t e = hipMemcpy(d, t.data(), (size_t)n * 8, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(d);
+        CAF_HIP_TRY(e);
+    }
+    tabs.push_back({{device, n}, d});
+    *out = d;
+    return CAF_OK;
+}
+
+int launch_perdelay_decimal(const float2* x, int32_t n, const float2* y, int64_t ylen, const double* prefix, const double* xnorm,
+                            int64_t start, int64_t step, int64_t num, int32_t zero_oor, float* qf2, uint32_t* fidx, float* plane,
+                            float2* cplane, hipStream_t st) {
+    int dev = 0;
+    CAF_HIP_TRY(hipGetDevice(&dev));
+    const float2* tw10 = nullptr;
+    const int rc = r10_twiddles(dev, n, &tw10);
+    if (rc) return rc;
+    switch (n) {
+        case 100: return r10_launch<2>(x, y, ylen, tw10, prefix, xnorm, start, step, num, zero_oor, qf2, fidx, plane, cplane, st);
+        case 1000: return r10_launch<3>(x, y, ylen, tw10, prefix, xnorm, start, step, num, zero_oor, qf2, fidx, plane, cplane, st);
+        case 10000: return r10_launch<4>(x, y, ylen, tw10, prefix, xnorm, start, step, num, zero_oor, qf2, fidx, plane, cplane, st);
+    }
+    set_error("launch_perdelay_decimal: unsupported length");
     return CAF_ERR_INVALID;
 }
 

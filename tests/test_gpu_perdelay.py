@@ -139,6 +139,49 @@ def test_4096_rules_and_long_runs():
     assert np.max(np.abs(q[~dead] - rq)) <= tol
 
 
+@pytest.mark.parametrize("n", [100, 1000, 10000])
+def test_decimal_cutouts_radix10_kernel(n):
+    """Cutouts of 100 / 1000 / 10000 samples (benchmark_xcorrs.py's default is 1000) run the same per-delay algorithm with
+    radix-10 passes in LDS (k_perdelay_r10): the oracle's branches B, C, C' again, a planted (delay, bin), odd row counts,
+    strides in both directions, the zero rows of the out-of-range rule and an all-zero window."""
+    rng = np.random.default_rng(n)
+    m = n + 900
+    rx = cn(rng, m)
+    d0, k0 = 77, (3 * n) // 10 + 1
+    cut = (rx[d0 : d0 + n] * np.exp(-2j * np.pi * k0 * np.arange(n) / n)).astype(np.complex64)  # planted at (d0, k0)
+    rx = (rx + 0.05 * cn(rng, m)).astype(np.complex64)
+    num = 301 if n <= 1000 else 101
+    shifts = np.arange(num)
+    q, fi, pl, cp = _perdelay(cut.conj(), rx, 0, 1, num, caf=True, ccaf=True)
+    ref_c = O.fastXcorr(cut, rx, freqsearch=True, outputCAF=True, shifts=shifts)
+    ref_cc = O.fastXcorr(cut, rx, freqsearch=True, outputCAF=True, shifts=shifts, absResult=False)
+    tol = 2e-5
+    assert np.max(np.abs(pl - ref_c)) <= tol
+    assert np.max(np.abs(cp - ref_cc)) <= 1e-4 * max(1.0, np.abs(ref_cc).max())
+    np.testing.assert_array_equal(q, pl.max(axis=1))
+    np.testing.assert_array_equal(fi, np.argmax(pl, axis=1))
+    assert (int(np.argmax(q)), int(fi[np.argmax(q)])) == (d0, k0)
+    for start, step, cnt in ((5, 7, 111), (m - n, -3, 200)):
+        q, fi, _, _ = _perdelay(cut.conj(), rx, start, step, cnt)
+        sh = start + step * np.arange(cnt)
+        rq, rf = O.fastXcorr(cut, rx, freqsearch=True, shifts=sh)
+        assert np.max(np.abs(q - rq)) <= tol
+        diff = np.nonzero(fi != rf)[0]
+        if diff.size:  # float32 ties only
+            rows = O.fastXcorr(cut, rx, freqsearch=True, outputCAF=True, shifts=sh[diff])
+            assert np.all(rows[np.arange(diff.size), fi[diff]] >= rows.max(axis=1) - 2 * tol)
+    # CyIppXcorrFFT rule: windows that leave rx give (0, 0) and zero rows
+    q, fi, pl, _ = _perdelay(cut.conj(), rx, -13, 1, m - n + 40, zero_oor=True, caf=True)
+    inside = (np.arange(-13, m - n + 27) >= 0) & (np.arange(-13, m - n + 27) + n <= m)
+    assert np.all(q[~inside] == 0) and np.all(fi[~inside] == 0) and np.all(pl[~inside] == 0)
+    rq, _ = O.fastXcorr(cut, rx, freqsearch=True, shifts=np.arange(0, m - n + 1))
+    assert np.max(np.abs(q[inside] - rq)) <= tol
+    # an all-zero window: NaN plane, (0, 0) row result
+    rz = np.concatenate([rx, np.zeros(n + 10, np.complex64), rx[:50]])
+    q, fi, pl, _ = _perdelay(cut.conj(), rz, m, 1, 8, caf=True)
+    assert np.all(q == 0) and np.all(fi == 0) and np.all(np.isnan(pl))
+
+
 def test_fused_equals_three_kernel_form():
     """The same calls through the path it replaces (rocFFT rows), in a child process because the switch is read once."""
     code = r"""
@@ -148,7 +191,7 @@ from test_gpu_perdelay import _perdelay
 from conftest import cn
 rng = np.random.default_rng(5)
 out = {}
-for n in (64, 1024, 4096):
+for n in (64, 1000, 1024, 4096):
     rx = cn(rng, n + 500); cut = cn(rng, n)
     q, fi, pl, _ = _perdelay(cut.conj(), rx, 3, 2, 200, caf=True)
     out['q%%d' %% n], out['f%%d' %% n], out['p%%d' %% n] = q, fi, pl
