@@ -21,7 +21,8 @@ ROWS = [  # (workload, kernel prefix of the manifest entry, label)
     ("perdelay_fused_256", "k_perdelay_fused", "`k_perdelay_fused<8>` (256 × 10⁶)"),
     ("direct_small_support", "k_direct_caf", "`k_direct_caf` (16 samples of support, 64 frequencies, 2²² delays, surface)"),
     ("cp_fastxcorr_1e7", "k_sliding_multiply", "`k_sliding_multiply` (128 rows × 10⁷)"),
-    ("perdelay_rows_1000", "k_sliding_multiply", "`k_sliding_multiply` (10⁵ rows × 1000)"),
+    ("perdelay_decimal_1000", "k_perdelay_r10", "`k_perdelay_r10<3>` (1000 × 10⁶, radix 10)"),
+    ("perdelay_rows_1000", "k_sliding_multiply", "`k_sliding_multiply` (10⁵ rows × 1200)"),
     ("cp_fastxcorr_1e7", "k_rows_argmax", "`k_rows_argmax` (chunked, 128 rows × 10⁷)"),
     ("kernels_misc", "k_magnsq", "`k_magnsq`"),
     ("kernels_misc", "k_iq16_to_c64", "`k_iq16_to_c64`"),

@@ -219,9 +219,17 @@ def w_perdelay_fused_256():
 
 
 def w_perdelay_rows_1000():
-    n, num = perdelay(1000, 100_000, "rows")
-    return [("k_sliding_multiply", "normalised product rows, N=1000 x 1e5 (8 B written per element)", num * n * 8.0, 0.0, 2),
+    """A cutout length that is neither a power of two nor of ten: product rows -> rocFFT rows -> argmax."""
+    n, num = perdelay(1200, 100_000, "rows")
+    return [("k_sliding_multiply", "normalised product rows, N=1200 x 1e5 (8 B written per element)", num * n * 8.0, 0.0, 2),
             ("k_rows_argmax", "|.|^2 + first argmax per row (8 B read per element)", num * n * 8.0, 0.0, 2)]
+
+
+def w_perdelay_decimal_1000():
+    """benchmark_xcorrs.py's default cutout (1000 samples): the per-delay algorithm on radix-10 passes in LDS."""
+    n, num = perdelay(1000, 1_000_000, "fused")
+    return [("k_perdelay_r10", "fused per-delay correlator, N=1000 x 1e6 rows (product elements at 8 B each; 5 N log2 N flop per row)",
+             num * n * 8.0, num * 5.0 * n * np.log2(n), 2)]
 
 
 def w_cp_fastxcorr_1e7():
