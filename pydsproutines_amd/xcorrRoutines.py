@@ -513,10 +513,10 @@ def cp_fastXcorr_v2(cutout, rx, startIdx=0, idxlen=None, THREADS_PER_BLOCK=32, n
         d_out = empty((idxlen, ncols), np.float32)
     lib = _lib.load()
     n = int(cutout.size)
-    if (flattenCAF and cztObj is None and 64 <= n <= 16384 and n & (n - 1) == 0 and startIdx >= 0
+    if (flattenCAF and cztObj is None and ((64 <= n <= 16384 and n & (n - 1) == 0) or n in (100, 1000, 10000)) and startIdx >= 0
             and startIdx + idxlen - 1 + n <= rx.size):
-        # power-of-two cutout, every window inside rx: the whole chain (product, row transform, |.|^2, argmax, both norms)
-        # is ONE kernel (caf_perdelay.hip) -- no (idxlen, N) matrix, no batches, nothing to wait for
+        # power-of-two cutout (or 100 / 1000 / 10000 samples: radix-10 passes), every window inside rx: the whole chain
+        # (product, row transform, |.|^2, argmax, both norms) is ONE kernel (caf_perdelay.hip) -- no (idxlen, N) matrix, no batches
         _lib.check(lib.caf_xcorr_perdelay(ct.c_void_p(cutout.ptr), n, ct.c_void_p(rx.ptr), rx.size, int(startIdx), 1,
                                           int(idxlen), 0, ct.c_void_p(d_qf2.ptr), ct.c_void_p(d_freqIdx.ptr), None, None,
                                           0, None), "caf_xcorr_perdelay")
