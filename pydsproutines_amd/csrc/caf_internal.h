@@ -15,8 +15,10 @@ constexpr int MAG_S = 64;         // delays per tile (one wave-row of 8-byte loa
 constexpr int MAG_F = 128;        // frequency hypotheses per LDS chunk (512 B store rows)
 
 // window energies below this fraction of the float64 prefix they are differences of are reported as zero-energy windows
-// (NaN results): k_inv_energy, k_block_spectra
-constexpr double CAF_ENERGY_FLOOR = 9.094947017729282e-13;  // 2^-40
+// (NaN results): k_inv_energy, k_block_spectra.  The prefix differences carry a few units in the 2^-53 place of the prefix
+// times log2(samples) (tree scans): 2^-44 is ~30 x that, and a window of 4096 samples at 100 dB below a full 2^24-sample
+// record before it still passes.
+constexpr double CAF_ENERGY_FLOOR = 5.6843418860808015e-14;  // 2^-44
 
 struct PeakRec {
     float v;

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void k_inv_energy(const double* __restrict__ p
     // A window of zeros (a gap in a recording) is the reference's 0 / 0 = NaN.  Here the energy is a difference of float64
     // prefix values from a parallel scan -- 0 up to a few units in the last place of the prefix, not exactly 0 -- and the
     // in-LDS engines multiply |y|^2, which is FFT rounding noise there, by this factor: 1 / (almost 0) would make that noise the
-    // row's maximum.  Anything below the resolution of the prefix it was taken from (2^-40 of it) is reported as NaN.
+    // row's maximum.  Anything below the resolution of the prefix it was taken from (2^-44 of it) is reported as NaN.
     inv_e[i] = e > CAF_ENERGY_FLOOR * ptop ? (float)(1.0 / e) : __builtin_nanf("");
 }
 
