@@ -157,6 +157,13 @@ typedef struct caf_outputs {
     float* d_cqf;          /* [T][F][num_shifts] complex64 QF = r / (||tmpl|| * ||rx window||), i.e.   */
                            /* hypothesis-major like TemplateCrossCorrelator.correlate (:352-357) and   */
                            /* fastXcorr(absResult=False) (:533-548)                                    */
+    float* d_surface_t;    /* [T][F][num_shifts] float32 QF2, HYPOTHESIS-major: the same numbers as d_surface, */
+                           /* bit for bit, transposed per template (not the reference's CAF layout,         */
+                           /* xcorrRoutines.py:553-566; it is what a frequency-row consumer -- a zoom, a       */
+                           /* results store, a per-bin detector -- reads contiguously).  Written by the FFT    */
+                           /* work items of the PERSISTENT engine with 16384-point blocks themselves: no       */
+                           /* |y|^2 tiles, no transposition (C2: 10 ms against 13.5).  Not together with      */
+                           /* d_surface or d_cqf; F == 1: any engine (the two layouts coincide).               */
 } caf_outputs;
 
 /* d_rx: device complex64 [rx_len].  Requires shift_start >= 0 and

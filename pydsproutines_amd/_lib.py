@@ -83,6 +83,7 @@ class CafOutputs(ct.Structure):
         ("d_peak_delay", ct.c_void_p),
         ("d_peak_freq", ct.c_void_p),
         ("d_cqf", ct.c_void_p),
+        ("d_surface_t", ct.c_void_p),
     ]
 
 

@@ -18,11 +18,11 @@ from .devarray import DeviceArray, as_device_ptr, asarray, empty, zeros
 class CAFResult:
     """Device-resident outputs of one execute."""
 
-    __slots__ = ("surface", "row_max", "row_arg", "peak_val", "peak_delay", "peak_freq", "cqf", "_row_arg_is_zero")
+    __slots__ = ("surface", "surface_t", "row_max", "row_arg", "peak_val", "peak_delay", "peak_freq", "cqf", "_row_arg_zeroed")
 
     def __init__(self):
-        self.surface = self.row_max = self.row_arg = None
-        self._row_arg_is_zero = False
+        self.surface = self.surface_t = self.row_max = self.row_arg = None
+        self._row_arg_zeroed = None  # (ptr, nbytes) of the F == 1 argument array this object has already filled with zeros
         self.peak_val = self.peak_delay = self.peak_freq = None
         self.cqf = None
 
@@ -121,7 +121,7 @@ class CAFPlan:
 
     # ------------------------------------------------------------------------------------
     def run(self, rx, shift_start=0, num_shifts=None, surface=False, rows=True, peak=True, stream=None, out=None,
-            cqf=False):
+            cqf=False, surface_t=False):
         """Asynchronous execute on device-resident rx (DeviceArray or CUDA torch tensor).
 
         Returns a CAFResult of DeviceArrays: surface (T,S,F) float32 if requested, row_max (T,S)
@@ -137,17 +137,25 @@ class CAFPlan:
         res = out if out is not None else CAFResult()
         if surface and res.surface is None:
             res.surface = empty((self.T, S, self.F), np.float32)
+        if surface_t and res.surface_t is None:
+            res.surface_t = empty((self.T, self.F, S), np.float32)
         want_arg = bool(rows) and rows != "max"  # rows="max": the per-delay maxima only (no argument array)
         if rows and res.row_max is None:
             res.row_max = empty((self.T, S), np.float32)
         if want_arg and res.row_arg is None:
-            if self.F == 1:
-                # one hypothesis per template: the argument of every per-delay maximum is 0.  Zeroed once, here, and not
-                # handed to the library again (which would fill T x S x 4 bytes on every call: 0.65 ms of C3's 4.5)
-                res.row_arg = zeros((self.T, S), np.int32)
-                res._row_arg_is_zero = True
-            else:
-                res.row_arg = empty((self.T, S), np.int32)
+            res.row_arg = empty((self.T, S), np.int32)
+        skip_arg = False
+        if want_arg and self.F == 1:
+            # one hypothesis per template: the argument of every per-delay maximum is 0.  The array is zeroed once per
+            # buffer -- on the stream of this run, keyed on the buffer itself, so a caller who swaps res.row_arg gets the
+            # new one filled -- and not handed to the library again (which would fill T x S x 4 bytes on every call:
+            # 0.65 ms of C3's 4.5)
+            key = (res.row_arg.ptr, res.row_arg.nbytes)
+            if res._row_arg_zeroed != key:
+                _lib.check(_lib.load().caf_memset(ct.c_void_p(res.row_arg.ptr), 0, res.row_arg.nbytes,
+                                                  ct.c_void_p(stream) if stream else None), "caf_memset")
+                res._row_arg_zeroed = key
+            skip_arg = True
         if peak and res.peak_val is None:
             res.peak_val = empty((self.T,), np.float32)
             res.peak_delay = empty((self.T,), np.int32)
@@ -158,7 +166,8 @@ class CAFPlan:
         o.d_cqf = res.cqf.ptr if cqf else None
         o.d_surface = res.surface.ptr if surface else None
         o.d_row_max = res.row_max.ptr if rows else None
-        o.d_row_arg = res.row_arg.ptr if want_arg and not (self.F == 1 and res._row_arg_is_zero) else None
+        o.d_row_arg = res.row_arg.ptr if want_arg and not skip_arg else None
+        o.d_surface_t = res.surface_t.ptr if surface_t else None
         o.d_peak_val = res.peak_val.ptr if peak else None
         o.d_peak_delay = res.peak_delay.ptr if peak else None
         o.d_peak_freq = res.peak_freq.ptr if peak else None

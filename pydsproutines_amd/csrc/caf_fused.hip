@@ -230,6 +230,10 @@ __device__ __forceinline__ void tile_store(__amdgpu_buffer_rsrc_t r, uint32_t vo
 // xcorrRoutines.py:352-357, :533-548): the hypothesis-major complex plane [T*F][num_shifts] is exactly what an FFT item
 // produces -- one transform = one row segment -- so the item writes y * sqrt(1/energy) * sqrt(1/||t||^2) as complex64
 // itself; no tiles, no tile role, any number of frequencies.
+// MODE 5 (hypothesis-major QF^2 surface: caf_outputs::d_surface_t [T][F][num_shifts]): MODE 2 and MODE 3 together -- every
+// transform's 12288 delays are one contiguous row segment of that layout, so the item normalises and writes them itself
+// (no tiles, no transposition) and keeps the running per-delay maxima of the NORMALISED values it has just formed, so that
+// row_arg is the first maximum of the written values bit for bit, inside a group and -- reduce_wave_nosurf -- across groups.
 struct F1Direct {
     float* out0;          // row_max or surface, [T][num_shifts]; MODE 4: the complex plane (2 floats per value)
     float* out1;          // the other one of the two when both are wanted, else nullptr
@@ -266,15 +270,16 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
     // all are not computed (N = 4096 with the step rounded to 12288: n4 = 3; N = 8192: n4 = 2 and 3; -3.3 % per transform
     // at NV4 = 3)
     constexpr int nv4 = NV4;  // (compile-time: as a run-time scalar the 16 branches per transform ate the 3 % it saves)
-    float bv[16];     // MODE 2: running maxima of this thread's 16 delays ...
+    float bv[16];     // MODE 2 / 5: running maxima of this thread's 16 delays ...
     uint32_t bi[4];   // ... and the item-local hypothesis (8 bits each) that produced them
-    if (MODE == 2) {
+    float ge[16];     // MODE 3 / 4 / 5: 1 / window energy of this thread's 16 delays
+    if (MODE == 2 || MODE == 5) {
 #pragma unroll
         for (int o = 0; o < 16; ++o) bv[o] = -1.f;
 #pragma unroll
         for (int o = 0; o < 4; ++o) bi[o] = 0u;
     }
-    // MODE 3: 1 / window energy of this thread's 16 delays (bv doubles as their storage), the valid extent of the block
+    // MODE 3+: 1 / window energy of this thread's 16 delays, the valid extent of the block
     uint32_t f1_bytes = 0;
     int64_t f1_rel0 = 0;
     if (MODE >= 3) {
@@ -288,12 +293,12 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int n4 = 0; n4 < 4; ++n4)
-                bv[4 * i + n4] = __builtin_bit_cast(
+                ge[4 * i + n4] = __builtin_bit_cast(
                     float, __builtin_amdgcn_raw_buffer_load_b32(rie, (((n2 >> 2) + 4 * q) * 64 + n1 + 16 * (n2 & 3)) * 4,
                                                                 (16 * i + 64 * n4) * 256, 0));
         if (MODE == 4) {  // amplitudes, not powers: sqrt(1 / energy) per delay
 #pragma unroll
-            for (int o = 0; o < 16; ++o) bv[o] = __builtin_sqrtf(bv[o]);
+            for (int o = 0; o < 16; ++o) ge[o] = __builtin_sqrtf(ge[o]);
         }
     }
 
@@ -365,6 +370,10 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
             f1_ts = __builtin_sqrtf(*((const CAF_AS1 float*)f1->tscale + h / nfreq));
             f1_r0 = buf_of(uniform_ptr(f1->out0 + 2 * ((int64_t)h * f1->num_shifts + f1_rel0)), 2u * f1_bytes);
         }
+        if (MODE == 5) {  // row h = t * nfreq + f of the hypothesis-major surface
+            f1_ts = *((const CAF_AS1 float*)f1->tscale + h / nfreq);
+            f1_r0 = buf_of(uniform_ptr(f1->out0 + (int64_t)h * f1->num_shifts + f1_rel0), f1_bytes);
+        }
         // ---- pass 1: P = X * Hc_h ; DFT16 over a ; twiddle w^n1 ; write A[n1][m2] ----
         // One butterfly at a time (32 live data registers).  pr is dead after this pass and is refilled
         // with the next hypothesis' products during pass 4, the low-pressure phase.
@@ -433,7 +442,8 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
         }
         if (MODE >= 2) {
             // (the 20 registers of the running maxima leave no room for the row during pass 3: it is fetched here,
-            // under the barrier and the pass-4 work; there are no tile stores to compete with in this mode)
+            // under the barrier and the pass-4 work.  MODE 5, measured: a quarter / half / three quarters of the row
+            // fetched before pass 3 instead cost 0.9 ms of 10.9 at C2 -- profiles/r04/ab_surface_t_early_row.log)
 #pragma unroll
             for (int j = 0; j < BPT; ++j)
 #pragma unroll
@@ -492,14 +502,27 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
                         const uint32_t sh8 = 8u * (uint32_t)(oo & 3);
                         const uint32_t repl = (bi[oo >> 2] & ~(0xffu << sh8)) | ((uint32_t)(h - h0) << sh8);
                         bi[oo >> 2] = up ? repl : bi[oo >> 2];
+                    } else if (MODE == 5) {
+                        // the finished value, rounded as every surface path rounds it; its running maximum is therefore
+                        // the maximum of the WRITTEN values (hypotheses in increasing order: the first one stays; a NaN
+                        // -- zero-energy window -- never enters)
+                        const int oo = 4 * i + n4;
+                        const float outv = val * (ge[oo] * f1_ts);
+                        const bool up = outv > bv[oo];
+                        bv[oo] = up ? outv : bv[oo];
+                        const uint32_t sh8 = 8u * (uint32_t)(oo & 3);
+                        const uint32_t repl = (bi[oo >> 2] & ~(0xffu << sh8)) | ((uint32_t)(h - h0) << sh8);
+                        bi[oo >> 2] = up ? repl : bi[oo >> 2];
+                        const uint32_t v3 = (uint32_t)(tile_t * 64 + n1 + 16 * (n2 & 3)) << 2, s3 = (uint32_t)tile_u * 256u;
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, outv), f1_r0, (int)v3, (int)s3, CAF_AUX_NT);
                     } else if (MODE == 4) {
-                        const float gq = bv[4 * i + n4] * f1_ts;
+                        const float gq = ge[4 * i + n4] * f1_ts;
                         const v2f_t ov = {yq.x * gq, yq.y * gq};
                         const uint32_t v3 = (uint32_t)(tile_t * 64 + n1 + 16 * (n2 & 3)) << 3, s3 = (uint32_t)tile_u * 512u;
                         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i_t, ov), f1_r0, (int)v3, (int)s3, CAF_AUX_NT);
                     } else if (MODE == 3) {
                         // the finished per-delay value, rounded as the tile roles round it: value * (1/energy * 1/||t||^2)
-                        const float outv = val * (bv[4 * i + n4] * f1_ts);
+                        const float outv = val * (ge[4 * i + n4] * f1_ts);
                         if (PK) {
                             // delays of one output quarter n4 are visited in increasing order (i): a strict comparison keeps
                             // the first maximum; NaN (zero-energy window) and delays past the block's valid extent never enter
@@ -551,7 +574,7 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
             }
         }
     }
-    if (MODE == 2) {
+    if (MODE == 2 || MODE == 5) {
         // one (value, hypothesis) pair per delay of the block, in 64-delay tiles: vt[tile][64], imax[tile][64]
         const int n1 = tid & 15, n2 = (tid >> 4) & 15, q = tid >> 8;
 #pragma unroll
@@ -1343,7 +1366,8 @@ __device__ __attribute__((noinline)) void reduce_wave_nosurf(const PersistParams
         // |y|^2 (it does not have the delay's normalisation at hand), so the two modes can name different hypotheses
         // only when two hypotheses of ONE group are within a float32 ulp of each other -- and both then hold the
         // reported maximum.
-        const float gn = ie * P->tscale[t];
+        // (nosurf == 2, the hypothesis-major surface mode: the items compared and stored the normalised values themselves)
+        const float gn = P->nosurf == 2 ? 1.f : ie * P->tscale[t];
         float bv = -1.f, bx = -1.f;
         int32_t bh = 0;
         for (int g = 0; g < gpt; ++g) {
@@ -1479,7 +1503,7 @@ __device__ __forceinline__ void pq_mark(const PersistParams* pp, int slot, int v
 // spilled values every hypothesis).  Called ~21 times per workgroup: the call and the callee-saved register
 // traffic are negligible.  Arguments arrive in VGPRs; v_readfirstlane makes them scalar again.
 typedef __attribute__((address_space(3))) float2 lds_float2;
-template <int KIND, int NV4>  // 0: |y|^2 tiles, 1: running maxima (no surface), 2: finished rows (no frequency scan), 3: complex rows
+template <int KIND, int NV4>  // 0: |y|^2 tiles, 1: running maxima (no surface), 2 / 4: finished rows (no frequency scan; 4: + peak records), 3: complex rows, 5: hypothesis-major surface rows + running maxima
 __device__ __attribute__((noinline)) void persistent_fft_item(lds_float2* s_d, const lds_float2* s_tw2,
                                                               const lds_float2* s_tw3, const PersistParams* pp_in,
                                                               int item_in) {
@@ -1524,6 +1548,22 @@ __device__ __attribute__((noinline)) void persistent_fft_item(lds_float2* s_d, c
         f1.shift_start = P->shift_start;
         fused_item<1024, 3, NV4, KIND == 4>((float2*)s_d, (const float2*)s_tw2, (const float2*)s_tw3, P->xb, P->hc, P->shifts, P->tw1,
                                             P->table_mode, P->nfreq, nhyp, blk, h0, h1, P->tiles_per_blk, nullptr, nullptr, &f1);
+    } else if (KIND == 5) {
+        // hypothesis-major surface rows + one (maximum of the written values, hypothesis) pair per delay and item
+        F1Direct f1;
+        f1.out0 = P->surface_t;
+        f1.out1 = nullptr;
+        f1.partial = nullptr;
+        f1.ppt = 0;
+        f1.shift_start = 0;
+        f1.inv_e = P->inv_e;
+        f1.tscale = P->tscale;
+        f1.num_shifts = P->num_shifts;
+        f1.step = P->step;
+        f1.blk_abs = P->blk0 + blk;
+        const int64_t o = ((int64_t)blk * ngroups + grp) * P->tiles_per_blk * 64;
+        fused_item<1024, 5, NV4>((float2*)s_d, (const float2*)s_tw2, (const float2*)s_tw3, P->xb, P->hc, P->shifts, P->tw1,
+                                 P->table_mode, P->nfreq, nhyp, blk, h0, h1, P->tiles_per_blk, P->vmax + o, P->imax + o, &f1);
     } else if (KIND == 1) {
         // no surface wanted: one (maximum, hypothesis) pair per delay and item instead of the |y|^2 tiles
         const int64_t o = ((int64_t)blk * ngroups + grp) * P->tiles_per_blk * 64;
@@ -1699,16 +1739,17 @@ __global__ __launch_bounds__(1024) void k_caf_persistent(const PersistParams* __
             else {
                 // (kind of output) x (valid quarters of the block: tiles <= 128 / 192 / 256) -> one out-of-line role each
                 const int kind3 = params_of(pp)->cqf ? 3
+                                  : params_of(pp)->surface_t ? 5
                                   : __builtin_amdgcn_readfirstlane(params_of(pp)->f1_direct) ? (params_of(pp)->partial ? 4 : 2)
                                   : __builtin_amdgcn_readfirstlane(params_of(pp)->nosurf) ? 1 : 0;
                 const int tpb = __builtin_amdgcn_readfirstlane(params_of(pp)->tiles_per_blk);
 #define CAF_FFT_ROLE(K, Q) persistent_fft_item<K, Q>((lds_float2*)s_d, (const lds_float2*)s_tw2, (const lds_float2*)s_tw3, pp, item)
                 if (tpb <= 128) {
-                    if (kind3 == 4) CAF_FFT_ROLE(4, 2); else if (kind3 == 3) CAF_FFT_ROLE(3, 2); else if (kind3 == 2) CAF_FFT_ROLE(2, 2); else if (kind3 == 1) CAF_FFT_ROLE(1, 2); else CAF_FFT_ROLE(0, 2);
+                    if (kind3 == 5) CAF_FFT_ROLE(5, 2); else if (kind3 == 4) CAF_FFT_ROLE(4, 2); else if (kind3 == 3) CAF_FFT_ROLE(3, 2); else if (kind3 == 2) CAF_FFT_ROLE(2, 2); else if (kind3 == 1) CAF_FFT_ROLE(1, 2); else CAF_FFT_ROLE(0, 2);
                 } else if (tpb <= 192) {
-                    if (kind3 == 4) CAF_FFT_ROLE(4, 3); else if (kind3 == 3) CAF_FFT_ROLE(3, 3); else if (kind3 == 2) CAF_FFT_ROLE(2, 3); else if (kind3 == 1) CAF_FFT_ROLE(1, 3); else CAF_FFT_ROLE(0, 3);
+                    if (kind3 == 5) CAF_FFT_ROLE(5, 3); else if (kind3 == 4) CAF_FFT_ROLE(4, 3); else if (kind3 == 3) CAF_FFT_ROLE(3, 3); else if (kind3 == 2) CAF_FFT_ROLE(2, 3); else if (kind3 == 1) CAF_FFT_ROLE(1, 3); else CAF_FFT_ROLE(0, 3);
                 } else {
-                    if (kind3 == 4) CAF_FFT_ROLE(4, 4); else if (kind3 == 3) CAF_FFT_ROLE(3, 4); else if (kind3 == 2) CAF_FFT_ROLE(2, 4); else if (kind3 == 1) CAF_FFT_ROLE(1, 4); else CAF_FFT_ROLE(0, 4);
+                    if (kind3 == 5) CAF_FFT_ROLE(5, 4); else if (kind3 == 4) CAF_FFT_ROLE(4, 4); else if (kind3 == 3) CAF_FFT_ROLE(3, 4); else if (kind3 == 2) CAF_FFT_ROLE(2, 4); else if (kind3 == 1) CAF_FFT_ROLE(1, 4); else CAF_FFT_ROLE(0, 4);
                 }
 #undef CAF_FFT_ROLE
             }

@@ -225,6 +225,8 @@ struct PersistParams {
     int32_t nosurf;  // 1: no |y|^2 tiles; per item one (maximum, hypothesis) pair per delay in vmax / imax
     int32_t f1_direct;  // 1 (nfreq == 1): the FFT items write the finished per-delay values to row_max / surface; no tile items
     float* cqf;         // != nullptr: the FFT items write complex QF rows [T*F][num_shifts] (2 floats per value); no tile items
+    float* surface_t;   // != nullptr: the FFT items write the hypothesis-major QF^2 surface [T*F][num_shifts] themselves and
+                        // keep running maxima of the written values (nosurf == 2: the pairs hold normalised values)
     float* vmax;     // [block][group][tile][64]
     int32_t* imax;
     int32_t* dbg;  // optional host-mapped progress marks (CAF_PERSIST_DEBUG), 4 ints per workgroup

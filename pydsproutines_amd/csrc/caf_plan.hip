@@ -247,7 +247,7 @@ int32_t caf_last_error(char* buf, int32_t len) {
     return CAF_OK;
 }
 
-int32_t caf_abi_version(void) { return (1 << 16) | 4; }  // minor: +1 per batch of added entry points
+int32_t caf_abi_version(void) { return (1 << 16) | 5; }  // minor: +1 per batch of added entry points
 
 int32_t caf_device_count(int32_t* count) {
     CAF_REQUIRE(count, "count is NULL");
@@ -813,6 +813,19 @@ int32_t caf_plan_execute(caf_plan p, const float* d_rx, int64_t rx_len, int64_t 
     const float2* rx = reinterpret_cast<const float2*>(d_rx);
     const int T = p->T, F = p->F;
     const bool want_peak = out->d_peak_val || out->d_peak_delay || out->d_peak_freq;
+    // hypothesis-major surface [T][F][S]: with one hypothesis per template it IS the delay-major one
+    caf_outputs out_f1;
+    if (out->d_surface_t && F == 1) {
+        CAF_REQUIRE(!out->d_surface, "d_surface and d_surface_t cannot both be given");
+        out_f1 = *out;
+        out_f1.d_surface = out->d_surface_t;
+        out_f1.d_surface_t = nullptr;
+        out = &out_f1;
+    }
+    const bool surf_t = out->d_surface_t != nullptr;
+    CAF_REQUIRE(!surf_t || (p->persistent && p->B == 16384 && !out->d_surface && !out->d_cqf),
+                "the hypothesis-major surface (d_surface_t) is written by the persistent engine with 16384-point blocks (templates of "
+                "at most 8192 samples), and not together with d_surface or d_cqf");
 
     if (p->direct) {
         CAF_REQUIRE(!out->d_cqf, "the direct engine has no complex-QF output (create the plan with CAF_ENGINE_ROCFFT)");
@@ -914,6 +927,9 @@ int32_t caf_plan_execute(caf_plan p, const float* d_rx, int64_t rx_len, int64_t 
                 // the two pair arrays must fit the tile buffer they replace (true for >= 2 hypotheses per group)
                 if (2 * (int64_t)T * gpt <= (int64_t)T * F) ns_gpt = gpt;
             }
+            // the hypothesis-major surface rides on the same per-template groups (F >= 2 here; fewer hypotheses than a
+            // group: one group per template)
+            if (surf_t) ns_gpt = (F + p->hyp_per_wg - 1) / p->hyp_per_wg;
         }
         // the |y|^2 tiles of one block are addressed with 32-bit byte offsets (descriptor + SGPR + VGPR offset)
         CAF_REQUIRE(ns_gpt || (int64_t)(p->B / 64) * T * F * 256 < ((int64_t)1 << 32),
@@ -966,8 +982,9 @@ int32_t caf_plan_execute(caf_plan p, const float* d_rx, int64_t rx_len, int64_t 
             h.pq = p->d_pq;
             h.tr_slots = p->tr_slots;
             h.ngroups = (T * F + p->hyp_per_wg - 1) / p->hyp_per_wg;
+            h.surface_t = out->d_surface_t;
             if (ns_gpt) {
-                h.nosurf = 1;
+                h.nosurf = surf_t ? 2 : 1;
                 h.gpt = ns_gpt;
                 h.hyp_per_wg = (F + ns_gpt - 1) / ns_gpt;
                 h.ngroups = T * ns_gpt;

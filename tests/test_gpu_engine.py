@@ -596,3 +596,67 @@ def test_zero_energy_windows_are_nan_and_never_win(engine):
             assert int(res.peak_delay.get()[0]) == 9000 and int(res.peak_freq.get()[0]) == F // 2
             assert res.peak_val.get()[0] == np.nanmax(rm)
         plan.close()
+
+
+@pytest.mark.parametrize("T,F,n,m", [(1, 5, 128, 40000), (2, 32, 300, 30000), (3, 200, 64, 20000), (1, 256, 4096, 70000),
+                                     (2, 64, 8192, 50000)])
+def test_hypothesis_major_surface_is_the_transposed_surface_bit_for_bit(T, F, n, m):
+    """caf_outputs.d_surface_t (T, F, S): written by the FFT work items themselves (fused_item MODE 5); the same numbers as
+    the delay-major surface the tile role writes, and row_max / row_arg / the peak are the maximum / first argmax of them."""
+    from pydsproutines_amd import CAFPlan, asarray
+
+    rng = np.random.default_rng(1000 * T + F)
+    tm = np.stack([qpsk(rng, n) for _ in range(T)])
+    rx = cn(rng, m)
+    d0 = m // 3
+    rx[d0 : d0 + n] += (2 * tm[T - 1] * np.exp(2j * np.pi * 2 * np.arange(n) / n)).astype(np.complex64)
+    rx[m // 2 : m // 2 + 2 * n] = 0  # a stretch of zero-energy windows: NaN in both layouts
+    bins = np.arange(F) - F // 2
+    plan = CAFPlan(tm, max_rx_len=m, bins=bins, grid=n if 16384 % n == 0 else 16384, engine="persistent")
+    d_rx = asarray(rx)
+    ref = plan.run(d_rx, surface=True)
+    got = plan.run(d_rx, surface_t=True)
+    a, b = ref.surface.get(), got.surface_t.get()
+    assert b.shape == (T, F, m - n + 1)
+    np.testing.assert_array_equal(np.transpose(a, (0, 2, 1)), b)  # (NaN == NaN in assert_array_equal)
+    assert np.isnan(b).any()
+    np.testing.assert_array_equal(got.row_max.get(), ref.row_max.get())
+    np.testing.assert_array_equal(got.row_arg.get(), ref.row_arg.get())
+    for k in ("peak_val", "peak_delay", "peak_freq"):
+        np.testing.assert_array_equal(getattr(got, k).get(), getattr(ref, k).get())
+    # against the oracle on sampled delays of the last template
+    sel = np.unique(np.concatenate((np.arange(0, 40), np.arange(d0 - 20, d0 + 20), np.arange(m - n + 1 - 40, m - n + 1))))
+    want = O.caf_bins(tm[T - 1], rx, bins, sel) if 16384 % n == 0 else None
+    if want is not None:
+        assert np.max(np.abs(b[T - 1][:, sel].T - want)) <= 1e-4 * want.max()
+    # a sub-range, the surface alone (no per-delay results, no peak)
+    lo, cnt = 777, min(13000, m - n + 1 - 777)
+    sub = plan.run(d_rx, shift_start=lo, num_shifts=cnt, surface_t=True, rows=False, peak=False)
+    # (another run start = other block boundaries: equal up to the rounding of the transform, like every sub-range run)
+    np.testing.assert_allclose(sub.surface_t.get(), b[:, :, lo : lo + cnt], atol=2e-6, equal_nan=True)
+    assert plan.watchdog() == (0, 0)
+    plan.close()
+
+
+def test_hypothesis_major_surface_rules():
+    """One hypothesis per template: the two layouts coincide (any engine); otherwise it is the persistent engine's output and
+    excludes the delay-major surface and the complex plane."""
+    from pydsproutines_amd import CAFPlan, asarray
+
+    rng = np.random.default_rng(77)
+    tm, rx = np.stack([qpsk(rng, 100) for _ in range(3)]), cn(rng, 9000)
+    for engine in ("persistent", "rocfft"):
+        plan = CAFPlan(tm, max_rx_len=rx.size, bins=[0], grid=100 if engine == "rocfft" else 16384, engine=engine)
+        r = plan.run(asarray(rx), surface_t=True)
+        ref = plan.run(asarray(rx), surface=True)
+        np.testing.assert_array_equal(r.surface_t.get()[:, 0, :], ref.surface.get()[:, :, 0])
+        np.testing.assert_array_equal(r.row_max.get(), ref.row_max.get())
+        plan.close()
+    plan = CAFPlan(tm, max_rx_len=rx.size, bins=[0, 1, 2], grid=16384, engine="rocfft")
+    with pytest.raises(ValueError, match="hypothesis-major"):
+        plan.run(asarray(rx), surface_t=True)
+    plan.close()
+    plan = CAFPlan(tm, max_rx_len=rx.size, bins=[0, 1, 2], grid=16384)
+    with pytest.raises(ValueError, match="hypothesis-major"):
+        plan.run(asarray(rx), surface_t=True, surface=True)
+    plan.close()

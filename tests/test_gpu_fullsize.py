@@ -110,6 +110,31 @@ def test_c2_engines_agree(c2):
     other.close()
 
 
+def test_c2_hypothesis_major_surface(c2):
+    """C2 with caf_outputs.d_surface_t: per-delay results and peak bit for bit those of the delay-major run; sampled
+    stretches of delays (block and tile boundaries, both ends, the peak) equal the transposed delay-major surface."""
+    res = c2["res"]
+    r = c2["plan"].run(c2["d_rx"], surface_t=True)
+    S = M - N + 1
+    assert r.surface_t.shape == (1, F, S)
+    np.testing.assert_array_equal(r.row_max.get(), res.row_max.get())
+    np.testing.assert_array_equal(r.row_arg.get(), res.row_arg.get())
+    assert (int(r.peak_delay.get()[0]), int(c2["bins"][r.peak_freq.get()[0]])) == (D0, K0)
+    assert float(r.peak_val.get()[0]) == float(res.peak_val.get()[0])
+    rows_t = {f: r.surface_t[0][f].get() for f in (0, 1, 63, 64, 127, K0 + F // 2, 255)}
+    for a in (0, 12288 - 100, 5 * 12288 - 64, D0 - 500, S - 3000):
+        n = 3000 if a + 3000 <= S else S - a
+        blk = res.surface[0][a : a + n].get()
+        for f, row in rows_t.items():
+            np.testing.assert_array_equal(row[a : a + n], blk[:, f])
+    # every row: its maximum over hypotheses is the per-delay maximum (a whole-surface property, checked per hypothesis row)
+    rmax = res.row_max.get()[0]
+    for f, row in rows_t.items():
+        assert np.all(row <= rmax)
+        hit = res.row_arg.get()[0] == f
+        np.testing.assert_array_equal(row[hit], rmax[hit])
+
+
 def test_c3_shape_multi_template_peaks():
     """Config C3 shape: 64 templates x 4096 samples vs a 2^24-sample rx, no frequency scan;
     per-template (delay, |peak|) and the across-template maximum per delay."""
