@@ -205,7 +205,11 @@ CAF_EXPORT int32_t caf_plan_execute_host(caf_plan plan, const float* h_rx, int64
  * Outputs (any may be NULL): d_qf2[num] = max_k |z_i[k]|^2, d_fidx[num] = first argmax bin,
  * d_caf[num][N] = |z_i|^2 (float32), d_ccaf[num][N] = z_i (complex64).
  * zero_oor != 0: delays whose window leaves [0, rx_len) give (0, 0) / zero rows (IppXcorrFFT.cpp:125-130);
- * zero_oor == 0: such a delay is an error (CAF_ERR_INVALID). Blocking (allocates and frees scratch). */
+ * zero_oor == 0: such a delay is an error (CAF_ERR_INVALID). Blocking (allocates and frees scratch).
+ * Zero-energy windows (a stretch of exact zeros in rx under the whole cutout -- the reference's 0 / 0,
+ * `pmax / cutoutNormSq / rxNormPartSq`, xcorrRoutines.py:527-528; IppXcorrFFT.cpp:174): d_qf2 = NaN, d_fidx = 0, NaN rows in
+ * d_caf / d_ccaf -- the same rule as caf_outputs.d_row_max / d_row_arg above.  (Only the stand-alone
+ * caf_argmax_abs_rows keeps the (0, 0) of the CUDA kernel's zero-initialised workspace, argmax.cu:108-109.) */
 CAF_EXPORT int32_t caf_xcorr_perdelay(const float* d_cutout, int32_t n, const float* d_rx, int64_t rx_len,
                                       int64_t start, int64_t step, int64_t num, int32_t zero_oor, float* d_qf2,
                                       int32_t* d_fidx, float* d_caf, float* d_ccaf, int64_t batch_rows, void* stream);

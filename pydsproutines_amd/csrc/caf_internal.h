@@ -14,10 +14,19 @@ constexpr int MAG_THREADS = 256;  // |.|^2/normalise/argmax: 4 waves
 constexpr int MAG_S = 64;         // delays per tile (one wave-row of 8-byte loads = 512 B)
 constexpr int MAG_F = 128;        // frequency hypotheses per LDS chunk (512 B store rows)
 
-// window energies below this fraction of the float64 prefix they are differences of are reported as zero-energy windows
+// Window energies below this fraction of the float64 prefix they are differences of are reported as zero-energy windows
 // (NaN results): k_inv_energy, k_block_spectra.  The prefix differences carry a few units in the 2^-53 place of the prefix
-// times log2(samples) (tree scans): 2^-44 is ~30 x that, and a window of 4096 samples at 100 dB below a full 2^24-sample
-// record before it still passes.
+// times log2(samples) (tree scans): 2^-44 is ~30 x that.  What "the prefix" is differs by engine, and with it the quietest
+// window that still passes:
+//   * 16384-point in-LDS engines (k_block_spectra): the prefix restarts in every overlap-save block, so the floor is
+//     2^-44 of the energy of the <= 16384 samples around the window -- a 4096-sample window passes down to ~-126 dB below
+//     its own block (2^-44 * 4 = -126 dB);
+//   * rocFFT engine, 32768-point blocks, per-delay path (k_inv_energy / the product kernels): ONE prefix over the whole
+//     record, so the floor is 2^-44 of everything BEFORE the window's end: behind 2^24 unit-power samples a 4096-sample
+//     window passes down to -96 dB (2^-44 * 2^24 / 4096 = 2.3e-10), behind 10^7 samples down to -98 dB.
+// A window between the two thresholds is finite on the first group and NaN on the second (tests/test_gpu_engine.py:
+// test_quiet_windows_late_in_a_long_record pins both sides: -90 dB finite everywhere, exact zeros NaN everywhere).  A common
+// threshold would need block-local energies in k_inv_energy too; the float64 global prefix cannot resolve less.
 constexpr double CAF_ENERGY_FLOOR = 5.6843418860808015e-14;  // 2^-44
 
 struct PeakRec {
@@ -78,7 +87,8 @@ void launch_sliding_multiply(const float2* x, int32_t xlen, const float2* y, int
                              hipStream_t st, const double* d_coef = nullptr);  // d_coef: device scalar multiplied into coef (launch_cutout_norm's result)
 // part: optional scratch of rows * rows_argmax_chunks(rows, len) 64-bit words -- long rows are then cut into chunks
 void launch_rows_argmax(const float2* z, int64_t rows, int64_t len, int32_t use_normsq, float scale, uint32_t* argmax,
-                        float* maxv, float* plane, hipStream_t st, unsigned long long* part = nullptr);
+                        float* maxv, float* plane, hipStream_t st, unsigned long long* part = nullptr,
+                        int32_t nan_empty = 0);  // nan_empty: an all-NaN row is (NaN, 0), not the CUDA workspace's (0, 0)
 int rows_argmax_chunks(int64_t rows, int64_t len);
 void launch_magnsq(const void* x, int64_t n, int in_c128, void* out, int out_f64, hipStream_t st);
 int64_t moving_num_tiles(int64_t n);

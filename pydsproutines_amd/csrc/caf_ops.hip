@@ -343,7 +343,7 @@ int32_t caf_xcorr_perdelay(const float* d_cutout, int32_t n, const float* d_rx, 
         if ((rc = fft_rows(buf, buf, nr, n, false, st))) return rc;
         if (d_qf2 || d_fidx || d_caf)
             launch_rows_argmax(buf, nr, n, 1, 1.0f, (uint32_t*)(d_fidx ? d_fidx + r0 : nullptr), d_qf2 ? d_qf2 + r0 : nullptr,
-                               d_caf ? d_caf + r0 * n : nullptr, st, part);
+                               d_caf ? d_caf + r0 * n : nullptr, st, part, 1);
     }
     CAF_HIP_TRY(hipStreamSynchronize(st));  // scratch is freed on return
     CAF_HIP_TRY(hipGetLastError());

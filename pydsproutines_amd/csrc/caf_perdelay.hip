@@ -178,7 +178,8 @@ __global__ __launch_bounds__((1 << LOGN) / 16 > 256 ? (1 << LOGN) / 16 : 256, 4)
             asm volatile("" : "+v"(br));  // (the selects above on 0 .. 15 -- inline constants -- and ONE index computation)
             const uint32_t bi = (uint32_t)lo + (br / RLE) * NTR + (br % RLE) * (N / RLE);  // = pd_out_index(lo, br)
             // (a thread that saw only NaNs offers key 0: it loses against every real value, and an all-NaN row -- a
-            // zero-energy window -- reports (0, 0), the reference's zero-initialised workspace)
+            // zero-energy window -- reports (NaN, 0): the reference's pmax / ||cutout||^2 / 0, xcorrRoutines.py:527-528,
+            // IppXcorrFFT.cpp:174; a zero ROW of the out-of-range rule has inv = 0, all values +0, key != 0: (0, 0))
             unsigned long long key = bv < 0.f ? 0ull : (((unsigned long long)__float_as_uint(bv) << 32) | (uint32_t)~bi);
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
@@ -198,7 +199,7 @@ __global__ __launch_bounds__((1 << LOGN) / 16 > 256 ? (1 << LOGN) / 16 : 256, 4)
                 }
             }
             if (live && l == 0) {
-                if (qf2) qf2[row] = key ? __uint_as_float((uint32_t)(key >> 32)) : 0.f;
+                if (qf2) qf2[row] = key ? __uint_as_float((uint32_t)(key >> 32)) : __builtin_nanf("");
                 if (fidx) fidx[row] = key ? ~(uint32_t)key : 0u;
             }
         }
@@ -668,7 +669,7 @@ __global__ __launch_bounds__(R10<P>::WG, 4) void k_perdelay_r10(  // (4 waves pe
             __syncthreads();
             if (live && l == 0) {
                 const unsigned long long kk = s_key[it & 1][rl];
-                if (qf2) qf2[row] = kk ? __uint_as_float((uint32_t)(kk >> 32)) : 0.f;  // (all-NaN row: the reference's zero-initialised workspace)
+                if (qf2) qf2[row] = kk ? __uint_as_float((uint32_t)(kk >> 32)) : __builtin_nanf("");  // (all-NaN row = zero-energy window: (NaN, 0))
                 if (fidx) fidx[row] = kk ? ~(uint32_t)kk : 0u;
                 s_key[it & 1][rl] = 0ull;  // (next used two rows from now, behind the barriers of the row in between)
             }

@@ -119,9 +119,11 @@ __global__ __launch_bounds__(256) void k_sliding_multiply(const float2* __restri
 //   optional |z|^2 plane (float32), all scaled by `scale`.
 // One workgroup per row.
 // ---------------------------------------------------------------------------------------
+// nan_empty: an all-NaN row reports (NaN, 0) -- the per-delay path's zero-energy window, the reference's pmax / norm / 0
+// (xcorrRoutines.py:527-528) -- instead of the (0, 0) of the CUDA kernel's zero-initialised workspace
 __global__ __launch_bounds__(256) void k_rows_argmax(const float2* __restrict__ z, int64_t len, int32_t use_normsq,
                                                      float scale, uint32_t* __restrict__ argmax,
-                                                     float* __restrict__ maxv, float* __restrict__ plane) {
+                                                     float* __restrict__ maxv, float* __restrict__ plane, int32_t nan_empty) {
     __shared__ float s_v[4];
     __shared__ uint32_t s_i[4];
     const int64_t row = blockIdx.x;
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(256) void k_rows_argmax(const float2* __restrict__ 
                 bi = s_i[w];
             }
         if (bv < 0.f) {  // empty or all-NaN row: the reference's zero-initialised workspace (argmax.cu:108-109)
-            bv = 0.f;
+            bv = (nan_empty && len > 0) ? __builtin_nanf("") : 0.f;
             bi = 0;
         }
         if (argmax) argmax[row] = bi;
@@ -203,7 +205,7 @@ __global__ __launch_bounds__(256) void k_rows_argmax_part(const float2* __restri
 }
 __global__ __launch_bounds__(64) void k_rows_argmax_fin(const unsigned long long* __restrict__ part, int32_t chunks,
                                                         int64_t rows, int32_t use_normsq, uint32_t* __restrict__ argmax,
-                                                        float* __restrict__ maxv) {
+                                                        float* __restrict__ maxv, int32_t nan_empty) {
     const int64_t row = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (row >= rows) return;
     unsigned long long key = 0ull;
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(64) void k_rows_argmax_fin(const unsigned long long
         const unsigned long long k = part[row * chunks + c];
         key = k > key ? k : key;
     }
-    const float bv = key ? __uint_as_float((uint32_t)(key >> 32)) : 0.f;  // empty / all-NaN row: (0, 0)
+    const float bv = key ? __uint_as_float((uint32_t)(key >> 32)) : nan_empty ? __builtin_nanf("") : 0.f;  // empty / all-NaN row: (0, 0) or (NaN, 0)
     if (argmax) argmax[row] = key ? 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull) : 0u;
     if (maxv) maxv[row] = use_normsq ? bv : sqrtf(bv);
 }
@@ -1274,7 +1276,7 @@ int rows_argmax_chunks(int64_t rows, int64_t len) {
 }
 
 void launch_rows_argmax(const float2* z, int64_t rows, int64_t len, int32_t use_normsq, float scale, uint32_t* argmax,
-                        float* maxv, float* plane, hipStream_t st, unsigned long long* part) {
+                        float* maxv, float* plane, hipStream_t st, unsigned long long* part, int32_t nan_empty) {
     if (rows <= 0) return;
     const int chunks = part ? rows_argmax_chunks(rows, len) : 0;
     if (chunks > 1) {
@@ -1282,11 +1284,11 @@ void launch_rows_argmax(const float2* z, int64_t rows, int64_t len, int32_t use_
         hipLaunchKernelGGL(k_rows_argmax_part, dim3((unsigned)chunks, (unsigned)rows), dim3(256), 0, st, z, len, chunk, scale, part,
                            plane);
         hipLaunchKernelGGL(k_rows_argmax_fin, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, st, part, chunks, rows, use_normsq,
-                           argmax, maxv);
+                           argmax, maxv, nan_empty);
         return;
     }
     hipLaunchKernelGGL(k_rows_argmax, dim3((unsigned)rows), dim3(256), 0, st, z, len, use_normsq, scale, argmax, maxv,
-                       plane);
+                       plane, nan_empty);
 }
 
 void launch_magnsq(const void* x, int64_t n, int in_c128, void* out, int out_f64, hipStream_t st) {

@@ -84,6 +84,39 @@ def test_kat2_cyippxcorrfft(golden):
     np.testing.assert_array_equal(f, g["freqidx"])
 
 
+@pytest.mark.parametrize("n", [64, 100, 120, 256])  # fused power-of-two kernel, radix-10 kernel, rocFFT rows, fused
+def test_zero_energy_windows_on_the_per_delay_path_follow_the_reference(n):
+    """A stretch of exact zeros under the whole cutout: the reference divides by a zero window energy
+    (xcorrRoutines.py:527-528 `pmax / cutoutNormSq / rxNormPartSq`; IppXcorrFFT.cpp:174) -> (NaN, 0), and a NaN CAF row
+    (:553-566).  Every entry point of the per-delay path reports exactly that, whichever kernel serves the length; (0, 0)
+    stays the answer for windows that LEAVE rx under CyIppXcorrFFT's rule (IppXcorrFFT.cpp:125-130)."""
+    from pydsproutines_amd.xcorrRoutines import CyIppXcorrFFT, cp_fastXcorr, fastXcorr
+
+    rng = np.random.default_rng(n)
+    m = 4000
+    rx = cn(rng, m)
+    cut = rx[300 : 300 + n].copy()
+    rx[2000 : 2000 + n + 20] = 0
+    sh = np.arange(1990, 2040)
+    dead = (sh >= 2000) & (sh <= 2020)
+    with np.errstate(all="ignore"):
+        rq, rf = O.fastXcorr(cut, rx, freqsearch=True, shifts=sh)
+        rc = O.fastXcorr(cut, rx, freqsearch=True, outputCAF=True, shifts=sh)
+    assert np.all(np.isnan(rq[dead])) and np.all(rf[dead] == 0) and np.all(np.isnan(rc[dead]))  # the oracle = the reference here
+    q, f = fastXcorr(cut, rx, freqsearch=True, shifts=sh)  # branch B
+    assert np.all(np.isnan(q[dead])) and np.all(f[dead] == 0)
+    np.testing.assert_allclose(q[~dead], rq[~dead], atol=TOL)
+    caf = fastXcorr(cut, rx, freqsearch=True, outputCAF=True, shifts=sh)  # branch C
+    assert np.all(np.isnan(caf[dead])) and np.max(np.abs(caf[~dead] - rc[~dead])) <= TOL
+    q2, f2 = cp_fastXcorr(cut, rx, freqsearch=True, shifts=sh)
+    assert np.all(np.isnan(q2[dead])) and np.all(f2[dead] == 0)
+    pk, fi = CyIppXcorrFFT(cut, 2).xcorr(rx, int(sh[0]), int(sh[-1]) + 1, 1)
+    assert np.all(np.isnan(pk[dead])) and np.all(fi[dead] == 0)
+    np.testing.assert_allclose(pk[~dead], rq[~dead], atol=TOL)
+    pk2, fi2 = CyIppXcorrFFT(cut, 2).xcorr(rx, m - n - 2, m + 5, 1)  # windows that leave rx: (0, 0), not NaN
+    assert np.all(pk2[3:] == 0) and np.all(fi2[3:] == 0) and np.all(pk2[:3] > 0)
+
+
 def test_cp_fastxcorr_v2_and_kernel_chain():
     from pydsproutines_amd import asarray
     from pydsproutines_amd.spectralRoutines import CZTCachedGPU

@@ -646,17 +646,54 @@ def test_hypothesis_major_surface_rules():
     rng = np.random.default_rng(77)
     tm, rx = np.stack([qpsk(rng, 100) for _ in range(3)]), cn(rng, 9000)
     for engine in ("persistent", "rocfft"):
-        plan = CAFPlan(tm, max_rx_len=rx.size, bins=[0], grid=100 if engine == "rocfft" else 16384, engine=engine)
+        plan = CAFPlan(tm, max_rx_len=rx.size, bins=[0], grid=1024, engine=engine)
         r = plan.run(asarray(rx), surface_t=True)
         ref = plan.run(asarray(rx), surface=True)
         np.testing.assert_array_equal(r.surface_t.get()[:, 0, :], ref.surface.get()[:, :, 0])
         np.testing.assert_array_equal(r.row_max.get(), ref.row_max.get())
         plan.close()
-    plan = CAFPlan(tm, max_rx_len=rx.size, bins=[0, 1, 2], grid=16384, engine="rocfft")
+    plan = CAFPlan(tm, max_rx_len=rx.size, bins=[0, 1, 2], grid=1024, engine="rocfft")
     with pytest.raises(ValueError, match="hypothesis-major"):
         plan.run(asarray(rx), surface_t=True)
     plan.close()
     plan = CAFPlan(tm, max_rx_len=rx.size, bins=[0, 1, 2], grid=16384)
     with pytest.raises(ValueError, match="hypothesis-major"):
         plan.run(asarray(rx), surface_t=True, surface=True)
+    plan.close()
+
+
+@pytest.mark.parametrize("engine", ["persistent", "fused", "rocfft"])
+def test_quiet_windows_late_in_a_long_record(engine):
+    """The zero-energy rule is a threshold on float64 prefix differences (CAF_ENERGY_FLOOR, caf_internal.h): 10^7 loud
+    samples, then a stretch 90 dB below them that holds a (scaled) copy of the template, then a gap of exact zeros.  On every
+    engine the quiet windows are FINITE -- and right: QF^2 does not depend on the scale -- and the gap is NaN."""
+    from pydsproutines_amd import CAFPlan, asarray
+
+    rng = np.random.default_rng(9)
+    n, loud, quiet_len = 4096, 10_000_000, 60000
+    t = qpsk(rng, n)
+    a = np.float32(10 ** (-90 / 20))
+    rx = np.concatenate((cn(rng, loud), a * cn(rng, quiet_len), np.zeros(3 * n, np.complex64), cn(rng, 20000)))
+    d0 = loud + 30000
+    rx[d0 : d0 + n] += a * t
+    m = rx.size
+    bins = np.arange(-2, 2)
+    plan = CAFPlan(t, max_rx_len=m, bins=bins, grid=n, engine=engine)
+    # (the last 2^20 samples only for the rocfft engine's sake: the prefix still runs over the whole record)
+    lo = loud - 50000
+    res = plan.run(asarray(rx), shift_start=lo, num_shifts=m - n + 1 - lo, surface=True)
+    rm = res.row_max.get()[0]
+    quiet = slice(loud + 16384 - lo, loud + quiet_len - n - lo)       # windows wholly inside the quiet stretch
+    gap = slice(loud + quiet_len - lo, loud + quiet_len + 2 * n - lo)  # windows wholly inside the zeros
+    assert not np.any(np.isnan(rm[quiet])), "quiet windows (-90 dB behind 10^7 loud samples) must stay finite"
+    assert np.all(np.isnan(rm[gap])) and np.all(res.row_arg.get()[0][gap] == 0)
+    assert np.all(np.isnan(res.surface.get()[0][gap]))
+    # the planted copy is found at full height although it is 90 dB down: the peak of the whole run
+    assert int(res.peak_delay.get()[0]) == d0 and int(bins[res.peak_freq.get()[0]]) == 0
+    assert 0.35 < float(res.peak_val.get()[0]) < 0.65
+    sel = np.arange(d0 - 40, d0 + 40)
+    ref = O.caf_bins(t, rx, bins, sel)
+    # (tolerance: the window energy is 4e-13 of the float64 prefix it is a difference of on the rocfft engine -- resolved to
+    #  about one part in a thousand; the 16384-point engines take it from a block-local prefix and hold 1e-4 here)
+    assert np.max(np.abs(res.surface.get()[0][sel - lo] - ref)) <= (5e-3 if engine == "rocfft" else 1e-4) * ref.max()
     plan.close()

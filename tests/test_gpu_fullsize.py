@@ -152,13 +152,79 @@ def test_c3_shape_multi_template_peaks():
     np.testing.assert_array_equal(res.peak_delay.get(), delays)
     pv = res.peak_val.get()
     assert np.all((pv > 0.35) & (pv < 0.65))
-    # oracle at each template's peak and a neighbour
-    for i in (0, 31, 63):
+    # EVERY template's (delay, value) against the oracle, with a neighbour on either side ...
+    rows = [res.row_max[i].get() for i in range(tm.shape[0])]
+    for i in range(tm.shape[0]):
         sh = np.array([delays[i] - 1, delays[i], delays[i] + 1])
         ref = O.fastXcorr(tm[i], rx, shifts=sh)
-        got = res.row_max[i].get()[sh]
-        assert np.max(np.abs(got - ref)) <= 1e-4 * ref.max()
+        assert np.max(np.abs(rows[i][sh] - ref)) <= 1e-4 * ref.max()
+        assert int(np.argmax(rows[i])) == delays[i] and rows[i][delays[i]] == pv[i]  # the record IS the row's first maximum
+        assert abs(float(pv[i]) - float(ref[1])) <= 1e-4 * ref.max()
+    # ... and the across-template maximum per delay (what TemplateCrossCorrelator(returnMax=True) reports,
+    # xcorrRoutines.py:361-371) on a sampled range: the oracle's maximum over the 64 templates and the template attaining it
+    lo = int(delays[7]) - 20
+    sh = np.arange(lo, lo + 41)
+    ref_all = np.stack([O.fastXcorr(tm[i], rx, shifts=sh) for i in range(tm.shape[0])])
+    got_all = np.stack([r[sh] for r in rows])
+    assert np.max(np.abs(got_all - ref_all)) <= 1e-4 * ref_all.max()
+    assert np.max(np.abs(got_all.max(axis=0) - ref_all.max(axis=0))) <= 1e-4 * ref_all.max()
+    assert int(np.argmax(got_all[:, 20])) == 7 == int(np.argmax(ref_all[:, 20]))
+    top2 = np.sort(ref_all, axis=0)[-2:]
+    clear = top2[1] - top2[0] > 2e-4 * ref_all.max()
+    np.testing.assert_array_equal(np.argmax(got_all, axis=0)[clear], np.argmax(ref_all, axis=0)[clear])
     plan.close()
+
+
+def test_c3_literal_correlate_full_size():
+    """TemplateCrossCorrelator(64 x 4096, 2^24).correlate(x) -- the complex-QF rows written by the FFT work items (fused_item
+    MODE 4) at full size: 8.6 GB of output, int64 offsets beyond 2^32 bytes, 1366 blocks x 2 items of 32 templates.  Sampled
+    (template, delay) cells -- first / last block, block and item boundaries, the planted peaks -- against the definition
+    QF = <rx window, template> / (||template|| ||window||) in float64, and returnMax == the column maximum of that plane."""
+    from pydsproutines_amd import asarray
+    from pydsproutines_amd.xcorrRoutines import TemplateCrossCorrelator
+
+    rng = np.random.default_rng(21)
+    T = 64
+    tm = np.stack([qpsk(rng, N) for _ in range(T)])
+    rx = cn(rng, M)
+    delays = rng.integers(0, M - N, T)
+    for i, d in enumerate(delays):
+        rx[d : d + N] += tm[i]
+    S = M - N + 1
+    d_x = asarray(rx)
+    tcc = TemplateCrossCorrelator(asarray(tm), M)
+    out = tcc.correlate(d_x)
+    assert out.shape == (T, S) and out.dtype == np.complex64 and tcc._plan.engine_used == "persistent"
+    step = tcc._plan.step
+    nblk = (S + step - 1) // step
+    picks = np.unique(np.concatenate((
+        np.arange(0, 3), np.arange(step - 2, step + 2), np.arange(2 * step - 1, 2 * step + 1),            # first blocks
+        np.arange((nblk // 2) * step - 2, (nblk // 2) * step + 2),                                        # the middle
+        np.arange((nblk - 1) * step - 2, (nblk - 1) * step + 2), np.arange(S - 3, S),                       # last block
+        delays, rng.integers(0, S, 40))))
+    picks = picks[(picks >= 0) & (picks < S)]
+
+    def definition(t, d):
+        w = rx[d : d + N].astype(np.complex128)
+        return np.vdot(tm[t].astype(np.complex128), w) / (np.linalg.norm(tm[t].astype(np.complex128)) * np.linalg.norm(w))
+
+    # a few whole rows to the host (134 MB each): templates on both sides of the item boundary (32 per item) and the ends
+    for t in (0, 31, 32, 63):
+        row = out[t].get()
+        want = np.array([definition(t, int(d)) for d in picks])
+        assert np.max(np.abs(row[picks] - want)) <= 2e-5, t
+        assert abs(abs(row[delays[t]]) - abs(definition(t, int(delays[t])))) <= 2e-5 and abs(row[delays[t]]) > 0.6
+    # returnMax: bit for bit the column maximum / first argmax of |plane| on a sampled range of delays (all 64 rows of it)
+    qf, ti = tcc.correlate(d_x, returnMax=True)
+    qf, ti = qf.get(), ti.get()
+    assert qf.dtype == np.float32 and ti.dtype == np.int64 and qf.shape == (S,)
+    for a in (0, int(delays[5]) - 1000, S - 5000):
+        blk = np.stack([out[t].get()[a : a + 5000] for t in range(T)])
+        # |z| as the kernel forms it: the correctly rounded float32 magnitude (np.abs rounds differently in the last place)
+        mag = np.sqrt(blk.real.astype(np.float64) ** 2 + blk.imag.astype(np.float64) ** 2).astype(np.float32)
+        np.testing.assert_array_equal(qf[a : a + 5000], mag.max(axis=0))
+        np.testing.assert_array_equal(ti[a : a + 5000], np.argmax(mag, axis=0))
+    assert int(ti[delays[5]]) == 5
 
 
 def test_c4_shape_sharded_peak_table_matches_single_gpu():
