@@ -140,6 +140,11 @@ int launch_perdelay_decimal(const float2* x, int32_t n, const float2* y, int64_t
 int launch_perdelay_fused(const float2* x, int32_t n, const float2* y, int64_t ylen, int64_t start, int64_t step,
                           int64_t num, int32_t zero_oor, float* qf2, uint32_t* fidx, float* plane, float2* cplane,
                           hipStream_t st);
+// cutouts of 2^a 3^b 5^c samples that are neither of the above (32 <= n <= 16200): mixed-radix in-LDS transform (caf_perdelay_mr.hip)
+bool perdelay_mixed_ok(int32_t n);
+int launch_perdelay_mixed(const float2* x, int32_t n, const float2* y, int64_t ylen, const double* prefix, const double* xnorm,
+                          int64_t start, int64_t step, int64_t num, int32_t zero_oor, float* qf2, uint32_t* fidx, float* plane,
+                          float2* cplane, hipStream_t st);
 int cutout_norm_scratch_doubles();
 const double* launch_cutout_norm(const float2* x, int64_t n, double* parts, hipStream_t st);  // -> device address of ||x||
 // e^{+j 2 pi q / 16384}, q < 16384: the twiddle table of the in-LDS transforms (caf_ldsfft.h), built once per device

@@ -506,38 +506,6 @@ struct R10 {
 };
 __device__ __forceinline__ int r10_pad(int a) { return a + a / 10; }
 
-// inverse 5-point DFT (kernel e^{+j 2 pi n k / 5})
-__device__ __forceinline__ void idft5(float2& x0, float2& x1, float2& x2, float2& x3, float2& x4) {
-    constexpr float C1 = 0.30901699437494742f, C2 = -0.80901699437494742f;  // cos(2 pi / 5), cos(4 pi / 5)
-    constexpr float S1 = 0.95105651629515357f, S2 = 0.58778525229247313f;   // sin(2 pi / 5), sin(4 pi / 5)
-    const float2 t1 = cadd(x1, x4), t2 = cadd(x2, x3), t3 = csub(x1, x4), t4 = csub(x2, x3);
-    const float2 a1 = make_float2(x0.x + C1 * t1.x + C2 * t2.x, x0.y + C1 * t1.y + C2 * t2.y);
-    const float2 a2 = make_float2(x0.x + C2 * t1.x + C1 * t2.x, x0.y + C2 * t1.y + C1 * t2.y);
-    const float2 b1 = make_float2(S1 * t3.x + S2 * t4.x, S1 * t3.y + S2 * t4.y);
-    const float2 b2 = make_float2(S2 * t3.x - S1 * t4.x, S2 * t3.y - S1 * t4.y);
-    x0 = make_float2(x0.x + t1.x + t2.x, x0.y + t1.y + t2.y);
-    x1 = make_float2(a1.x - b1.y, a1.y + b1.x);  // a1 + j b1
-    x4 = make_float2(a1.x + b1.y, a1.y - b1.x);  // a1 - j b1
-    x2 = make_float2(a2.x - b2.y, a2.y + b2.x);
-    x3 = make_float2(a2.x + b2.y, a2.y - b2.x);
-}
-// inverse 10-point DFT in place: X[k] = E[k mod 5] + W10^k O[k mod 5]
-__device__ __forceinline__ void idft10(float2 (&v)[10]) {
-    float2 e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6], e4 = v[8];
-    float2 o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7], o4 = v[9];
-    idft5(e0, e1, e2, e3, e4);
-    idft5(o0, o1, o2, o3, o4);
-    // W10^k = e^{+j 2 pi k / 10}, k = 1 .. 4
-    o1 = cmul(o1, make_float2(0.80901699437494742f, 0.58778525229247313f));
-    o2 = cmul(o2, make_float2(0.30901699437494742f, 0.95105651629515357f));
-    o3 = cmul(o3, make_float2(-0.30901699437494742f, 0.95105651629515357f));
-    o4 = cmul(o4, make_float2(-0.80901699437494742f, 0.58778525229247313f));
-    v[0] = cadd(e0, o0), v[5] = csub(e0, o0);
-    v[1] = cadd(e1, o1), v[6] = csub(e1, o1);
-    v[2] = cadd(e2, o2), v[7] = csub(e2, o2);
-    v[3] = cadd(e3, o3), v[8] = csub(e3, o3);
-    v[4] = cadd(e4, o4), v[9] = csub(e4, o4);
-}
 // one Stockham pass of radix 10 with Ns = 10^(pass index): butterfly j = l of the row; tw10 = W_N^q, q < N
 template <int P, int NS, bool FIRST, bool LAST>
 __device__ __forceinline__ void r10_pass(float2* __restrict__ buf, const float2* __restrict__ tw10, int l, bool active, float2 (&v)[10]) {

@@ -1,0 +1,379 @@
+// Per-delay correlator for cutouts of N = 2^a 3^b 5^c samples (32 <= N <= 16200, N neither a power of two nor of ten: those
+// have kernels of their own in caf_perdelay.hip): rx window x conj(cutout) -> N-point FFT in LDS -> |.|^2 -> (max, first
+// argmax) per delay, in ONE kernel -- the reference's literal per-delay algorithm (fastXcorr branches B / C,
+// xcorrRoutines.py:511-566; cp_fastXcorr :29-167, whose cutout length is a free argument, benchmark_xcorrs.py:62-71;
+// IppXcorrFFT.cpp:94-178) without the (rows, N) product matrix that the product kernel -> rocFFT rows -> argmax chain
+// moves through HBM four times.
+//
+// Mixed-radix Stockham autosort transform, radices from {16, 10, 8, 5, 4, 3, 2}, chosen on the host (fewest passes, the
+// largest first).  The lengths are too many to instantiate one kernel each, so the passes after the first are driven by
+// a small plan in the kernel arguments: a uniform switch picks the butterfly, the trip counts are compile-time bounds with
+// a guard (a thread owns up to MR_PT = 20 points: floor(20 / R) butterflies of radix R), divisions by the pass stride are
+// multiplications by a host-prepared reciprocal.  Only the FIRST radix is a template parameter: that pass is the one with
+// the global loads.  One LDS image per row (padded by one element per sixteen), inputs
+// read before a barrier and outputs written after it; ceil(N / 16) threads per row, several rows per workgroup for short
+// cutouts.  Window energies from the caller's float64 prefix and ||cutout|| from launch_cutout_norm, exactly as the
+// three-kernel form and the radix-10 kernel normalise; same out-of-range and zero-energy rules (include/caf.h).
+#include <algorithm>
+#include <cmath>
+#include <complex>
+#include <cstring>
+#include <functional>
+#include <mutex>
+#include <vector>
+
+#include "caf_internal.h"
+#include "caf_fft_dev.h"
+
+namespace caf {
+namespace {
+
+constexpr int MR_MAXP = 8;  // passes (2^14 as radix-2 passes would need 14: the planner never produces more than 7)
+constexpr int MR_PT = 20;   // points per thread and pass
+
+struct MrPlan {
+    int32_t n, tpr, rpw, npass, img;      // length, threads per row, rows per workgroup, passes, padded row image (elements)
+    int32_t radix[MR_MAXP], ns[MR_MAXP];  // pass p: radix, product of the radices before it
+    uint32_t ns_rcp[MR_MAXP];             // floor(2^32 / ns) + 1: j / ns == umulhi(j, ns_rcp) for j < 2^16
+};
+
+__device__ __forceinline__ int mr_pad(int a) { return a + (a >> 4); }
+
+template <int R>
+__device__ __forceinline__ void mr_idft(float2* v) {
+    if constexpr (R == 2) idft2(v[0], v[1]);
+    if constexpr (R == 3) idft3(v[0], v[1], v[2]);
+    if constexpr (R == 4) idft4(v[0], v[1], v[2], v[3]);
+    if constexpr (R == 5) idft5(v[0], v[1], v[2], v[3], v[4]);
+    if constexpr (R == 8) idft8(*reinterpret_cast<float2(*)[8]>(v));
+    if constexpr (R == 10) idft10(*reinterpret_cast<float2(*)[10]>(v));
+    if constexpr (R == 16) idft16(*reinterpret_cast<float2(*)[16]>(v));
+}
+
+// What a finished row leaves: planes, (max, first argmax).  Register (c, t) of the last pass <-> spectrum index
+// l + c tpr + t ns (ns = N / R there); visited t-major, so ascending, and a strict comparison keeps the first maximum.
+struct MrRowOut {
+    float inv;
+    bool live;
+    int64_t row;
+    float* plane;
+    float2* cplane;
+    bool want_key;
+    unsigned long long* key_slot;
+};
+template <int R>
+__device__ __forceinline__ void mr_epilogue(const MrPlan& pl, const float2 (&v)[MR_PT], int l, bool active, int nb, int ns,
+                                            const MrRowOut& o) {
+    constexpr int CNT = MR_PT / R;
+    const float inv = o.inv;
+    if ((o.plane || o.cplane) && o.live) {
+        float* prow = o.plane ? o.plane + o.row * pl.n : nullptr;
+        float2* crow = o.cplane ? o.cplane + o.row * pl.n : nullptr;
+#pragma unroll
+        for (int t = 0; t < R; ++t)
+#pragma unroll
+            for (int c = 0; c < CNT; ++c) {
+                const int j = l + c * pl.tpr;
+                if (j < nb) {
+                    const float zr = v[c * R + t].x * inv, zi = v[c * R + t].y * inv;
+                    if (prow) prow[j + t * ns] = __builtin_fmaf(zr, zr, zi * zi);
+                    if (crow) crow[j + t * ns] = make_float2(zr, -zi);
+                }
+            }
+    }
+    if (o.want_key) {
+        float bv = -1.f;
+        uint32_t bi = 0;
+#pragma unroll
+        for (int t = 0; t < R; ++t)
+#pragma unroll
+            for (int c = 0; c < CNT; ++c) {
+                const int j = l + c * pl.tpr;
+                const float zr = v[c * R + t].x * inv, zi = v[c * R + t].y * inv;
+                const float val = __builtin_fmaf(zr, zr, zi * zi);
+                if (j < nb && val > bv) {
+                    bv = val;
+                    bi = (uint32_t)(j + t * ns);
+                }
+            }
+        // (a thread that saw only NaNs offers nothing: an all-NaN row -- a zero-energy window -- keeps key 0)
+        const unsigned long long key = bv < 0.f ? 0ull : (((unsigned long long)__float_as_uint(bv) << 32) | (uint32_t)~bi);
+        if (o.live && active && key) atomicMax(o.key_slot, key);
+    }
+}
+
+// One Stockham pass of radix R with ns = the product of the earlier radices.  first: the inputs are in v already and there
+// is no twiddle; last: the outputs stay in v (mr_epilogue).  Returns with the image written and published (barrier).
+template <int R>
+__device__ __forceinline__ void mr_pass(const MrPlan& pl, int p, float2* __restrict__ buf, const float2* __restrict__ tw, int l_in,
+                                        bool active, bool first, bool last, float2 (&v)[MR_PT], const MrRowOut& o) {
+    constexpr int CNT = MR_PT / R;
+    const int nb = pl.n / R, ns = pl.ns[p], tpr = pl.tpr;
+    // (an opaque copy of the lane's index: the image addresses of a radix depend on nothing that changes from row to row,
+    //  and hoisted out of the row loop -- twenty per radix, seven radices -- they were spilled: ~330 registers of scratch)
+    int l = l_in;
+    asm volatile("" : "+v"(l));
+    if (!first) {
+#pragma unroll
+        for (int c = 0; c < CNT; ++c) {
+            const int j = l + c * tpr;
+            if (active && j < nb) {
+#pragma unroll
+                for (int t = 0; t < R; ++t) v[c * R + t] = buf[mr_pad(j + t * nb)];
+            }
+        }
+        __syncthreads();  // every butterfly has its inputs: the image may be overwritten
+    }
+    const int tws = nb / ns;  // W_{R ns}^k = W_N^{k N / (R ns)}
+    int dst[CNT];
+#pragma unroll
+    for (int c = 0; c < CNT; ++c) {
+        const int j = l + c * tpr;
+        const int k = first ? 0 : j - ns * (int)__umulhi((uint32_t)j, pl.ns_rcp[p]);
+        dst[c] = (j - k) * R + k;
+        if (!first && j < nb) {
+            const float2 w1 = tw[k * tws];
+            float2 pw = w1;
+            v[c * R + 1] = cmul(v[c * R + 1], pw);
+#pragma unroll
+            for (int t = 2; t < R; ++t) {
+                pw = cmul(pw, w1);
+                v[c * R + t] = cmul(v[c * R + t], pw);
+            }
+        }
+        mr_idft<R>(&v[c * R]);
+    }
+    if (last) {
+        mr_epilogue<R>(pl, v, l, active, nb, ns, o);
+        return;
+    }
+#pragma unroll
+    for (int c = 0; c < CNT; ++c) {
+        const int j = l + c * tpr;
+        if (active && j < nb) {
+#pragma unroll
+            for (int t = 0; t < R; ++t) buf[mr_pad(dst[c] + t * ns)] = v[c * R + t];
+        }
+    }
+    __syncthreads();
+}
+
+// WGMAX: the largest workgroup the instance is launched with -- 512 for cutouts of up to 8192 samples (256 VGPRs per lane:
+// no spills), 1024 beyond (128 VGPRs)
+template <int R0, int WGMAX>
+__global__ __launch_bounds__(WGMAX) void k_perdelay_mr(MrPlan pl, const float2* __restrict__ x, const float2* __restrict__ y,
+                                                       int64_t ylen, const float2* __restrict__ tw,
+                                                       const double* __restrict__ prefix, const double* __restrict__ xnorm,
+                                                       int64_t start, int64_t step, int64_t num, int32_t rows_per_wg,
+                                                       int32_t zero_oor, float* __restrict__ qf2, uint32_t* __restrict__ fidx,
+                                                       float* __restrict__ plane, float2* __restrict__ cplane) {
+    extern __shared__ __attribute__((aligned(16))) float2 s_buf[];  // rpw row images, then 2 x rpw key slots
+    constexpr int CNT0 = MR_PT / R0;
+    const int tid = threadIdx.x, N = pl.n, tpr = pl.tpr, rpw = pl.rpw, nb0 = N / R0;
+    unsigned long long* s_key = reinterpret_cast<unsigned long long*>(s_buf + (size_t)rpw * pl.img);
+    const bool active = tid < rpw * tpr;  // (the last threads of the workgroup only keep the barriers company)
+    const int rl = active ? tid / tpr : 0, l = active ? tid - rl * tpr : 0;
+    float2* buf = s_buf + (size_t)rl * pl.img;
+    const double xn = *xnorm;
+    if (tid < 2 * rpw) s_key[tid] = 0ull;
+    __syncthreads();
+    const int64_t row0 = (int64_t)blockIdx.x * rows_per_wg * rpw;
+    for (int it = 0; it < rows_per_wg; ++it) {
+        const int64_t row = row0 + (int64_t)it * rpw + rl;
+        const bool live = active && row < num;
+        const int64_t s = start + row * step;
+        const bool oor = (s < 0) || (s + N > ylen);
+        const bool zero = !live || (oor && zero_oor);
+        float2 v[MR_PT];
+#pragma unroll
+        for (int c = 0; c < CNT0; ++c)
+#pragma unroll
+            for (int t = 0; t < R0; ++t) {
+                const int j = l + c * tpr;
+                const int64_t g = s + j + t * nb0;
+                const bool ok = !zero && j < nb0 && (!oor || (g >= 0 && g < ylen));
+                const float2 b = ok ? y[g] : make_float2(0.f, 0.f);
+                // (the cutout is re-read per row -- it stays in the L1 / L2 --: with 20 points per thread resident beside the
+                //  transform's 20 the passes spilled ~300 registers)
+                const float2 a = (active && j < nb0) ? x[j + t * nb0] : make_float2(0.f, 0.f);
+                v[c * R0 + t] = make_float2(a.x * b.x - a.y * b.y, -(a.x * b.y + a.y * b.x));  // conj(x y): see k_perdelay_fused
+            }
+        // normalisation exactly as the three-kernel form computes it (k_sliding_multiply): window energy from the prefix
+        MrRowOut o;
+        o.inv = 0.f;
+        if (!zero) {
+            const int64_t a = s < 0 ? 0 : (s > ylen ? ylen : s);
+            int64_t b = s + N;
+            b = b < 0 ? 0 : (b > ylen ? ylen : b);
+            o.inv = (float)(1.0 / (sqrt(prefix[b] - prefix[a]) * xn));
+        }
+        o.live = live;
+        o.row = row;
+        o.plane = plane;
+        o.cplane = cplane;
+        o.want_key = qf2 || fidx;
+        o.key_slot = &s_key[(it & 1) * rpw + rl];
+        mr_pass<R0>(pl, 0, buf, tw, l, active, true, pl.npass == 1, v, o);
+        for (int p = 1; p < pl.npass; ++p) {
+            const bool last = p + 1 == pl.npass;
+            switch (pl.radix[p]) {  // (uniform)
+                case 2: mr_pass<2>(pl, p, buf, tw, l, active, false, last, v, o); break;
+                case 3: mr_pass<3>(pl, p, buf, tw, l, active, false, last, v, o); break;
+                case 4: mr_pass<4>(pl, p, buf, tw, l, active, false, last, v, o); break;
+                case 5: mr_pass<5>(pl, p, buf, tw, l, active, false, last, v, o); break;
+                case 8: mr_pass<8>(pl, p, buf, tw, l, active, false, last, v, o); break;
+                case 10: mr_pass<10>(pl, p, buf, tw, l, active, false, last, v, o); break;
+                default: mr_pass<16>(pl, p, buf, tw, l, active, false, last, v, o); break;
+            }
+        }
+        if (o.want_key) {
+            __syncthreads();
+            if (live && l == 0) {
+                const unsigned long long kk = *o.key_slot;
+                if (qf2) qf2[row] = kk ? __uint_as_float((uint32_t)(kk >> 32)) : __builtin_nanf("");  // (zero-energy window: (NaN, 0))
+                if (fidx) fidx[row] = kk ? ~(uint32_t)kk : 0u;
+                *o.key_slot = 0ull;  // (next used two rows from now, behind the barriers of the row in between)
+            }
+        }
+    }
+}
+
+// fewest passes with radices from {16, 10, 8, 5, 4, 3, 2}; ties: the lexicographically largest sequence (big radices first)
+bool mr_factor(int32_t n, std::vector<int>& best) {
+    static const int radices[] = {16, 10, 8, 5, 4, 3, 2};
+    std::vector<int> cur;
+    best.clear();
+    bool found = false;
+    // (radices in non-increasing order: one representative per multiset; the first sequence with the fewest passes stays)
+    std::function<void(int32_t, int)> rec = [&](int32_t rem, int max_r) {
+        if (rem == 1) {
+            if (!found || cur.size() < best.size()) best = cur, found = true;
+            return;
+        }
+        if ((int)cur.size() >= MR_MAXP || (found && cur.size() + 1 >= best.size())) return;
+        for (int r : radices) {
+            if (r > max_r || rem % r) continue;
+            cur.push_back(r);
+            rec(rem / r, r);
+            cur.pop_back();
+        }
+    };
+    rec(n, 16);
+    return found;
+}
+
+// e^{+j 2 pi q / n}, q < n (built once per device and length; at most 64 tables are kept)
+int mr_twiddles(int device, int32_t n, const float2** out) {
+    static std::mutex mu;
+    static std::vector<std::pair<std::pair<int, int32_t>, float2*>> tabs;
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto& e : tabs)
+        if (e.first.first == device && e.first.second == n) {
+            *out = e.second;
+            return CAF_OK;
+        }
+    if (tabs.size() >= 64) {  // a caller sweeping lengths: drop the oldest table once nothing can be reading it any more
+        CAF_HIP_TRY(hipDeviceSynchronize());
+        (void)hipFree(tabs.front().second);
+        tabs.erase(tabs.begin());
+    }
+    std::vector<std::complex<float>> t(n);
+    for (int q = 0; q < n; ++q) {
+        const double ph = 2.0 * M_PI * (double)q / (double)n;
+        t[q] = std::complex<float>((float)std::cos(ph), (float)std::sin(ph));
+    }
+    float2* d = nullptr;
+    CAF_HIP_TRY(hipMalloc((void**)&d, (size_t)n * 8));
+    const hipError_t e = hipMemcpy(d, t.data(), (size_t)n * 8, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(d);
+        CAF_HIP_TRY(e);
+    }
+    tabs.push_back({{device, n}, d});
+    *out = d;
+    return CAF_OK;
+}
+
+template <int R0, int WGMAX>
+int mr_launch(const MrPlan& pl, size_t lds, int dev, const float2* x, const float2* y, int64_t ylen, const float2* tw,
+              const double* prefix, const double* xnorm, int64_t start, int64_t step, int64_t num, int32_t zero_oor, float* qf2,
+              uint32_t* fidx, float* plane, float2* cplane, hipStream_t st) {
+    // the LDS limit of the function is raised per device (a process may drive several), remembered under a lock
+    static std::mutex mu;
+    static std::vector<size_t> attr_bytes;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if ((int)attr_bytes.size() <= dev) attr_bytes.resize(dev + 1, 0);
+        if (lds > 65536 && attr_bytes[dev] < lds) {
+            CAF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_perdelay_mr<R0, WGMAX>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            163840));
+            attr_bytes[dev] = 163840;
+        }
+    }
+    const int wg = (pl.rpw * pl.tpr + 63) / 64 * 64;
+    const int64_t groups = (num + pl.rpw - 1) / pl.rpw;
+    const int32_t rows_per_wg = (int32_t)std::max<int64_t>(1, std::min<int64_t>(16, groups / 4096));
+    const int64_t nwg = (groups + rows_per_wg - 1) / rows_per_wg;
+    CAF_REQUIRE(nwg <= 0x7fffffff, "caf_xcorr_perdelay: too many delays for one launch");
+    hipLaunchKernelGGL((k_perdelay_mr<R0, WGMAX>), dim3((unsigned)nwg), dim3((unsigned)wg), lds, st, pl, x, y, ylen, tw, prefix, xnorm, start,
+                       step, num, rows_per_wg, zero_oor, qf2, fidx, plane, cplane);
+    CAF_HIP_TRY(hipGetLastError());
+    return CAF_OK;
+}
+
+}  // namespace
+
+bool perdelay_mixed_ok(int32_t n) {
+    if (n < 32 || n > 16200) return false;
+    int32_t r = n;
+    for (int p : {2, 3, 5})
+        while (r % p == 0) r /= p;
+    return r == 1;
+}
+
+int launch_perdelay_mixed(const float2* x, int32_t n, const float2* y, int64_t ylen, const double* prefix, const double* xnorm,
+                          int64_t start, int64_t step, int64_t num, int32_t zero_oor, float* qf2, uint32_t* fidx, float* plane,
+                          float2* cplane, hipStream_t st) {
+    std::vector<int> rad;
+    if (!perdelay_mixed_ok(n) || !mr_factor(n, rad)) {
+        set_error("launch_perdelay_mixed: unsupported length");
+        return CAF_ERR_INVALID;
+    }
+    int dev = 0;
+    CAF_HIP_TRY(hipGetDevice(&dev));
+    const float2* tw = nullptr;
+    int rc = mr_twiddles(dev, n, &tw);
+    if (rc) return rc;
+    MrPlan pl;
+    std::memset(&pl, 0, sizeof(pl));
+    pl.n = n;
+    pl.tpr = (n + 15) / 16;
+    pl.rpw = std::max(1, 256 / pl.tpr);
+    pl.npass = (int)rad.size();
+    pl.img = n + (n >> 4) + 1;
+    int32_t ns = 1;
+    for (int p = 0; p < pl.npass; ++p) {
+        pl.radix[p] = rad[p];
+        pl.ns[p] = ns;
+        pl.ns_rcp[p] = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)ns + 1);  // exact for j * ns < 2^32 (the first pass, ns = 1, never divides)
+        ns *= rad[p];
+    }
+    const size_t lds = (size_t)pl.rpw * pl.img * sizeof(float2) + (size_t)2 * pl.rpw * sizeof(unsigned long long);
+    CAF_REQUIRE(lds <= 163840, "launch_perdelay_mixed: row image does not fit the LDS");
+#define CAF_MR_GO(R)                                                                                                                   \
+    return pl.rpw * pl.tpr <= 512                                                                                                       \
+               ? mr_launch<R, 512>(pl, lds, dev, x, y, ylen, tw, prefix, xnorm, start, step, num, zero_oor, qf2, fidx, plane, cplane, st) \
+               : mr_launch<R, 1024>(pl, lds, dev, x, y, ylen, tw, prefix, xnorm, start, step, num, zero_oor, qf2, fidx, plane, cplane, st)
+    switch (rad[0]) {
+        case 2: CAF_MR_GO(2);
+        case 3: CAF_MR_GO(3);
+        case 4: CAF_MR_GO(4);
+        case 5: CAF_MR_GO(5);
+        case 8: CAF_MR_GO(8);
+        case 10: CAF_MR_GO(10);
+        default: CAF_MR_GO(16);
+    }
+#undef CAF_MR_GO
+}
+
+}  // namespace caf

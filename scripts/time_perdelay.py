@@ -16,7 +16,7 @@ from pydsproutines_amd.devarray import empty  # noqa: E402
 lib = _lib.load()
 rng = np.random.default_rng(3)
 tag = "three-kernel form" if os.environ.get("CAF_PERDELAY_UNFUSED") == "1" else "fused kernel"
-for n, num in ((4096, 1_000_000), (2048, 1_000_000), (8192, 200_000), (1024, 1_000_000), (256, 1_000_000), (16384, 100_000), (1000, 1_000_000), (1000, 100_000), (100, 1_000_000), (10000, 100_000), (1200, 100_000)):
+for n, num in ((4096, 1_000_000), (2048, 1_000_000), (8192, 200_000), (1024, 1_000_000), (256, 1_000_000), (16384, 100_000), (1000, 1_000_000), (1000, 100_000), (100, 1_000_000), (10000, 100_000), (1200, 100_000), (1536, 100_000), (3000, 100_000), (5000, 100_000), (12000, 100_000), (96, 1_000_000)):
     rx = cn(rng, n + num)
     d_rx, d_cut = asarray(rx), asarray(rx[500 : 500 + n].conj().copy())
     q, fi = empty(num, np.float32), empty(num, np.int32)

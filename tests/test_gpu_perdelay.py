@@ -148,6 +148,22 @@ def test_decimal_cutouts_radix10_kernel(n):
     """Cutouts of 100 / 1000 / 10000 samples (benchmark_xcorrs.py's default is 1000) run the same per-delay algorithm with
     radix-10 passes in LDS (k_perdelay_r10): the oracle's branches B, C, C' again, a planted (delay, bin), odd row counts,
     strides in both directions, the zero rows of the out-of-range rule and an all-zero window."""
+    _composite_cutout_checks(n)
+
+
+# 2^a 3^b 5^c lengths that are neither a power of two nor of ten: every radix of the planner first (48 = 16.3, 60 = 10.3.2,
+# 72 = 8.3.3, 75 = 5.5.3, 36 = 4.3.3, 243 = 3^5, 486 = 3^5.2 -> radix 3 first / radix 2 last), several rows per workgroup and
+# one, both launch-bound variants (> 8192 samples), the benchmark's kind of lengths (1200, 1536, 3000, 5000, 12000)
+@pytest.mark.parametrize("n", [36, 48, 60, 72, 75, 243, 486, 1200, 1536, 3000, 5000, 12000, 15552, 16200])
+def test_mixed_radix_cutouts(n):
+    """Cutouts of 2^a 3^b 5^c samples run the per-delay algorithm in ONE kernel too (k_perdelay_mr, caf_perdelay_mr.hip: a
+    mixed-radix Stockham transform in LDS, radices 16 / 10 / 8 / 5 / 4 / 3 / 2) instead of product rows -> rocFFT rows ->
+    argmax through HBM: the same checks as the other two kernels against the oracle's branches B, C, C'
+    (xcorrRoutines.py:511-566)."""
+    _composite_cutout_checks(n)
+
+
+def _composite_cutout_checks(n):
     rng = np.random.default_rng(n)
     m = n + 900
     rx = cn(rng, m)
@@ -195,7 +211,7 @@ from test_gpu_perdelay import _perdelay
 from conftest import cn
 rng = np.random.default_rng(5)
 out = {}
-for n in (64, 1000, 1024, 4096):
+for n in (64, 1000, 1024, 1200, 4096):
     rx = cn(rng, n + 500); cut = cn(rng, n)
     q, fi, pl, _ = _perdelay(cut.conj(), rx, 3, 2, 200, caf=True)
     out['q%%d' %% n], out['f%%d' %% n], out['p%%d' %% n] = q, fi, pl
