@@ -50,123 +50,78 @@ __device__ __forceinline__ void mr_idft(float2* v) {
     if constexpr (R == 16) idft16(*reinterpret_cast<float2(*)[16]>(v));
 }
 
-// What a finished row leaves: planes, (max, first argmax).  Register (c, t) of the last pass <-> spectrum index
-// l + c tpr + t ns (ns = N / R there); visited t-major, so ascending, and a strict comparison keeps the first maximum.
-struct MrRowOut {
-    float inv;
-    bool live;
-    int64_t row;
-    float* plane;
-    float2* cplane;
-    bool want_key;
-    unsigned long long* key_slot;
-};
-template <int R>
-__device__ __forceinline__ void mr_epilogue(const MrPlan& pl, const float2 (&v)[MR_PT], int l, bool active, int nb, int ns,
-                                            const MrRowOut& o) {
-    constexpr int CNT = MR_PT / R;
-    const float inv = o.inv;
-    if ((o.plane || o.cplane) && o.live) {
-        float* prow = o.plane ? o.plane + o.row * pl.n : nullptr;
-        float2* crow = o.cplane ? o.cplane + o.row * pl.n : nullptr;
-#pragma unroll
-        for (int t = 0; t < R; ++t)
-#pragma unroll
-            for (int c = 0; c < CNT; ++c) {
-                const int j = l + c * pl.tpr;
-                if (j < nb) {
-                    const float zr = v[c * R + t].x * inv, zi = v[c * R + t].y * inv;
-                    if (prow) prow[j + t * ns] = __builtin_fmaf(zr, zr, zi * zi);
-                    if (crow) crow[j + t * ns] = make_float2(zr, -zi);
-                }
-            }
-    }
-    if (o.want_key) {
-        float bv = -1.f;
-        uint32_t bi = 0;
-#pragma unroll
-        for (int t = 0; t < R; ++t)
-#pragma unroll
-            for (int c = 0; c < CNT; ++c) {
-                const int j = l + c * pl.tpr;
-                const float zr = v[c * R + t].x * inv, zi = v[c * R + t].y * inv;
-                const float val = __builtin_fmaf(zr, zr, zi * zi);
-                if (j < nb && val > bv) {
-                    bv = val;
-                    bi = (uint32_t)(j + t * ns);
-                }
-            }
-        // (a thread that saw only NaNs offers nothing: an all-NaN row -- a zero-energy window -- keeps key 0)
-        const unsigned long long key = bv < 0.f ? 0ull : (((unsigned long long)__float_as_uint(bv) << 32) | (uint32_t)~bi);
-        if (o.live && active && key) atomicMax(o.key_slot, key);
-    }
-}
-
-// One Stockham pass of radix R with ns = the product of the earlier radices.  first: the inputs are in v already and there
-// is no twiddle; last: the outputs stay in v (mr_epilogue).  Returns with the image written and published (barrier).
-template <int R>
+// One Stockham pass of radix R with ns = the product of the earlier radices: image -> registers, barrier, twiddles,
+// butterflies, registers -> image, barrier.  Nothing is live across a pass but the image: each of the seven bodies behind the
+// uniform switch gets a register allocation of its own (with the data registers carried from pass to pass through the
+// switch, and the last pass' outputs into a per-radix epilogue, every body spilled 10 .. 20 registers at 128).
+// A thread's butterflies past the end (j >= N / R: floor(20 / R) tpr may exceed N / R) are CLAMPED to the last one instead
+// of being branched around: they recompute it and store the same values to the same places.
+template <int R, bool FIRST>
 __device__ __forceinline__ void mr_pass(const MrPlan& pl, int p, float2* __restrict__ buf, const float2* __restrict__ tw, int l_in,
-                                        bool active, bool first, bool last, float2 (&v)[MR_PT], const MrRowOut& o) {
+                                        bool active, float2 (&v)[MR_PT]) {
     constexpr int CNT = MR_PT / R;
     const int nb = pl.n / R, ns = pl.ns[p], tpr = pl.tpr;
     // (an opaque copy of the lane's index: the image addresses of a radix depend on nothing that changes from row to row,
     //  and hoisted out of the row loop -- twenty per radix, seven radices -- they were spilled: ~330 registers of scratch)
     int l = l_in;
     asm volatile("" : "+v"(l));
-    if (!first) {
+    if (!FIRST) {
+        // the twiddle bases W_{R ns}^k = W_N^{k N / (R ns)} of all of the thread's butterflies are fetched FIRST: they do not
+        // depend on the image, and their L1 / L2 latency then runs under the image reads and the barrier
+        const int tws = nb / ns;
+        float2 w1[CNT];
 #pragma unroll
         for (int c = 0; c < CNT; ++c) {
-            const int j = l + c * tpr;
-            if (active && j < nb) {
+            const int j = min(l + c * tpr, nb - 1);
+            const int k = j - ns * (int)__umulhi((uint32_t)j, pl.ns_rcp[p]);
+            w1[c] = tw[k * tws];
+        }
+        if (active) {
+#pragma unroll
+            for (int c = 0; c < CNT; ++c) {
+                const int j = min(l + c * tpr, nb - 1);
 #pragma unroll
                 for (int t = 0; t < R; ++t) v[c * R + t] = buf[mr_pad(j + t * nb)];
             }
         }
         __syncthreads();  // every butterfly has its inputs: the image may be overwritten
-    }
-    const int tws = nb / ns;  // W_{R ns}^k = W_N^{k N / (R ns)}
-    int dst[CNT];
 #pragma unroll
-    for (int c = 0; c < CNT; ++c) {
-        const int j = l + c * tpr;
-        const int k = first ? 0 : j - ns * (int)__umulhi((uint32_t)j, pl.ns_rcp[p]);
-        dst[c] = (j - k) * R + k;
-        if (!first && j < nb) {
-            const float2 w1 = tw[k * tws];
-            float2 pw = w1;
+        for (int c = 0; c < CNT; ++c) {
+            float2 pw = w1[c];
             v[c * R + 1] = cmul(v[c * R + 1], pw);
 #pragma unroll
             for (int t = 2; t < R; ++t) {
-                pw = cmul(pw, w1);
+                pw = cmul(pw, w1[c]);
                 v[c * R + t] = cmul(v[c * R + t], pw);
             }
         }
-        mr_idft<R>(&v[c * R]);
-    }
-    if (last) {
-        mr_epilogue<R>(pl, v, l, active, nb, ns, o);
-        return;
     }
 #pragma unroll
     for (int c = 0; c < CNT; ++c) {
-        const int j = l + c * tpr;
-        if (active && j < nb) {
+        mr_idft<R>(&v[c * R]);
+        if (CNT > 1) __builtin_amdgcn_sched_barrier(0);  // (one butterfly's temporaries at a time)
+    }
+    if (active) {
 #pragma unroll
-            for (int t = 0; t < R; ++t) buf[mr_pad(dst[c] + t * ns)] = v[c * R + t];
+        for (int c = 0; c < CNT; ++c) {
+            const int j = min(l + c * tpr, nb - 1);
+            const int k = FIRST ? 0 : j - ns * (int)__umulhi((uint32_t)j, pl.ns_rcp[p]);
+            const int dst = (j - k) * R + k;
+#pragma unroll
+            for (int t = 0; t < R; ++t) buf[mr_pad(dst + t * ns)] = v[c * R + t];
         }
     }
     __syncthreads();
 }
 
-// WGMAX: the largest workgroup the instance is launched with -- 512 for cutouts of up to 8192 samples (256 VGPRs per lane:
-// no spills), 1024 beyond (128 VGPRs)
+// WGMAX: the largest workgroup the instance is launched with (512 for cutouts of up to 8192 samples, 1024 beyond)
 template <int R0, int WGMAX>
-__global__ __launch_bounds__(WGMAX) void k_perdelay_mr(MrPlan pl, const float2* __restrict__ x, const float2* __restrict__ y,
-                                                       int64_t ylen, const float2* __restrict__ tw,
-                                                       const double* __restrict__ prefix, const double* __restrict__ xnorm,
-                                                       int64_t start, int64_t step, int64_t num, int32_t rows_per_wg,
-                                                       int32_t zero_oor, float* __restrict__ qf2, uint32_t* __restrict__ fidx,
-                                                       float* __restrict__ plane, float2* __restrict__ cplane) {
+__global__ __launch_bounds__(WGMAX, 4) void k_perdelay_mr(MrPlan pl, const float2* __restrict__ x, const float2* __restrict__ y,
+                                                          int64_t ylen, const float2* __restrict__ tw,
+                                                          const double* __restrict__ prefix, const double* __restrict__ xnorm,
+                                                          int64_t start, int64_t step, int64_t num, int32_t rows_per_wg,
+                                                          int32_t zero_oor, float* __restrict__ qf2, uint32_t* __restrict__ fidx,
+                                                          float* __restrict__ plane, float2* __restrict__ cplane) {
     extern __shared__ __attribute__((aligned(16))) float2 s_buf[];  // rpw row images, then 2 x rpw key slots
     constexpr int CNT0 = MR_PT / R0;
     const int tid = threadIdx.x, N = pl.n, tpr = pl.tpr, rpw = pl.rpw, nb0 = N / R0;
@@ -184,56 +139,98 @@ __global__ __launch_bounds__(WGMAX) void k_perdelay_mr(MrPlan pl, const float2* 
         const int64_t s = start + row * step;
         const bool oor = (s < 0) || (s + N > ylen);
         const bool zero = !live || (oor && zero_oor);
-        float2 v[MR_PT];
-#pragma unroll
-        for (int c = 0; c < CNT0; ++c)
-#pragma unroll
-            for (int t = 0; t < R0; ++t) {
-                const int j = l + c * tpr;
-                const int64_t g = s + j + t * nb0;
-                const bool ok = !zero && j < nb0 && (!oor || (g >= 0 && g < ylen));
-                const float2 b = ok ? y[g] : make_float2(0.f, 0.f);
-                // (the cutout is re-read per row -- it stays in the L1 / L2 --: with 20 points per thread resident beside the
-                //  transform's 20 the passes spilled ~300 registers)
-                const float2 a = (active && j < nb0) ? x[j + t * nb0] : make_float2(0.f, 0.f);
-                v[c * R0 + t] = make_float2(a.x * b.x - a.y * b.y, -(a.x * b.y + a.y * b.x));  // conj(x y): see k_perdelay_fused
-            }
-        // normalisation exactly as the three-kernel form computes it (k_sliding_multiply): window energy from the prefix
-        MrRowOut o;
-        o.inv = 0.f;
+        // normalisation exactly as the three-kernel form computes it (k_sliding_multiply): window energy from the prefix.
+        // (Up here: the two prefix loads travel with the window loads instead of starting a round trip of their own after
+        //  the last pass.)
+        float inv = 0.f;
         if (!zero) {
             const int64_t a = s < 0 ? 0 : (s > ylen ? ylen : s);
             int64_t b = s + N;
             b = b < 0 ? 0 : (b > ylen ? ylen : b);
-            o.inv = (float)(1.0 / (sqrt(prefix[b] - prefix[a]) * xn));
+            inv = (float)(1.0 / (sqrt(prefix[b] - prefix[a]) * xn));
         }
-        o.live = live;
-        o.row = row;
-        o.plane = plane;
-        o.cplane = cplane;
-        o.want_key = qf2 || fidx;
-        o.key_slot = &s_key[(it & 1) * rpw + rl];
-        mr_pass<R0>(pl, 0, buf, tw, l, active, true, pl.npass == 1, v, o);
+        {
+            float2 v[MR_PT];
+            // (the cutout is re-read per row -- it stays in the L1 / L2 --: twenty more resident points per thread do not fit
+            //  beside the transform's twenty.  Butterflies past the end are clamped, see mr_pass.)
+            int lx = l;  // (opaque: otherwise the cutout loads are hoisted out of the row loop and held -- and spilled -- after all)
+            asm volatile("" : "+v"(lx));
+            if (!zero && !oor) {
+                const float2* yrow = y + s;
+#pragma unroll
+                for (int c = 0; c < CNT0; ++c) {
+                    const int j = min(lx + c * tpr, nb0 - 1);
+#pragma unroll
+                    for (int t = 0; t < R0; ++t) {
+                        const float2 a = x[j + t * nb0], b = yrow[j + t * nb0];
+                        v[c * R0 + t] = make_float2(a.x * b.x - a.y * b.y, -(a.x * b.y + a.y * b.x));  // conj(x y): see k_perdelay_fused
+                    }
+                    // (one butterfly's loads in flight at a time: all twenty points' x and y at once are 80 registers)
+                    if (CNT0 > 1) __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < CNT0; ++c) {
+                    const int j = min(lx + c * tpr, nb0 - 1);
+#pragma unroll
+                    for (int t = 0; t < R0; ++t) {
+                        const int64_t g = s + j + t * nb0;
+                        const float2 a = x[j + t * nb0];
+                        const float2 b = (!zero && g >= 0 && g < ylen) ? y[g] : make_float2(0.f, 0.f);
+                        v[c * R0 + t] = make_float2(a.x * b.x - a.y * b.y, -(a.x * b.y + a.y * b.x));
+                    }
+                }
+            }
+            mr_pass<R0, true>(pl, 0, buf, tw, l, active, v);
+        }
         for (int p = 1; p < pl.npass; ++p) {
-            const bool last = p + 1 == pl.npass;
+            float2 v[MR_PT];
             switch (pl.radix[p]) {  // (uniform)
-                case 2: mr_pass<2>(pl, p, buf, tw, l, active, false, last, v, o); break;
-                case 3: mr_pass<3>(pl, p, buf, tw, l, active, false, last, v, o); break;
-                case 4: mr_pass<4>(pl, p, buf, tw, l, active, false, last, v, o); break;
-                case 5: mr_pass<5>(pl, p, buf, tw, l, active, false, last, v, o); break;
-                case 8: mr_pass<8>(pl, p, buf, tw, l, active, false, last, v, o); break;
-                case 10: mr_pass<10>(pl, p, buf, tw, l, active, false, last, v, o); break;
-                default: mr_pass<16>(pl, p, buf, tw, l, active, false, last, v, o); break;
+                case 2: mr_pass<2, false>(pl, p, buf, tw, l, active, v); break;
+                case 3: mr_pass<3, false>(pl, p, buf, tw, l, active, v); break;
+                case 4: mr_pass<4, false>(pl, p, buf, tw, l, active, v); break;
+                case 5: mr_pass<5, false>(pl, p, buf, tw, l, active, v); break;
+                case 8: mr_pass<8, false>(pl, p, buf, tw, l, active, v); break;
+                case 10: mr_pass<10, false>(pl, p, buf, tw, l, active, v); break;
+                default: mr_pass<16, false>(pl, p, buf, tw, l, active, v); break;
             }
         }
-        if (o.want_key) {
+        // The finished spectrum is in the image in natural order: thread l takes indices l, l + tpr, ... (ascending, so a
+        // strict comparison keeps the first maximum); planes leave as contiguous runs.
+        float bv = -1.f;
+        uint32_t bi = 0;
+        float* prow = (plane && live) ? plane + row * N : nullptr;
+        float2* crow = (cplane && live) ? cplane + row * N : nullptr;
+        if (active) {
+#pragma unroll 4
+            for (int i = 0; i < 16; ++i) {
+                const int idx = l + i * tpr;
+                if (idx < N) {
+                    const float2 z = buf[mr_pad(idx)];
+                    const float zr = z.x * inv, zi = z.y * inv;
+                    const float val = __builtin_fmaf(zr, zr, zi * zi);
+                    if (prow) prow[idx] = val;
+                    if (crow) crow[idx] = make_float2(zr, -zi);
+                    const bool up = val > bv;
+                    bv = up ? val : bv;
+                    bi = up ? (uint32_t)idx : bi;
+                }
+            }
+        }
+        if (qf2 || fidx) {
+            // (a thread that saw only NaNs offers nothing: an all-NaN row -- a zero-energy window -- keeps key 0)
+            unsigned long long* slot = &s_key[(it & 1) * rpw + rl];
+            const unsigned long long key = bv < 0.f ? 0ull : (((unsigned long long)__float_as_uint(bv) << 32) | (uint32_t)~bi);
+            if (live && key) atomicMax(slot, key);
             __syncthreads();
             if (live && l == 0) {
-                const unsigned long long kk = *o.key_slot;
+                const unsigned long long kk = *slot;
                 if (qf2) qf2[row] = kk ? __uint_as_float((uint32_t)(kk >> 32)) : __builtin_nanf("");  // (zero-energy window: (NaN, 0))
                 if (fidx) fidx[row] = kk ? ~(uint32_t)kk : 0u;
-                *o.key_slot = 0ull;  // (next used two rows from now, behind the barriers of the row in between)
+                *slot = 0ull;  // (next used two rows from now, behind the barriers of the row in between)
             }
+        } else {
+            __syncthreads();  // the image is read to the end before the next row's first pass overwrites it
         }
     }
 }
