@@ -333,6 +333,124 @@ def run_c4(args, torch, dist, device, world, rank, rehearse):
     print(json.dumps(out))
 
 
+def run_c2_freq_shard(args, torch, dist, device, world, rank, rehearse):
+    """The metric's own configuration strong-scaled (second paragraph): ONE 4096-sample template x 256 bins, the
+    bins block-distributed over the ranks (sharding.shard_bins), rx replicated; every rank evaluates all delays for its bins
+    -- its column block (S, 256 / N) of the CAF surface stays in its own HBM -- and the only exchange is the all-gather of one
+    (delay, bin, value) row per rank, reduced with the engine's tie rule (sharding.sharded_bin_peak)."""
+    from pydsproutines_amd import CAFPlan, sharding
+    from pydsproutines_amd.caf import CAFResult
+    from pydsproutines_amd.devarray import DeviceArray
+
+    rx, tmpl = make_inputs(torch, device, 0)  # the same template and rx on every rank
+    bins = np.arange(-F_BINS // 2, F_BINS // 2, dtype=np.int32)
+    lo, hi = sharding.shard_bins(F_BINS, world, rank)
+    fl = hi - lo
+    S = M_RX - N_TMPL + 1
+    surface_on = not args.no_surface
+    plan = CAFPlan(tmpl.cpu().numpy(), max_rx_len=M_RX, bins=bins[lo:hi], grid=N_TMPL, log2_block=args.log2_block,
+                   blocks_per_batch=args.blocks_per_batch, engine=args.engine)
+    res = CAFResult()
+    t_surface = torch.empty((1, S, fl), dtype=torch.float32, device=device) if surface_on else None
+    t_rowmax = torch.empty((1, S), dtype=torch.float32, device=device)
+    t_rowarg = torch.empty((1, S), dtype=torch.int32, device=device)
+    t_peak = torch.zeros(3, dtype=torch.int32, device=device)  # (delay, local bin index, value bits)
+    if surface_on:
+        res.surface = DeviceArray((1, S, fl), np.float32, ptr=t_surface.data_ptr())
+    res.row_max = DeviceArray((1, S), np.float32, ptr=t_rowmax.data_ptr())
+    res.row_arg = DeviceArray((1, S), np.int32, ptr=t_rowarg.data_ptr())
+    res.peak_delay = DeviceArray((1,), np.int32, ptr=t_peak.data_ptr())
+    res.peak_freq = DeviceArray((1,), np.int32, ptr=t_peak.data_ptr() + 4)
+    res.peak_val = DeviceArray((1,), np.float32, ptr=t_peak.data_ptr() + 8)
+    state = {}
+
+    def compute_local(a, b):
+        assert (a, b) == (lo, hi)
+        plan.run(rx, surface=surface_on, rows=True, peak=True, stream=torch.cuda.current_stream().cuda_stream, out=res)
+        return t_peak.cpu() if rehearse else t_peak
+
+    def step():
+        state["peak"], state["table"] = sharding.sharded_bin_peak(F_BINS, compute_local)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def check():
+        d, f, v = state["peak"]
+        if (int(d), int(bins[f])) != (D0, K0):
+            raise SystemExit("rank %d: wrong peak (%d, bin %d), expected (%d, %d)" % (rank, d, int(bins[f]), D0, K0))
+        return float(v)
+
+    for _ in range(max(args.warmup, 1)):
+        step()
+    fence()
+    check()  # on every rank
+    plan.profile(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    stages = plan.profile_get()
+    plan.profile(False)
+    pv = check()
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if rank != 0:
+        return
+    dt = elapsed / args.steps
+    B, step_len, nb = plan.block, plan.step, plan.blocks_per_batch
+    ms, n = stages["spectral_conj_multiply"]
+    avg_ms = ms / max(n, 1)
+    nblk_total = -(-S // step_len)
+    blocks_per_launch = nblk_total / max(1, -(-nblk_total // nb))
+    tiles = -(-step_len // 64)
+    # this rank's launch: |y|^2 tiles written and read back, its surface block and the per-delay results written
+    alg = blocks_per_launch * (tiles * 64 * fl * 4.0 * (2.0 if surface_on else 0.0) + 8.0 * B * (fl / 64.0 + 1)) \
+        + blocks_per_launch * step_len * (fl * (4.0 if surface_on else 0.0) + 12.0)
+    out = {
+        "metric": "CAF Msamples/s (4k template x 256 freq bins)",
+        "value": S / dt / 1e6,
+        "unit": "Msamples/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": ("C2" if M_RX == 1 << 24 else "REHEARSAL SIZE (not C2)")
+            + ": ONE 4096-sample template vs 2^%d-sample rx, its 256 on-grid freq bins block-distributed over %d rank(s) "
+              "(%d per rank), " % (int(np.log2(M_RX)), world, fl)
+            + ("every rank writes its column block f32[S][%d] of the CAF surface + its per-delay argmax; " % fl if surface_on
+               else "per-delay argmax only; ")
+            + "one (delay, bin, |peak|) row per rank all-gathered inside the step and reduced (lowest delay, then lowest bin "
+              "on ties) on every rank; value counts delays fully evaluated over all 256 bins by the whole job",
+            "templates": 1, "freq_bins": F_BINS, "freq_bins_per_gpu": fl, "rx_len": M_RX, "delays": S,
+            "block": B, "blocks_per_batch": nb, "parallelism": "freq-shard x%d" % world,
+        },
+        "correlations_per_s": F_BINS / dt,
+        "caf_cells_per_s": S * F_BINS / dt,
+        "engine": plan.engine_used,
+        "roofline": {"kernel": "k_caf_persistent (rank 0's launch: %d of the 256 bins)" % fl if plan.engine_used == "persistent"
+                     else plan.engine_used, "bound": "hbm", "achieved": alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": (alg / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if avg_ms > 0 else 0.0, "traffic": None,
+                     "avg_launch_ms": avg_ms, "alg_bytes_per_launch": alg},
+        "peak_check": {"delay": D0, "bin": K0, "qf2": pv, "exact_on_every_rank": True},
+        "stages_ms_per_step": {k: v[0] / args.steps for k, v in stages.items()},
+    }
+    print(json.dumps(out))
+
+
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` started by hand (no torchrun): start N child processes of this script, one per
     LOCAL_RANK, with the rendezvous variables torch.distributed reads (127.0.0.1, a free port), wait for all of them,
@@ -358,8 +476,34 @@ def launch_ranks(n, argv):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    # All ranks are watched: a rank that dies before the rendezvous (bad device index, import error) would otherwise leave
+    # the others waiting for the whole store timeout with the GPU held.  The first non-zero exit -- or the overall limit --
+    # ends the rest.  Rank 0's stdout is drained by a thread so that a long JSON line cannot block it.
+    import threading
+
+    out0_parts = []
+    reader = threading.Thread(target=lambda: out0_parts.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    limit = float(os.environ.get("BENCH_LAUNCH_TIMEOUT_S", "3000"))
+    t_start = time.monotonic()
+    failed = False
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs) or time.monotonic() - t_start > limit:
+            failed = True
+            break
+        time.sleep(0.2)
+    if failed:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    reader.join(timeout=30)
+    out0 = out0_parts[0] if out0_parts else ""
+    codes = [p.wait() for p in procs]
     line = [ln for ln in (out0 or "").splitlines() if ln.startswith("{")]
     if any(codes) or not line:
         print("bench.py --gpus %d: rank exit codes %r" % (n, codes), file=sys.stderr)
@@ -381,6 +525,9 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("BENCH_WORKLOAD", "c2"), choices=["c2", "c4"],
                     help="c2: the metric's configuration (default); c4: 512 templates x 512 bins, template-sharded")
     ap.add_argument("--templates", type=int, default=512, help="c4 only: total number of templates (512 = config C4)")
+    ap.add_argument("--shard", default="template", choices=["template", "freq"],
+                    help="c2 with --gpus N: 'template' = every rank its own template (weak scaling, the default the driver "
+                         "measures); 'freq' = ONE template, its 256 bins block-distributed over the ranks (strong scaling)")
     ap.add_argument("--engine", default="auto", choices=["auto", "persistent", "fused", "rocfft"])
     ap.add_argument("--no-surface", action="store_true", help="peak-only mode (no CAF surface written)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -436,6 +583,12 @@ def main():
     _lib.check(_lib.load().caf_set_device(local_rank), "caf_set_device")
     if args.workload == "c4":
         run_c4(args, torch, dist, device, world, rank, rehearse)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    if args.shard == "freq":
+        run_c2_freq_shard(args, torch, dist, device, world, rank, rehearse)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()

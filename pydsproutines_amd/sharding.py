@@ -6,6 +6,12 @@ over the ranks and every rank evaluates all frequency bins of its templates agai
 rx.  There is no data-path collective; the only exchange is one all-gather of the per-template
 peak table (int32 delay, int32 freq index, float32 |peak|^2 = 12 bytes per template).  The
 reference has no multi-GPU code at all, so nothing here mirrors an upstream call pattern.
+
+A SINGLE template can be split as well (the configuration BASELINE.json's metric is quoted on: one 4096-sample template x
+256 bins on 1 / 2 / 4 / 8 GPUs = strong scaling): its frequency bins are block-distributed (``shard_bins``), every rank
+evaluates all delays for its bins -- its column block of the CAF surface stays in its own HBM -- and the exchange is again
+one all-gather, of one (delay, bin, value) row per rank, reduced with the engine's own tie rule (``reduce_bin_peaks``).
+The nearest thing upstream is the thread-strided split over shifts of cython_ext/CyIppXcorrFFT/IppXcorrFFT.cpp:117.
 """
 
 import numpy as np
@@ -24,6 +30,72 @@ def shard_range(num_items, world_size, rank):
 def shard_counts(num_items, world_size):
     return [shard_range(num_items, world_size, r)[1] - shard_range(num_items, world_size, r)[0]
             for r in range(world_size)]
+
+
+def shard_bins(num_bins, world_size, rank):
+    """Block distribution of one template's frequency bins: rank r evaluates bins [lo, hi) -- contiguous and in order, so a
+    local hypothesis index f maps to the global index lo + f and "lowest index wins" carries across ranks."""
+    return shard_range(num_bins, world_size, rank)
+
+
+def reduce_bin_peaks(table, num_bins):
+    """Combine the (world, 3) int32 table of per-rank peaks (delay, LOCAL bin index, float32 value bits) of a
+    ``shard_bins`` split into the template's global peak (delay, GLOBAL bin index, value): the largest value; on equal values
+    the lowest delay, then the lowest bin -- the order in which a one-process run meets them (the peak search keeps the first
+    maximum over delays, the per-delay search the first over bins).  NaN values (a rank whose bins saw only zero-energy
+    windows) never win.  Returns (delay int, bin int, value float32)."""
+    table = np.ascontiguousarray(table, dtype=np.int32)
+    world = table.shape[0]
+    vals = table[:, 2].copy().view(np.float32)
+    best = None
+    for r in range(world):
+        lo, _ = shard_bins(num_bins, world, r)
+        v = vals[r]
+        if np.isnan(v):
+            continue
+        key = (-float(v), int(table[r, 0]), lo + int(table[r, 1]))
+        if best is None or key < best:
+            best = key
+    if best is None:
+        return 0x7FFFFFFF, 0, np.float32(np.nan)
+    return best[1], best[2], np.float32(-best[0])
+
+
+def merge_bin_rows(row_max_parts, row_arg_parts, num_bins):
+    """Per-delay (maximum, first argmax over bins) of the whole template from the per-rank parts of a ``shard_bins`` split
+    (lists in rank order, each (S,)): the value of the first rank that attains the maximum, its local index shifted by the
+    rank's first bin.  NaN (zero-energy window: NaN on every rank) stays NaN with index 0, as one process reports it."""
+    world = len(row_max_parts)
+    best = np.array(row_max_parts[0], dtype=np.float32, copy=True)
+    arg = np.array(row_arg_parts[0], dtype=np.int32, copy=True)
+    for r in range(1, world):
+        lo, _ = shard_bins(num_bins, world, r)
+        v = np.asarray(row_max_parts[r], dtype=np.float32)
+        up = v > best  # strict: the lower bin keeps a tie; NaN compares false
+        best = np.where(up, v, best)
+        arg = np.where(up, lo + np.asarray(row_arg_parts[r], dtype=np.int32), arg)
+    return best, arg
+
+
+def sharded_bin_peak(num_bins, compute_local, group=None):
+    """One step of the frequency-sharded CAF of ONE template (strong scaling of the metric's configuration).
+
+    ``compute_local(lo, hi)`` evaluates bins [lo, hi) over all delays and returns the rank's peak as a (3,) int32 torch tensor
+    (delay, local bin index, float32 value bits) on the device the group communicates from.  One all-gather of these rows;
+    returns ((delay, global bin, value), the gathered (world, 3) table), identical on every rank."""
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized():
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+    else:
+        world, rank = 1, 0
+    lo, hi = shard_bins(num_bins, world, rank)
+    row = compute_local(lo, hi)
+    if tuple(row.shape) != (3,):
+        raise ValueError("compute_local returned shape %r, expected (3,)" % (tuple(row.shape),))
+    table = row.view(1, 3) if world == 1 else all_gather_peak_table(row.view(1, 3), world, group)
+    tb = table.cpu().numpy()
+    return reduce_bin_peaks(tb, num_bins), tb
 
 
 def pack_peak_table(delay, freq, val):

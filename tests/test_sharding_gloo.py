@@ -156,6 +156,103 @@ def test_c4_step_sharded_equals_single_process(world):
         np.testing.assert_array_equal(got[r], single)
 
 
+# ---- strong scaling of ONE template: its frequency bins block-distributed (sharding.shard_bins / sharded_bin_peak) ----
+BIN_MINI = dict(template_len=64, num_bins=16, rx_len=1500, d0=700, k0=3)
+
+
+def _bin_mini_inputs():
+    rng = np.random.default_rng(50)
+    N, F, M = (BIN_MINI[k] for k in ("template_len", "num_bins", "rx_len"))
+    t = np.exp(1j * (np.pi / 4 + np.pi / 2 * rng.integers(0, 4, N))).astype(np.complex64)
+    rx = ((rng.standard_normal(M) + 1j * rng.standard_normal(M)) / np.sqrt(2)).astype(np.complex64)
+    d0, k0 = BIN_MINI["d0"], BIN_MINI["k0"]
+    rx[d0 : d0 + N] += (t * np.exp(2j * np.pi * k0 * np.arange(N) / N)).astype(np.complex64)
+    rx[1200:1300] = 0  # zero-energy windows: NaN on every rank, index 0
+    return t, rx, np.arange(-F // 2, F // 2)
+
+
+def _oracle_bin_engine(t, rx, bins):
+    """A rank's engine for bins [lo, hi): the oracle's surface restricted to them, as float32 like the GPU's, reduced the way
+    the engine reduces it (first maximum over bins per delay, first maximum over delays)."""
+    import torch
+
+    import oracle
+
+    S = rx.size - t.size + 1
+    keep = {}
+
+    def compute(lo, hi):
+        with np.errstate(all="ignore"):
+            surf = oracle.caf_bins(t, rx, bins[lo:hi], np.arange(S)).astype(np.float32)
+        dead = np.all(np.isnan(surf), axis=1)
+        rmax = np.where(dead, np.float32(np.nan), np.nanmax(np.where(np.isnan(surf), -1, surf), axis=1)).astype(np.float32)
+        rarg = np.where(dead, 0, np.argmax(np.where(np.isnan(surf), -1, surf), axis=1)).astype(np.int32)
+        d = int(np.nanargmax(rmax))
+        keep["rows"] = (rmax, rarg)
+        return torch.from_numpy(np.array([d, rarg[d], rmax[d : d + 1].view(np.int32)[0]], np.int32))
+
+    return compute, keep
+
+
+def _bin_worker(rank, world, port, q):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        t, rx, bins = _bin_mini_inputs()
+        compute, keep = _oracle_bin_engine(t, rx, bins)
+        peak, table = sharding.sharded_bin_peak(bins.size, compute)
+        q.put((rank, peak, table.copy(), keep["rows"][0].copy(), keep["rows"][1].copy()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_frequency_sharded_single_template_equals_single_process(world):
+    """bench.py --shard freq calls sharding.sharded_bin_peak; here over gloo with the oracle as the per-rank engine: the
+    reduced peak is identical on every rank and equals the one-process run bit for bit, and the per-delay (max, first argmax)
+    merged from the ranks' parts (sharding.merge_bin_rows) equals the one-process per-delay results, NaN windows included."""
+    import torch.multiprocessing as mp
+
+    t, rx, bins = _bin_mini_inputs()
+    compute, keep = _oracle_bin_engine(t, rx, bins)
+    single_peak, _ = sharding.sharded_bin_peak(bins.size, compute)
+    single_rows = keep["rows"]
+    assert (single_peak[0], int(bins[single_peak[1]])) == (BIN_MINI["d0"], BIN_MINI["k0"])
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bin_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {g[0]: g[1:] for g in (q.get(timeout=180) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(world):
+        peak, table = got[r][0], got[r][1]
+        assert (peak[0], peak[1]) == (single_peak[0], single_peak[1])
+        assert np.float32(peak[2]).view(np.int32) == np.float32(single_peak[2]).view(np.int32)
+        np.testing.assert_array_equal(table, got[0][1])
+    rmax, rarg = sharding.merge_bin_rows([got[r][2] for r in range(world)], [got[r][3] for r in range(world)], bins.size)
+    np.testing.assert_array_equal(rmax, single_rows[0])  # (NaN == NaN here)
+    np.testing.assert_array_equal(rarg, single_rows[1])
+    assert np.isnan(rmax).any()
+
+
+def test_reduce_bin_peaks_tie_rule():
+    v = np.float32(0.5).view(np.int32)
+    # equal values: the lowest delay wins; at equal delays the lowest GLOBAL bin (= the lower rank's)
+    tb = np.array([[900, 1, v], [700, 0, v], [700, 2, v], [100, 0, np.float32(np.nan).view(np.int32)]], np.int32)
+    d, f, val = sharding.reduce_bin_peaks(tb, 16)
+    assert (d, f, float(val)) == (700, 4 + 0, 0.5)
+    tb[0] = (700, 3, v)
+    assert sharding.reduce_bin_peaks(tb, 16)[:2] == (700, 3)
+
+
 # ---- bench.py --gpus N starts its own ranks (no torchrun needed) and never silently measures fewer GPUs ----
 def _run_bench(extra_env, *argv, timeout=600):
     import subprocess
@@ -201,3 +298,19 @@ def test_bench_gpus_2_launches_its_own_ranks_rehearsal():
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["config"]["parallelism"] == "template-shard x2" and "REHEARSAL" in j["config"]["workload"]
     assert j["value"] > 0 and j["steps"] == 2
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_frequency_shard_rehearsal():
+    """python bench.py --gpus 2 --shard freq: ONE template, 128 bins per rank, the two (delay, bin, value) rows gathered over
+    gloo (both ranks share GPU 0: rehearsal switch) and reduced to the planted peak on every rank; the line says strong."""
+    import json
+
+    r = _run_bench({"BENCH_REHEARSE_GLOO": "1"}, "--gpus", "2", "--shard", "freq", "--steps", "2", "--warmup", "1",
+                   "--no-cpu-baseline", "--rx-log2", "20")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["config"]["parallelism"] == "freq-shard x2"
+    assert j["config"]["freq_bins_per_gpu"] == 128 and j["peak_check"]["exact_on_every_rank"] and j["value"] > 0
