@@ -54,3 +54,22 @@ def addSigToNoise(signal, noiseLen=None, sigStartIdx=0, bw_signal=1, chnBW=1, sn
         tone = np.exp(1j * 2 * np.pi * fshift * np.arange(noiseLen) / chnBW)
         return noise, rx * tone, tone
     return noise, rx
+
+
+def addManySigToNoise(noiseLen, sigStartIdxList, signalList, bw_signal, chnBW, snr_inband_linearList, fshifts=None,
+                      sigStartTimeList=None):
+    """ref: signalCreationRoutines.py:148-218 (what benchmark_multiTemplateDotKernels.py:42-48 builds its input with): one
+    noise record scaled for the FIRST signal's SNR, every unit-power signal placed at its start index with amplitude
+    sqrt(snr_i / snr_0), optionally frequency-shifted.  Returns (noise, rx) or (noise, rx, tones).  The sub-sample placement
+    (sigStartTimeList, upstream's propagateSignal) is outside the CAF path and not provided."""
+    if sigStartTimeList is not None:
+        raise NotImplementedError("sub-sample placement (sigStartTimeList) is outside the CAF hot path")
+    snrs = np.asarray(snr_inband_linearList, dtype=np.float64)
+    noise = randnoise(noiseLen, bw_signal, chnBW, snrs[0], 1.0)
+    parts = np.zeros((len(snrs), noiseLen), dtype=np.complex128)
+    for i, (start, sig) in enumerate(zip(sigStartIdxList, signalList)):
+        parts[i, start : start + len(sig)] = np.asarray(sig) * np.sqrt(snrs[i] / snrs[0])
+    if fshifts is None:
+        return noise, parts.sum(axis=0) + noise
+    tones = np.exp(2j * np.pi * np.asarray(fshifts, dtype=np.float64)[:, None] * np.arange(noiseLen) / chnBW)
+    return noise, (parts * tones).sum(axis=0) + noise, tones

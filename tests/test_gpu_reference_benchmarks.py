@@ -7,6 +7,12 @@ that run in seconds.  Written from the cited call lines, not from the scripts' t
     benchmarks/benchmark_groupXcorrs.py:37-72                 GroupXcorrCZT <-> pbIppGroupXcorrCZT (1 thread, 4 threads)
     benchmarks/benchmark_cupyTemplateCrossCorrelator.py:32-37 TemplateCrossCorrelator(...).correlate(dx, returnMax=True)
     benchmarks/benchmark_czts.py:31-82                        CZTCachedGPU / CZTCached / pbIppCZT32fc / dot-tones kernel
+and the five kernel-level scripts:
+    benchmarks/benchmark_xcorrKernels.py:25-76                cp_fastXcorr_v2 with its tuning arguments, twice (warm-up + timed)
+    benchmarks/benchmark_multiTemplateDotKernels.py:24-64     randPSKsyms -> addManySigToNoise -> multiTemplateSlidingDotProduct
+    benchmarks/benchmark_filterkernels.py:33-75               lfilter <-> filter_smtaps <-> filter_smtaps_sminput (128 / 1024 per block)
+    benchmarks/benchmark_upfirdnkernels.py:15-67              upfirdn_naive per row <-> upfirdn_sm <-> scipy.signal.upfirdn, frac < 1e-4
+    benchmarks/benchmark_movAvgKernels.py:19-48               filter_smtaps_sminput(ones / L) <-> cupyMovingAverage
 """
 
 import numpy as np
@@ -176,3 +182,178 @@ def test_benchmark_czts_sequence():
     assert np.max(np.abs(outkernel - ref[0])) <= 1e-4 * scale  # 10000-term float32 sums per bin
     raw, frac = compareValues(d_out.get().flatten(), out.flatten(), verbose=False)
     assert raw <= 2e-5 * scale
+
+
+def test_benchmark_xcorr_kernels_sequence():
+    """benchmark_xcorrKernels.py:25-76: cp_fastXcorr_v2(d_cutout, d_x, 0, numShifts, THREADS_PER_BLOCK, numSlidesPerBlk) with
+    the script's defaults (cutoutlen 1000, 128 threads, 1024 slides per block) and one of its other settings, run twice
+    as the script does (warm-up, then the timed call); 20000 shifts instead of 100000.  The CUDA tuning arguments are
+    accepted and change nothing.  Note the script's convention: the cutout is x[:cutoutlen], NOT conjugated (v2 multiplies as
+    given, xcorrRoutines.py:169-274) -- the oracle is asked for exactly that product."""
+    from pydsproutines_amd import asarray
+    from pydsproutines_amd.timingRoutines import Timer
+    from pydsproutines_amd.xcorrRoutines import cp_fastXcorr_v2
+
+    rng = np.random.default_rng(3)
+    timer = Timer()
+    for cutoutlen, tpb, spb in ((1000, 128, 1024), (1000, 256, 512), (1200, 128, 1024), (2048, 128, 3872)):
+        numShifts = 20000
+        datalen = cutoutlen + numShifts - 1
+        x = (rng.standard_normal(datalen) + 1j * rng.standard_normal(datalen)).astype(np.complex64)
+        cutout = x[:cutoutlen]
+        d_cutout, d_x = asarray(cutout), asarray(x)
+        cpout2 = cp_fastXcorr_v2(d_cutout, d_x, 0, numShifts, tpb, spb)  # warm-up
+        timer.start()
+        cpout2 = cp_fastXcorr_v2(d_cutout, d_x, 0, numShifts, tpb, spb)
+        timer.end("cp_fastxcorr v2")
+        # as the script calls it (flattenCAF left at False) the result is the float32 (numShifts, cutoutlen) |.|^2 plane
+        assert cpout2.dtype == np.float32 and cpout2.shape == (numShifts, cutoutlen)
+        # v2 multiplies by the cutout AS GIVEN: the oracle's branch C with conj(cutout) as its cutout (it conjugates again)
+        sh = np.concatenate((np.arange(0, 48), rng.integers(0, numShifts, 48)))
+        rows = O.fastXcorr(cutout.conj(), x, freqsearch=True, outputCAF=True, shifts=sh)
+        got = np.stack([cpout2[int(r)].get() for r in sh])
+        assert np.max(np.abs(got - rows)) <= 2e-5
+        # the flattened form of the same call (one fused kernel for these lengths): (uint32 bin, float32 QF^2) per shift
+        fi, q = cp_fastXcorr_v2(d_cutout, d_x, 0, numShifts, tpb, spb, flattenCAF=True)
+        fi, q = fi.get(), q.get()
+        assert fi.dtype == np.uint32 and q.dtype == np.float32 and fi.shape == q.shape == (numShifts,)
+        assert np.max(np.abs(q[sh] - rows.max(axis=1))) <= 2e-5
+        top2 = np.sort(rows, axis=1)[:, -2:]
+        clear = top2[:, 1] - top2[:, 0] > 4e-5  # (ties in noise: the index is compared only where the margin is clear)
+        np.testing.assert_array_equal(fi[sh][clear], np.argmax(rows, axis=1)[clear])
+
+
+def test_benchmark_multi_template_dot_kernels_sequence():
+    """benchmark_multiTemplateDotKernels.py:24-64 with its defaults (10 QPSK templates of 100 symbols at starts 0, 200, ...,
+    10 dB, idxlen 100000 -> 30000 here) and its plotted expectation: template i wins at its own start with QF^2 near
+    snr / (snr + 1); everything against the oracle's kernel restatement."""
+    from oracle import kernels as K
+    from pydsproutines_amd import asarray
+    from pydsproutines_amd.cupyExtensions import multiTemplateSlidingDotProduct
+    from pydsproutines_amd.signalCreationRoutines import addManySigToNoise, randPSKsyms
+
+    np.random.seed(5)
+    idxlen, numTemplates, templateLength = 30000, 10, 100
+    templates = np.zeros((numTemplates, templateLength), dtype=np.complex64)
+    for i in range(numTemplates):
+        syms, bits = randPSKsyms(templateLength, 4, dtype=np.complex64)
+        templates[i, :] = syms
+    sigStartIdxList = np.arange(numTemplates) * 2 * templateLength
+    _, rx = addManySigToNoise(idxlen + templateLength - 1, sigStartIdxList, templates, 1, 1, np.zeros(numTemplates) + 10)
+    d_x = asarray(rx.astype(np.complex64))
+    d_templates = asarray(templates)
+    for tpb, spb in ((32, 100), (128, 100)):  # the function default and the script's command-line default
+        d_templateIdx, d_qf2 = multiTemplateSlidingDotProduct(d_x, d_templates.conj(), 0, idxlen, numSlidesPerBlk=spb,
+                                                              THREADS_PER_BLOCK=tpb)
+        tidx, qf2 = d_templateIdx.get(), d_qf2.get()
+        assert tidx.shape == qf2.shape == (idxlen,)
+        for i, s0 in enumerate(sigStartIdxList):
+            assert tidx[s0] == i and 0.8 < qf2[s0] < 1.0  # 10 dB: snr / (snr + 1) = 0.91
+        rt, rq = K.multiTemplateSlidingDotProduct(rx.astype(np.complex64), templates.conj(), 0, idxlen)
+        assert np.max(np.abs(qf2 - rq)) <= 2e-5
+        strong = rq > 0.2  # (in noise-only slides two templates can tie to float32 rounding)
+        np.testing.assert_array_equal(tidx[strong], rt[strong])
+
+
+def test_benchmark_filter_kernels_sequence():
+    """benchmark_filterkernels.py:33-75: 10^6 complex64 noise samples, firwin(128, 0.5): scipy lfilter, filter_smtaps,
+    filter_smtaps_sminput with 128 (default) and 1024 outputs per block, compared with compareValues as the script does (it
+    prints; here bounded), plus the decimating call the script keeps commented out (:78-85)."""
+    import scipy.signal as sps
+
+    from pydsproutines_amd import asarray
+    from pydsproutines_amd.filterRoutines import CupyKernelFilter
+    from pydsproutines_amd.signalCreationRoutines import randnoise
+    from pydsproutines_amd.timingRoutines import Timer
+    from pydsproutines_amd.verifyRoutines import compareValues
+
+    np.random.seed(6)
+    timer = Timer()
+    length = 1000000
+    noise = randnoise(length, 1.0, 1.0, 1.0).astype(np.complex64)
+    d_noise = asarray(noise)
+    taps = sps.firwin(128, 0.5).astype(np.float32)
+    d_taps = asarray(taps)
+    timer.start()
+    cpu_filt = sps.lfilter(taps, 1.0, noise)
+    timer.end("cpu")
+    cpkf = CupyKernelFilter()
+    timer.start()
+    d_filt_smtaps = cpkf.filter_smtaps(d_noise, d_taps)
+    timer.end("gpu smtaps")
+    timer.start()
+    d_filt_smtaps_sminput = cpkf.filter_smtaps_sminput(d_noise, d_taps)
+    timer.end("gpu smtaps sminput 128 per blk")
+    timer.start()
+    d_filt_1024 = cpkf.filter_smtaps_sminput(d_noise, d_taps, OUTPUT_PER_BLK=1024)
+    timer.end("gpu smtaps sminput 1028 per blk")
+    for d in (d_filt_smtaps, d_filt_smtaps_sminput, d_filt_1024):
+        got = d.get()
+        assert got.dtype == np.complex64 and got.shape == cpu_filt.shape
+        raw, frac = compareValues(cpu_filt, got, verbose=False)
+        assert raw <= 2e-5 * np.abs(cpu_filt).max() + 1e-6
+    dsr, dsphase = 4, 1
+    d_ds = cpkf.filter_smtaps(d_noise, d_taps, dsr=dsr, dsPhase=dsphase)
+    raw, _ = compareValues(cpu_filt[dsphase::dsr], d_ds.get(), verbose=False)
+    assert raw <= 2e-5 * np.abs(cpu_filt).max() + 1e-6
+
+
+def test_benchmark_upfirdn_kernels_sequence():
+    """benchmark_upfirdnkernels.py:15-67: 100 rows x 1000 samples, firwin(128, 0.2), up from (5, 7, 11), down from (2, 3):
+    upfirdn_naive row by row into a preallocated matrix, upfirdn_sm on the whole matrix, scipy.signal.upfirdn per row; the
+    script's own assertion fracChg < 1e-4 between the two GPU forms, and the CPU comparison it prints.  Every (up, down)
+    pair instead of ten random draws."""
+    import scipy.signal as sps
+
+    from pydsproutines_amd import asarray
+    from pydsproutines_amd.devarray import zeros
+    from pydsproutines_amd.filterRoutines import CupyKernelFilter
+    from pydsproutines_amd.signalCreationRoutines import randnoise
+    from pydsproutines_amd.verifyRoutines import compareValues
+
+    np.random.seed(7)
+    for up in (5, 7, 11):
+        for down in (2, 3):
+            numRows, length = 100, 1000
+            h_x = randnoise(numRows * length, 1, 1, 1).reshape((numRows, length)).astype(np.complex64)
+            d_x = asarray(h_x)
+            h_taps = sps.firwin(128, 0.2).astype(np.float32)
+            d_taps = asarray(h_taps)
+            cpkf = CupyKernelFilter()
+            d_manualout = zeros((numRows, cpkf.getUpfirdnSize(d_x.shape[1], d_taps.size, up, down)), np.complex64)
+            for i in range(numRows):
+                cpkf.upfirdn_naive(d_x[i], d_taps, up, down, d_out=d_manualout[i])
+            d_out = zeros(d_manualout.shape, np.complex64)
+            cpkf.upfirdn_sm(d_x, d_taps, up, down, d_out=d_out)
+            h_out = np.vstack([sps.upfirdn(h_taps, h_x[i, :], up, down) for i in range(numRows)])
+            assert h_out.shape == d_manualout.shape
+            raw, frac = compareValues(h_out.reshape(-1), d_manualout.get().reshape(-1), verbose=False)
+            assert raw <= 2e-5 * np.abs(h_out).max() + 1e-6
+            rawChg, fracChg = compareValues(d_manualout.get().reshape(-1), d_out.get().reshape(-1), verbose=False)
+            assert fracChg < 1e-4  # (the script's own assert, benchmark_upfirdnkernels.py:67)
+
+
+def test_benchmark_mov_avg_kernels_sequence():
+    """benchmark_movAvgKernels.py:19-48: 10^7 float32 samples (mean 2), a 100-tap averaging window as FIR taps through
+    filter_smtaps_sminput(THREADS_PER_BLOCK=128, OUTPUT_PER_BLK=256) and as cupyMovingAverage(NUM_PER_THREAD=33,
+    THREADS_PER_BLK=32); the script compares the two (compareValues) -- here bounded, and both against NumPy's cumulative sum."""
+    from pydsproutines_amd import asarray
+    from pydsproutines_amd.filterRoutines import CupyKernelFilter, cupyMovingAverage
+    from pydsproutines_amd.verifyRoutines import compareValues
+
+    rng = np.random.default_rng(8)
+    length = 10000000
+    x = rng.standard_normal(length).astype(np.float32) + np.float32(2.0)
+    avgLength = 100
+    avgTaps = np.ones(avgLength).astype(np.float32) / avgLength
+    d_x, d_avgTaps = asarray(x), asarray(avgTaps)
+    cpkf = CupyKernelFilter()
+    d_old = cpkf.filter_smtaps_sminput(d_x, d_avgTaps, THREADS_PER_BLOCK=128, OUTPUT_PER_BLK=256)
+    d_new = cupyMovingAverage(d_x, avgLength, NUM_PER_THREAD=33, THREADS_PER_BLK=32)
+    old, new = d_old.get(), d_new.get()
+    assert old.shape == new.shape == (length,) and new.dtype == np.float32
+    raw, frac = compareValues(old, new, verbose=False)
+    assert raw <= 2e-5
+    c = np.concatenate(([0.0], np.cumsum(x.astype(np.float64))))
+    ref = (c[1:] - np.concatenate((np.zeros(avgLength), c[1 : length - avgLength + 1]))) / avgLength
+    assert np.max(np.abs(new - ref)) <= 2e-5 and np.max(np.abs(old.real - ref)) <= 2e-5
