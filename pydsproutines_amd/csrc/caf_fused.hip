@@ -765,6 +765,189 @@ __device__ __forceinline__ void fused_item2(float2* __restrict__ s_d, const floa
     }
 }
 
+// ----------------------------------------------------------------------------------------
+// Templates of 16385 .. 32768 samples: 65536-point blocks as FOUR chained 16384-point transforms in the same LDS image.
+//   y[n] = sum_m P[m] W^{mn},  W = e^{+j 2 pi / 65536},  m = 4 m' + c:
+//   y[n' + 16384 q] = sum_c j^{cq} W^{c n'} Y_c[n'],   Y_c = IFFT_16384 of the samples m = c (mod 4)
+// The block spectra and the template-spectrum rows arrive RESIDUE-MAJOR ([c][16384] per row, each residue in butterfly order:
+// k_residue_major below), so a sub-transform reads exactly what fused_item reads, with the shift of an on-grid hypothesis
+// (a multiple of 4 here) divided by 4.  The combination twiddle W^{c n'}, n' = n1 + 16 n2 + 256 n3 + 4096 n4, is applied
+// digit by digit as in fused_item2: pass 1 through its recurrence base (4 m2 + c in 65536ths), passes 2 and 3 through the
+// even / odd twiddle tables (c = 0 / 2 exactly; c = 1 / 3: the same two tables times the constants e^{j 2 pi n2 / 4096},
+// e^{j 2 pi n3 / 256}), pass 4 as the constants W_16^{c n4}.
+// Registers decide the shape.  A thread owns sixteen positions n'; two pending output quarters would be 64 registers of
+// accumulators beside the 32 of a transform and the 64 of the next sub-transform's inputs in flight.  So an item
+// accumulates ONE quarter q (template parameter: acc += j^{cq} W^{c n'} Y_c, 32 registers -- the budget of fused_item2) and
+// the job runs every (block, hypothesis group) twice, q = 0 and q = 1: the block's step is 32768 delays whatever the
+// template length in (16384, 32768], i.e. 8 sub-transforms per 32768 delays -- the same cost per delay as the 32768-point
+// role has at N = 16384.  The next sub-transform's inputs are fetched at the start of pass 4 (acc + the four values of a
+// sub-step + 64 registers of loads in flight) and multiplied at the start of its pass 1.
+template <int MODE, int Q>
+__device__ __forceinline__ void fused_item4(float2* __restrict__ s_d, const float2* __restrict__ s_tw2,
+                                            const float2* __restrict__ s_tw3, const float2* __restrict__ xb,  // [blocks][4][16384], butterfly order
+                                            const float2* __restrict__ hc,       // [T][4][16384] or [T*F][4][16384]
+                                            const int32_t* __restrict__ shifts, const float2* __restrict__ tw1,
+                                            int32_t table_mode, int32_t nfreq, int32_t nhyp, int blk, int h0, int h1,
+                                            int32_t tiles_per_blk, float* __restrict__ vt) {
+    constexpr int FB4 = 4 * FB;
+    const int tid = threadIdx.x;
+    const lds_char* img = (const lds_char*)s_d;
+    const uint32_t img0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)img);
+    const uint32_t wave_u = __builtin_amdgcn_readfirstlane((uint32_t)tid >> 6);
+    const uint32_t m0_x1 = img0 + wave_u * 256u, m0_w = img0 + wave_u * (uint32_t)FP_P1;
+    const uint32_t m2 = fp_m2((uint32_t)tid);
+    const float2 w = ld2(tw1, 1024u + m2);  // pass-1 twiddle base e^{+j 2 pi m2 / 16384}
+    const float2* xp = xb + (int64_t)blk * FB4;
+    float* vt_blk = vt + (int64_t)blk * tiles_per_blk * nhyp * 64;
+    const __amdgpu_buffer_rsrc_t rvt = buf_of(uniform_ptr(vt_blk), (uint32_t)tiles_per_blk * (uint32_t)nhyp * 256u);
+    const int n1o = tid & 15, n2o = (tid >> 4) & 15, qo = tid >> 8;  // this thread's pass-4 position
+    const float2* hrow_cur;
+    uint32_t hb_cur;  // as in fused_item, with the shift in residue-major elements (= a quarter of the 65536-point shift)
+    auto row_of = [&](int h) {
+        if (table_mode) {
+            hrow_cur = hc + (int64_t)h * FB4;
+            hb_cur = (uint32_t)tid;
+        } else {
+            const int t = h / nfreq;
+            const int32_t sh = *((const CAF_AS1 int32_t*)shifts + (h - t * nfreq)) >> 2;
+            hrow_cur = hc + (int64_t)t * FB4;
+            hb_cur = fp_hbase(m2, sh);
+        }
+    };
+    float2 xn[16], hn[16];  // inputs of the NEXT sub-transform
+    row_of(h0);
+#pragma unroll
+    for (int a = 0; a < 16; ++a) {
+        xn[a] = ld2(xp, 1024u * a + tid);
+        hn[a] = ld2(hrow_cur, (1024u * a + hb_cur) & (FB - 1));
+    }
+    float2 acc[16];  // register 4 i + n4 <-> n3 = q + 4 i, n4
+
+    for (int h = h0; h < h1; ++h) {
+        uint32_t hoff = (uint32_t)h * 256u;  // bytes
+        asm volatile("" : "+s"(hoff));
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            int lz = 0;
+            asm volatile("" : "+v"(lz));
+            // ---- pass 1: product, DFT16 over a, twiddle with the base e^{j 2 pi (4 m2 + c) / 65536}, write ----
+            {
+                float2 v1[16];
+#pragma unroll
+                for (int a = 0; a < 16; ++a) v1[a] = cmul(xn[a], hn[a]);
+                idft16(v1);
+                // e^{+j 2 pi c / 65536}, c = 1, 2, 3
+                float2 p = c == 0   ? w
+                           : c == 1 ? cmul(w, make_float2(0.99999999540410733f, 9.5873799095977345e-5f))
+                           : c == 2 ? cmul(w, make_float2(0.99999998161642933f, 1.9174759731070330e-4f))
+                                    : cmul(w, make_float2(0.99999995863696604f, 2.8762139372793800e-4f));
+                asm volatile("" : "+v"(p.x), "+v"(p.y));
+                const float2 wj = p;
+                v1[1] = cmul(v1[1], p);
+#pragma unroll
+                for (int n1 = 2; n1 < 16; ++n1) {
+                    p = cmul(p, wj);
+                    v1[n1] = cmul(v1[n1], p);
+                }
+                __syncthreads();  // the previous sub-transform's pass-4 reads are done
+                lds_rows16c<FP_P1>(m0_x1, v1);
+            }
+            __syncthreads();
+            // ---- pass 2: table A (c = 0, 1) or B (c = 2, 3); odd c: times e^{j 2 pi n2 / 4096} ----
+            {
+                float2 v[16];
+                const uint32_t rd2 = fp_rd2((uint32_t)(tid + lz)), rd2i = fp_im(rd2);
+                const lds_tw_ptr t2 = tw_base(s_tw2, fp_cd2((uint32_t)(tid + lz)));
+#pragma unroll
+                for (int bh = 0; bh < 4; ++bh) lds_get4c(img, rd2 + 256u * bh, rd2i + 256u * bh, v[4 * bh], v[4 * bh + 1], v[4 * bh + 2], v[4 * bh + 3]);
+                idft16(v);
+#pragma unroll
+                for (int n2 = 1; n2 < 16; ++n2) {
+                    float2 t = tw_ld(t2, 1024 * (c >> 1) + n2 * 64);
+                    if (c & 1) {
+                        // e^{+j 2 pi n2 / 4096}: cos / sin as compile-time constants
+                        const float cs = (float)__builtin_cos(6.283185307179586476925 * n2 / 4096.0);
+                        const float sn = (float)__builtin_sin(6.283185307179586476925 * n2 / 4096.0);
+                        t = cmul(t, make_float2(cs, sn));
+                    }
+                    v[n2] = cmul(v[n2], t);
+                }
+                lds_rows16c_x2(m0_w, v);
+            }
+            __builtin_amdgcn_wave_barrier();
+            // ---- pass 3: table A / B likewise; odd c: times e^{j 2 pi n3 / 256} ----
+            {
+                float2 v[16];
+                const uint32_t rd3 = fp_rd3((uint32_t)(tid + lz)), rd3i = fp_im(rd3);
+#pragma unroll
+                for (int ch = 0; ch < 4; ++ch) lds_get4c(img, rd3 + 64u * ch, rd3i + 64u * ch, v[4 * ch], v[4 * ch + 1], v[4 * ch + 2], v[4 * ch + 3]);
+                idft16(v);
+#pragma unroll
+                for (int n3 = 1; n3 < 16; ++n3) {
+                    float2 t = tw_ld(tw_base(s_tw3, (uint32_t)((tid & 3) + lz)), 64 * (c >> 1) + n3 * 4);
+                    if (c & 1) {
+                        const float cs = (float)__builtin_cos(6.283185307179586476925 * n3 / 256.0);
+                        const float sn = (float)__builtin_sin(6.283185307179586476925 * n3 / 256.0);
+                        t = cmul(t, make_float2(cs, sn));
+                    }
+                    v[n3] = cmul(v[n3], t);
+                }
+                lds_rows16c<256>(m0_w, v);
+            }
+            __syncthreads();
+            // ---- pass 4: DFT4 over d and the accumulation; the next sub-transform's inputs go out at its end ----
+            if (c == 3) row_of(h + 1 < h1 ? h + 1 : h);
+            const uint32_t rd4 = fp_rd4((uint32_t)tid), rd4i = fp_im(rd4);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                uint32_t lzi = 0;
+                asm volatile("" : "+v"(lzi));
+                float2 a0, a1, a2, a3;
+                lds_get4c(img, rd4 + 1024u * i + lzi, rd4i + 1024u * i + lzi, a0, a1, a2, a3);
+                idft4(a0, a1, a2, a3);
+                const float2 y[4] = {a0, a1, a2, a3};
+#pragma unroll
+                for (int n4 = 0; n4 < 4; ++n4) {
+                    // z = y * e^{j 2 pi c (n4 + 4 Q) / 16}: the last factor of the combination twiddle and j^{cQ} in one constant
+                    constexpr double TWO_PI = 6.283185307179586476925;
+                    const int e16 = (c * (n4 + 4 * Q)) & 15;
+                    float2 z;
+                    if (e16 == 0) z = y[n4];
+                    else if (e16 == 4) z = mulj(y[n4]);
+                    else if (e16 == 8) z = make_float2(-y[n4].x, -y[n4].y);
+                    else if (e16 == 12) z = make_float2(y[n4].y, -y[n4].x);
+                    else z = cmul(y[n4], make_float2((float)__builtin_cos(TWO_PI * e16 / 16.0), (float)__builtin_sin(TWO_PI * e16 / 16.0)));
+                    if (c == 0)
+                        acc[4 * i + n4] = z;
+                    else
+                        acc[4 * i + n4] = cadd(acc[4 * i + n4], z);
+                    if (c == 3) {
+                        const int tile_u = 16 * i + 64 * n4 + 256 * Q;
+                        const int tile_t = (n2o >> 2) + 4 * qo;
+                        const uint32_t soff = (uint32_t)tile_u * (uint32_t)nhyp * 256u + hoff;  // uniform (scalar) offset
+                        const uint32_t voff = ((uint32_t)tile_t * (uint32_t)nhyp * 64u + (uint32_t)(n1o + 16 * (n2o & 3))) << 2;
+                        const float2 yy = acc[4 * i + n4];
+                        tile_store<MODE>(rvt, voff, soff, __builtin_fmaf(yy.x, yy.x, yy.y * yy.y));
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ... and its share of the block spectrum last, when the sub-steps' temporaries are gone: accumulators + row + these
+            // = 96 registers.  (All 64 registers of inputs in flight during the sub-steps spilled the accumulators to scratch in
+            // every sub-transform -- 56 ms at the C2 shape --; fetched before pass 3 instead they spilled that pass.)
+            {
+                const int cn = (c + 1) & 3;
+#pragma unroll
+                for (int a = 0; a < 16; ++a) {
+                    xn[a] = ld2(xp, FB * cn + 1024u * a + tid + lz);
+                    hn[a] = ld2(hrow_cur, FB * cn + ((1024u * a + hb_cur) & (FB - 1)) + lz);
+                }
+            }
+        }
+    }
+}
+
 // natural order -> butterfly order, chunk by chunk of 1024 elements (see fp_tid_of)
 __global__ __launch_bounds__(256) void k_butterfly_order(const float2* __restrict__ in, float2* __restrict__ out, int64_t nchunks) {
     for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x)
@@ -786,6 +969,25 @@ __global__ __launch_bounds__(256) void k_parity_major(const float2* __restrict__
         const float4 v = *reinterpret_cast<const float4*>(&ir[2 * m]);
         orow[j] = make_float2(v.x, v.y);
         orow[half + j] = make_float2(v.z, v.w);
+    }
+}
+// rows of B = 4 * quarter complex samples -> residue-major: out[r][c][m'] = in[r][4 m' + c], each residue in butterfly order
+__global__ __launch_bounds__(256) void k_residue_major4(const float2* __restrict__ in, float2* __restrict__ out, int32_t quarter) {
+    const float2* ir = in + (int64_t)blockIdx.y * 4 * quarter;
+    float2* orow = out + (int64_t)blockIdx.y * 4 * quarter;
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < quarter; j += gridDim.x * 256) {
+        const int m = (int)((j & ~1023) + fp_m2((uint32_t)j & 1023u));  // output position j holds source element m
+        const float4 lo = *reinterpret_cast<const float4*>(&ir[4 * m]), hi = *reinterpret_cast<const float4*>(&ir[4 * m + 2]);
+        orow[j] = make_float2(lo.x, lo.y);
+        orow[quarter + j] = make_float2(lo.z, lo.w);
+        orow[2 * quarter + j] = make_float2(hi.x, hi.y);
+        orow[3 * quarter + j] = make_float2(hi.z, hi.w);
+    }
+}
+void launch_residue_major4(const float2* in, float2* out, int64_t rows, int32_t quarter, hipStream_t st) {
+    for (int64_t r0 = 0; r0 < rows; r0 += 65535) {
+        const int64_t nr = std::min<int64_t>(65535, rows - r0);
+        hipLaunchKernelGGL(k_residue_major4, dim3(16, (unsigned)nr), dim3(256), 0, st, in + r0 * 4 * quarter, out + r0 * 4 * quarter, quarter);
     }
 }
 void launch_parity_major(const float2* in, float2* out, int64_t rows, int32_t half, hipStream_t st, bool butterfly) {
@@ -1603,6 +1805,27 @@ __device__ __attribute__((noinline)) void persistent_fft_item2(lds_float2* s_d, 
         __hip_atomic_fetch_add(&params_of(pp)->pq[PQ_DONE + blk], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// FFT role for 65536-point blocks (templates of 16385 .. 32768 samples): fused_item4, one output quarter per item -- the
+// host doubles ngroups, group number = 2 * (hypothesis group) + q -- and the same publish sequence
+template <int Q>
+__device__ __attribute__((noinline)) void persistent_fft_item4(lds_float2* s_d, const lds_float2* s_tw2, const lds_float2* s_tw3,
+                                                               const PersistParams* pp_in, int item_in) {
+    const PersistParams* pp = uniform_ptr(pp_in);
+    const int item = __builtin_amdgcn_readfirstlane(item_in);
+    const CAF_AS4 PersistParams* P = params_of(pp);
+    const int ngroups = P->ngroups, hyp_per_wg = P->hyp_per_wg, nhyp = P->nhyp;
+    const int blk = item / ngroups;
+    const int grp = (item - blk * ngroups) >> 1;
+    const int h0 = grp * hyp_per_wg;
+    const int h1 = min(h0 + hyp_per_wg, nhyp);
+    fused_item4<1, Q>((float2*)s_d, (const float2*)s_tw2, (const float2*)s_tw3, P->xb, P->hc, P->shifts, P->tw1, P->table_mode,
+                      P->nfreq, nhyp, blk, h0, h1, P->tiles_per_blk, P->vt);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (threadIdx.x == 0)
+        __hip_atomic_fetch_add(&params_of(pp)->pq[PQ_DONE + blk], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <bool STATS>
 __global__ __launch_bounds__(1024) void k_caf_persistent(const PersistParams* __restrict__ pp) {
     static_assert(16 * TW_LDS * 4 <= F_LDS_DATA * 8, "transposer patches must fit the FFT image");
@@ -1674,13 +1897,13 @@ __global__ __launch_bounds__(1024) void k_caf_persistent(const PersistParams* __
                     const int nblk = P->nblk;
                     const int x0 = (int)(blockIdx.x & 7);
                     int got = -1;
-                    if (P->block_log2 != 15) {
+                    if (P->block_log2 < 15) {
                         int i = 0;
                         if (lane0) i = atomicAdd(&pq[PQ_FFT_XCD], 1);
                         i = __builtin_amdgcn_readfirstlane(i);
                         if (i < n_fft) got = i;
                     }
-                    for (int k = 0; k < 8 && got < 0 && P->block_log2 == 15; ++k) {
+                    for (int k = 0; k < 8 && got < 0 && P->block_log2 >= 15; ++k) {
                         const int x = (x0 + k) & 7;
                         const int items_x = ((nblk - x + 7) >> 3) * ngroups;  // blocks x, x + 8, ... < nblk
                         if (__builtin_amdgcn_readfirstlane(pq_load(&pq[PQ_FFT_XCD + x])) >= items_x) continue;
@@ -1727,7 +1950,12 @@ __global__ __launch_bounds__(1024) void k_caf_persistent(const PersistParams* __
             break;
         }
         if (kind == 1) {
-            if (__builtin_amdgcn_readfirstlane(params_of(pp)->block_log2) == 15) {
+            if (__builtin_amdgcn_readfirstlane(params_of(pp)->block_log2) == 16) {
+                if ((item - (item / params_of(pp)->ngroups) * params_of(pp)->ngroups) & 1)
+                    persistent_fft_item4<1>((lds_float2*)s_d, (const lds_float2*)s_tw2, (const lds_float2*)s_tw3, pp, item);
+                else
+                    persistent_fft_item4<0>((lds_float2*)s_d, (const lds_float2*)s_tw2, (const lds_float2*)s_tw3, pp, item);
+            } else if (__builtin_amdgcn_readfirstlane(params_of(pp)->block_log2) == 15) {
                 const int tpb2 = __builtin_amdgcn_readfirstlane(params_of(pp)->tiles_per_blk);  // tiles >= 256: upper half
                 if (tpb2 <= 256)
                     persistent_fft_item2<0>((lds_float2*)s_d, (const lds_float2*)s_tw2, (const lds_float2*)s_tw3, pp, item);

@@ -193,6 +193,8 @@ void launch_fos_scatter(const float2* rows, int64_t b0, int64_t nb, int64_t L, i
 
 // caf_fused.hip
 void launch_parity_major(const float2* in, float2* out, int64_t rows, int32_t half, hipStream_t st, bool butterfly = false);
+// rows of 4 * quarter samples -> residue-major ([c][quarter], m = 4 m' + c), each residue in butterfly order (fused_item4)
+void launch_residue_major4(const float2* in, float2* out, int64_t rows, int32_t quarter, hipStream_t st);
 void launch_fused_caf(const float2* xb, const float2* hc, const int32_t* shifts, const float2* tw1,
                       const float2* tw23, int32_t table_mode, int32_t nfreq, int32_t nhyp, int32_t hyp_per_wg,
                       int32_t nblk, int32_t tiles_per_blk, float* vt, hipStream_t st);
@@ -221,7 +223,9 @@ struct PersistParams {
     const float2* tw23;
     float* vt;
     int32_t table_mode, nfreq, nhyp, hyp_per_wg, nblk, tiles_per_blk;
-    int32_t block_log2;  // 14: one 16384-point transform per hypothesis; 15: 32768 points as two chained halves (fused_item2)
+    int32_t block_log2;  // 14: one 16384-point transform per hypothesis; 15: 32768 points as two chained halves (fused_item2);
+                         // 16: 65536 points as four chained sub-transforms, one output quarter per item (fused_item4:
+                         // ngroups is then 2 x the hypothesis groups, group = 2 * hypothesis group + quarter)
     // tile items (same meaning as launch_transpose_norm_argmax)
     int32_t ntmpl, step, blk0;
     int32_t gpt;  // > 0: hypothesis groups are formed per template, gpt per template (group g of template t covers

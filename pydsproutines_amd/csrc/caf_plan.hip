@@ -451,11 +451,17 @@ static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
         const char* e = getenv("CAF_FUSED_LB15");
         return e && atoi(e);
     }();
-    const int fused_lb = (N <= 8192 && !lb15_env) ? 14 : 15;
-    const bool fused_ok = N <= 16384 && (d->freq_mode != CAF_FREQ_BINS || (d->grid >= 1 && 16384 % d->grid == 0)) &&
+    // (templates of 16385 .. 32768 samples: 65536-point blocks = four chained transforms, one output quarter per work item,
+    //  fused_item4; CAF_FUSED_LB16=0 sends them to the rocfft engine as before -- A/B switch)
+    static const bool lb16_env = [] {
+        const char* e = getenv("CAF_FUSED_LB16");
+        return !e || atoi(e);
+    }();
+    const int fused_lb = (N <= 8192 && !lb15_env) ? 14 : N <= 16384 ? 15 : 16;
+    const bool fused_ok = N <= (lb16_env ? 32768 : 16384) && (d->freq_mode != CAF_FREQ_BINS || (d->grid >= 1 && 16384 % d->grid == 0)) &&
                           (d->log2_block == 0 || d->log2_block == fused_lb);
     CAF_REQUIRE(d->engine != CAF_ENGINE_PERSISTENT || fused_ok,
-                "the persistent engine needs template_len <= 16384, grid | 16384 and log2_block 0, 14 (<= 8192 samples) or 15");
+                "the persistent engine needs template_len <= 32768, grid | 16384 and log2_block 0, 14 (<= 8192 samples), 15 (<= 16384) or 16");
     CAF_REQUIRE(d->engine != CAF_ENGINE_FUSED || (fused_ok && N <= 8192),
                 "the two-launch fused engine needs template_len <= 8192, grid | 16384 and log2_block 0 or 14");
     p->fused = (d->engine == CAF_ENGINE_FUSED) || (d->engine == CAF_ENGINE_PERSISTENT) ||
@@ -485,6 +491,10 @@ static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
     // (1365 of 17745 items at C2) and, in the FFT role, the whole last quarter of the radix-4 pass for one output.
     // Giving up those few delays per block (< 0.33 % more blocks) removes both.
     if (p->fused && p->step % 64 != 0 && (p->step % 64) * 300 <= p->step) p->step -= p->step % 64;
+    // 65536-point blocks: a work item accumulates ONE output quarter of 16384 delays and the job runs quarters 0 and 1, so a
+    // block yields 32768 delays whatever the template length in (16384, 32768] (fused_item4: two pending quarters do not fit
+    // the registers, and a third quarter would cost what it yields)
+    if (p->fused && lb == 16) p->step = 32768;
     p->pitch = p->B + 64;  // break the power-of-two stride between hypothesis rows
     const int B = p->B;
 
@@ -588,7 +598,7 @@ static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
     // (~32 MiB of spectra per forward launch: 256 blocks of 16384, 64 blocks of 65536, ...)
     p->fwd_chunk = (int)std::min<int64_t>(std::max<int64_t>(1, ((int64_t)1 << 22) / B), p->max_blocks);
     if ((rc = p->alloc(&p->d_xb, (p->max_blocks + p->fwd_chunk) * B))) return rc;
-    if (p->fused && p->B == 32768 && (rc = p->alloc(&p->d_xb2, (p->max_blocks + p->fwd_chunk) * B))) return rc;
+    if (p->fused && p->B >= 32768 && (rc = p->alloc(&p->d_xb2, (p->max_blocks + p->fwd_chunk) * B))) return rc;
     if (p->fused) {
         if ((rc = p->alloc(&p->d_vt, (int64_t)nb * p->tiles_per_blk * T * F * 64))) return rc;
         if ((rc = fused_twiddles(p->device, &p->d_tw1, &p->d_tw23))) return rc;  // per device, shared by all plans
@@ -670,6 +680,18 @@ static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
         rc = fft_plan_acquire(&tmp, false, (size_t)B, (size_t)nspec, (size_t)B);
         if (rc == CAF_OK) rc = tmp.exec(p->d_hc, nullptr, nullptr);
         if (rc == CAF_OK) launch_conj_scale(p->d_hc, nspec * B, 1.0f / (float)B, nullptr);
+        if (rc == CAF_OK && p->fused && B == 65536) {
+            // the 65536-point engine reads its template-spectrum rows residue-major (m = 4 m' + c) -- and in butterfly order,
+            // which this one pass produces as well (the permutation below is skipped)
+            float2* tmp = nullptr;
+            rc = pool_alloc((void**)&tmp, nspec * (int64_t)B * 8);
+            if (rc == CAF_OK) {
+                launch_residue_major4(p->d_hc, tmp, nspec, B / 4, nullptr);
+                if (hipMemcpyAsync(p->d_hc, tmp, (size_t)nspec * B * 8, hipMemcpyDeviceToDevice, nullptr) != hipSuccess) rc = CAF_ERR_HIP;
+                (void)hipStreamSynchronize(nullptr);
+                (void)pool_free(tmp);
+            }
+        }
         if (rc == CAF_OK && p->fused && B == 32768) {
             // the 32768-point engine reads its template-spectrum rows parity-major (even samples, then odd samples)
             float2* tmp = nullptr;
@@ -681,7 +703,7 @@ static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
                 (void)pool_free(tmp);
             }
         }
-        if (rc == CAF_OK && p->fused) {
+        if (rc == CAF_OK && p->fused && B != 65536) {
             // the in-LDS engines read their rows in butterfly order (caf_fused.hip, fp_tid_of): permuted once, here
             float2* tmpb = nullptr;
             rc = pool_alloc((void**)&tmpb, nspec * (int64_t)B * 8);
@@ -905,6 +927,8 @@ int32_t caf_plan_execute(caf_plan p, const float* d_rx, int64_t rx_len, int64_t 
     }
     if (p->fused && p->B == 32768 && !lds_fwd32)  // block spectra parity-major for the two chained half-transforms
         launch_parity_major(p->d_xb, p->d_xb2, nfwd * p->fwd_chunk, p->B / 2, st, true);
+    if (p->fused && p->B == 65536)  // ... residue-major for the four chained sub-transforms
+        launch_residue_major4(p->d_xb, p->d_xb2, nfwd * p->fwd_chunk, p->B / 4, st);
     if (aux) CAF_HIP_TRY(hipStreamWaitEvent(st, p->ev_join, 0));
     bool f1_direct = false, f1_item_peaks = false;
     if (p->fused) {
@@ -954,7 +978,7 @@ int32_t caf_plan_execute(caf_plan p, const float* d_rx, int64_t rx_len, int64_t 
             const int32_t nbk = (int32_t)std::min<int64_t>(nb_launch, nblk - b0);
             PersistParams h;
             std::memset(&h, 0, sizeof(h));
-            h.xb = (p->B == 32768 ? p->d_xb2 : p->d_xb) + b0 * (int64_t)p->B;
+            h.xb = (p->B >= 32768 ? p->d_xb2 : p->d_xb) + b0 * (int64_t)p->B;
             h.hc = p->d_hc;
             h.shifts = p->d_shifts;
             h.tw1 = p->d_tw1;
@@ -966,7 +990,7 @@ int32_t caf_plan_execute(caf_plan p, const float* d_rx, int64_t rx_len, int64_t 
             h.hyp_per_wg = p->hyp_per_wg;
             h.nblk = nbk;
             h.tiles_per_blk = p->tiles_per_blk;
-            h.block_log2 = p->B == 32768 ? 15 : 14;
+            h.block_log2 = p->B == 65536 ? 16 : p->B == 32768 ? 15 : 14;
             h.ntmpl = T;
             h.step = p->step;
             h.blk0 = (int32_t)b0;
@@ -991,6 +1015,7 @@ int32_t caf_plan_execute(caf_plan p, const float* d_rx, int64_t rx_len, int64_t 
             }
             h.vmax = p->d_vt;
             h.imax = reinterpret_cast<int32_t*>(p->d_vt + (int64_t)nb_launch * h.ngroups * p->tiles_per_blk * 64);
+            if (h.block_log2 == 16) h.ngroups *= 2;  // one work item per (hypothesis group, output quarter): fused_item4
             h.n_fft = nbk * h.ngroups;
             h.ipb = (p->tiles_per_blk + 15) / 16;  // 16 tiles per item (PQ_TILES, caf_fused.hip)
             h.n_tr = nbk * h.ipb;

@@ -1,5 +1,6 @@
 """The C2 shape (2^24-sample rx, 256 on-grid bins, full surface) for template lengths around the LDS engines' limits:
-N = 4096 / 8192 (16384-point blocks), 8193 / 16384 (32768-point blocks = two chained transforms), 16385 (rocfft engine)."""
+N = 4096 / 8192 (16384-point blocks), 8193 / 16384 (32768-point blocks = two chained transforms), 16385 / 24576 / 32768
+(65536-point blocks = four chained transforms, one output quarter per work item), 32769 (rocfft engine)."""
 import sys
 import time
 
@@ -14,10 +15,10 @@ M, F = 1 << 24, 256
 rng = np.random.default_rng(4)
 rx = cn(rng, M)
 d_rx = asarray(rx)
-for n in (4096, 8192, 8193, 16384, 16385):
+for n in (4096, 8192, 8193, 16384, 16385, 24576, 32768, 32769):
     t = qpsk(rng, n)
     grid = min(16384, 1 << int(np.ceil(np.log2(n))))
-    for engine in (("auto",) if n <= 8192 or n > 16384 else ("auto", "rocfft")):
+    for engine in (("auto",) if n <= 8192 or n > 32768 else ("auto", "rocfft")):
         plan = CAFPlan(t, max_rx_len=M, bins=np.arange(-F // 2, F // 2), grid=grid, engine=engine)
         res = plan.run(d_rx, surface=True)
         _lib.check(_lib.load().caf_stream_sync(None))

@@ -324,26 +324,28 @@ def test_engines_agree_with_oracle(engine, golden):
     assert np.all(r7.peak_delay.get()[1:20] == d6[1:20])
 
 
-@pytest.mark.parametrize("n", [4095, 8191, 8192, 8193, 12000, 16384, 16385])
+@pytest.mark.parametrize("n", [4095, 8191, 8192, 8193, 12000, 16384, 16385, 24000, 32768, 32769])
 def test_template_lengths_around_the_fused_limits(n):
     """The LDS-resident engines: 16384-point blocks for templates up to 8192 samples (persistent and two-launch fused,
-    bit-identical), 32768-point blocks as two chained 16384-point transforms up to 16384 samples (persistent only);
-    longer ones go to the rocfft engine automatically and are refused by an explicit fused / persistent request."""
+    bit-identical), 32768-point blocks as two chained 16384-point transforms up to 16384 samples, 65536-point blocks as four
+    chained transforms (one output quarter per work item) up to 32768 samples (persistent only); longer ones go to the
+    rocfft engine automatically and are refused by an explicit fused / persistent request."""
     from pydsproutines_amd import CAFPlan, asarray
     from test_gpu_engine_fuzz import _oracle_rows
 
     rng = np.random.default_rng(n)
-    m = 90_000 if n > 8192 else 40_000
+    m = 40_000 if n <= 8192 else 90_000 if n <= 16384 else 150_000
     t = qpsk(rng, n)
     rx = cn(rng, m)
     d0, bins = 12_345, np.arange(-4, 4)
     grid = min(16384, 1 << int(np.ceil(np.log2(n))))
     rx[d0 : d0 + n] += (t * np.exp(2j * np.pi * 3 * np.arange(n) / grid)).astype(np.complex64)
     d_rx = asarray(rx)
-    rows = np.array([0, 1, d0 - 1, d0, d0 + 1, 16383, 16384, 16385, 24575, 24576, 32767, 32768, m - n])
+    rows = np.array([0, 1, d0 - 1, d0, d0 + 1, 16383, 16384, 16385, 24575, 24576, 32767, 32768, 49151, 49152, 65535, 65536,
+                     98303, 98304, m - n])
     rows = rows[rows <= m - n]
     ref = _oracle_rows(t, rx, bins / grid, rows)
-    engines = ("persistent", "fused", "rocfft") if n <= 8192 else ("persistent", "rocfft") if n <= 16384 else ("rocfft",)
+    engines = ("persistent", "fused", "rocfft") if n <= 8192 else ("persistent", "rocfft") if n <= 32768 else ("rocfft",)
     surf = {}
     for engine in engines:
         plan = CAFPlan(t, max_rx_len=m, bins=bins, grid=grid, engine=engine)
@@ -367,6 +369,13 @@ def test_template_lengths_around_the_fused_limits(n):
         auto = CAFPlan(t, max_rx_len=m, bins=bins, grid=grid)
         valid = 32768 - n + 1  # a step a few delays over a multiple of 64 is rounded down to whole 64-delay tiles
         assert auto.engine_used == "persistent" and auto.block == 32768 and auto.step in (valid, valid - valid % 64)
+        auto.close()
+        with pytest.raises(ValueError):
+            CAFPlan(t, max_rx_len=m, bins=bins, grid=grid, engine="fused")
+    elif n <= 32768:
+        assert np.max(np.abs(surf["persistent"] - surf["rocfft"])) <= 2e-6 * max(1.0, surf["rocfft"].max())  # two engines
+        auto = CAFPlan(t, max_rx_len=m, bins=bins, grid=grid)
+        assert auto.engine_used == "persistent" and auto.block == 65536 and auto.step == 32768
         auto.close()
         with pytest.raises(ValueError):
             CAFPlan(t, max_rx_len=m, bins=bins, grid=grid, engine="fused")
