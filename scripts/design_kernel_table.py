@@ -5,9 +5,11 @@ import sys
 
 ROWS = [  # (workload, kernel prefix of the manifest entry, label)
     ("c2_surface", "k_caf_persistent", "`k_caf_persistent` (C2 surface)"),
+    ("c2_surface_t", "k_caf_persistent", "`k_caf_persistent` (C2, hypothesis-major surface written by the FFT items)"),
     ("c2_nosurface", "k_caf_persistent", "`k_caf_persistent` (C2 no surface)"),
     ("c4_share", "k_caf_persistent", "`k_caf_persistent` (C4 share: 64 templates × 512 bins)"),
     ("c2_long_template", "k_caf_persistent", "`k_caf_persistent` (N = 16384, 2 × 16384)"),
+    ("c2_lb16", "k_caf_persistent", "`k_caf_persistent` (N = 32768, 4 × 16384, one output quarter per item)"),
     ("c3", "k_caf_persistent", "`k_caf_persistent` (C3: rows written by the FFT items)"),
     ("c3_complex_rows", "k_caf_persistent", "`k_caf_persistent` (C3 complex-QF rows, `TemplateCrossCorrelator.correlate`)"),
     ("c2_fused", "k_fused_caf", "`k_fused_caf`"),
@@ -22,7 +24,9 @@ ROWS = [  # (workload, kernel prefix of the manifest entry, label)
     ("direct_small_support", "k_direct_caf", "`k_direct_caf` (16 samples of support, 64 frequencies, 2²² delays, surface)"),
     ("cp_fastxcorr_1e7", "k_sliding_multiply", "`k_sliding_multiply` (128 rows × 10⁷)"),
     ("perdelay_decimal_1000", "k_perdelay_r10", "`k_perdelay_r10<3>` (1000 × 10⁶, radix 10)"),
-    ("perdelay_rows_1000", "k_sliding_multiply", "`k_sliding_multiply` (10⁵ rows × 1200)"),
+    ("perdelay_mixed_1200", "k_perdelay_mr<16", "`k_perdelay_mr<16>` (1200 × 10⁵, radices 16·5·5·3)"),
+    ("perdelay_mixed_1200", "k_perdelay_mr<10", "`k_perdelay_mr<10>` (5000 × 10⁵, radices 10·10·10·5)"),
+    ("perdelay_rows_1400", "k_sliding_multiply", "`k_sliding_multiply` (10⁵ rows × 1400)"),
     ("cp_fastxcorr_1e7", "k_rows_argmax", "`k_rows_argmax` (chunked, 128 rows × 10⁷)"),
     ("kernels_misc", "k_magnsq", "`k_magnsq`"),
     ("kernels_misc", "k_iq16_to_c64", "`k_iq16_to_c64`"),
@@ -52,8 +56,10 @@ def main(path):
         if not ks:
             continue
         k = ks[0]
-        ach = "%.2f TB/s" % (k["achieved_GBs"] / 1e3) if k["alg_bytes_per_call"] else ""
-        of = "%.2f HBM" % k["frac_hbm_peak"] if k["alg_bytes_per_call"] else ""
+        # (kernels whose bytes do not scale with their work -- the fused per-delay correlators -- are priced on f32 only)
+        hbm = k["alg_bytes_per_call"] and not (k["alg_flops_per_call"] and k["frac_hbm_peak"] < 0.02 and k["kernel"].startswith("k_perdelay"))
+        ach = "%.2f TB/s" % (k["achieved_GBs"] / 1e3) if hbm else ""
+        of = "%.2f HBM" % k["frac_hbm_peak"] if hbm else ""
         if k["alg_flops_per_call"]:
             ach += (" + " if ach else "") + "%.1f TFLOP/s" % k["achieved_TFLOPs"]
             of += (" / " if of else "") + "%.2f f32" % k["frac_f32_peak"]
@@ -64,4 +70,4 @@ def main(path):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "profiles/r03/kernels_summary.json")
+    main(sys.argv[1] if len(sys.argv) > 1 else "profiles/r04/kernels_summary.json")

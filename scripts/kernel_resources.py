@@ -68,8 +68,8 @@ def main():
         rows = functions(listing(f))
         names = demangle([r[0] for r in rows])
         for r, n in zip(rows, names):
-            n = re.sub(r"\(.*", "", n)
             n = n.replace("caf::", "").replace("(anonymous namespace)::", "")
+            n = re.sub(r"\(.*", "", n)
             if r[3] or r[4] or "k_" in n or "persistent_" in n:
                 print("%-96s %5d %5d %8d %7d %8d %9d %8d" % (n[:96], r[1], r[2], r[3], r[4], r[5], r[6], r[7]))
 

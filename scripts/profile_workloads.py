@@ -154,6 +154,43 @@ def w_c2_long_template():
              "16384-point transforms (8 B read + 8 B written per point)", nblk * B * 16.0, nblk * (2 * 5.0 * 16384 * 14 + 10.0 * B), 2)]
 
 
+def w_c2_surface_t():
+    """C2 with the hypothesis-major surface (caf_outputs.d_surface_t): rows written by the FFT items, no tiles."""
+    t, d_rx = c2_inputs()
+    plan = CAFPlan(t, max_rx_len=M, bins=np.arange(-128, 128), grid=N)
+    res = None
+    for _ in range(2):
+        res = plan.run(d_rx, surface_t=True, out=res)
+    sync()
+    B, step = plan.block, plan.step
+    nblk = -(-S // step)
+    # surface written once, (value, hypothesis) pairs per delay and group written + read, traces written, block spectra read
+    alg = S * 256 * 4.0 + nblk * (-(-step // 64) * 64 * 4 * 8.0 * 2 + 8.0 * B * 5) + S * 12.0
+    flops = nblk * 256 * (5.0 * B * np.log2(B) + 6.0 * B + 3.0 * step)
+    plan.close()
+    return [("k_caf_persistent", "one-launch engine, hypothesis-major surface [F][S] written by the FFT items (no tiles)", alg, flops, 2)]
+
+
+def w_c2_lb16():
+    """C2 shape with a 32768-sample template: 65536-point blocks = four chained 16384-point transforms, one quarter per item."""
+    n = 32768
+    t = qpsk(rng, n)
+    d_rx = asarray(cn(rng, M))
+    plan = CAFPlan(t, max_rx_len=M, bins=np.arange(-128, 128), grid=16384)
+    res = None
+    for _ in range(2):
+        res = plan.run(d_rx, surface=True, out=res)
+    sync()
+    Sn = M - n + 1
+    B, step = plan.block, plan.step
+    nblk = -(-Sn // step)
+    alg = nblk * ((step // 64) * 64 * 256 * 4.0 + 8.0 * B) + Sn * 256 * 8.0 + Sn * 12.0
+    flops = nblk * 256 * 2 * (4 * 5.0 * 16384 * 14 + 6.0 * B + 3.0 * 16384)
+    plan.close()
+    return [("k_caf_persistent", "one-launch engine, N=32768 (B=65536 as 4 x 16384, one output quarter per item), F=256, surface",
+             alg, flops, 2)]
+
+
 def w_c5_zoom():
     from pydsproutines_amd.zoom import caf_with_zoom
 
@@ -206,30 +243,48 @@ def perdelay(n, num, label):
     return n, num
 
 
+# The fused per-delay kernels keep the (rows, N) product matrix in LDS: the bytes they MOVE are the rx samples (read once
+# from HBM, overlapping windows come back from the L2) and 8 B of results per row -- that is what is declared, and the bound
+# they sit on is the f32 rate (5 N log2 N flop per row), not the HBM.
+def _perdelay_bytes(n, num):
+    return (n + num) * 8.0 + num * 8.0
+
+
 def w_perdelay_fused_4096():
     n, num = perdelay(4096, 1_000_000, "fused")
-    return [("k_perdelay_fused", "product -> LDS FFT -> |.|^2 -> argmax, N=4096 x 1e6 delays; bytes = the 8 B product elements the "
-             "unfused form writes (SURVEY 8d slidingMultiplyNormalised), which this kernel never materialises", num * n * 8.0,
-             num * 5.0 * n * np.log2(n), 2)]
+    return [("k_perdelay_fused", "product -> LDS FFT -> |.|^2 -> argmax, N=4096 x 1e6 delays (f32-bound: no bytes scale with rows x N)",
+             _perdelay_bytes(n, num), num * 5.0 * n * np.log2(n), 2)]
 
 
 def w_perdelay_fused_256():
     n, num = perdelay(256, 1_000_000, "fused")
-    return [("k_perdelay_fused", "N=256 x 1e6 delays (same accounting)", num * n * 8.0, num * 5.0 * n * np.log2(n), 2)]
+    return [("k_perdelay_fused", "N=256 x 1e6 delays (same accounting)", _perdelay_bytes(n, num), num * 5.0 * n * np.log2(n), 2)]
 
 
-def w_perdelay_rows_1000():
-    """A cutout length that is neither a power of two nor of ten: product rows -> rocFFT rows -> argmax."""
-    n, num = perdelay(1200, 100_000, "rows")
-    return [("k_sliding_multiply", "normalised product rows, N=1200 x 1e5 (8 B written per element)", num * n * 8.0, 0.0, 2),
+def w_perdelay_rows_1400():
+    """A cutout length with a factor 7 (no in-LDS kernel): product rows -> rocFFT rows -> argmax."""
+    n, num = perdelay(1400, 100_000, "rows")
+    return [("k_sliding_multiply", "normalised product rows, N=1400 x 1e5 (8 B written per element)", num * n * 8.0, 0.0, 2),
             ("k_rows_argmax", "|.|^2 + first argmax per row (8 B read per element)", num * n * 8.0, 0.0, 2)]
 
 
 def w_perdelay_decimal_1000():
     """benchmark_xcorrs.py's default cutout (1000 samples): the per-delay algorithm on radix-10 passes in LDS."""
     n, num = perdelay(1000, 1_000_000, "fused")
-    return [("k_perdelay_r10", "fused per-delay correlator, N=1000 x 1e6 rows (product elements at 8 B each; 5 N log2 N flop per row)",
-             num * n * 8.0, num * 5.0 * n * np.log2(n), 2)]
+    return [("k_perdelay_r10", "fused per-delay correlator, N=1000 x 1e6 rows (f32-bound; 5 N log2 N flop per row)",
+             _perdelay_bytes(n, num), num * 5.0 * n * np.log2(n), 2)]
+
+
+def w_perdelay_mixed_1200():
+    """2^a 3^b 5^c cutouts: the mixed-radix in-LDS kernel (caf_perdelay_mr.hip), here 1200 = 16.5.5.3 and 5000 = 10.10.10.5."""
+    man = []
+    for n, num in ((1200, 100_000), (5000, 100_000)):
+        perdelay(n, num, "mixed")
+    man.append(("k_perdelay_mr<16", "mixed-radix per-delay correlator, N=1200 x 1e5 rows (f32-bound)", _perdelay_bytes(1200, 100_000),
+                100_000 * 5.0 * 1200 * np.log2(1200), 2))
+    man.append(("k_perdelay_mr<10", "mixed-radix per-delay correlator, N=5000 x 1e5 rows (f32-bound)", _perdelay_bytes(5000, 100_000),
+                100_000 * 5.0 * 5000 * np.log2(5000), 2))
+    return man
 
 
 def w_cp_fastxcorr_1e7():

@@ -117,6 +117,18 @@ def main(out):
                 wres["others"].append({"kernel": k, "dispatches": n, "total_ms": t / 1e3, "share": t / total_us})
         result["workloads"][name] = wres
     json.dump(result, open(os.path.join(out, "kernels_summary.json"), "w"), indent=1)
+    # registers / scratch / spills of every kernel and role, from the compiler's listing of these sources
+    try:
+        import subprocess
+
+        txt = subprocess.run([sys.executable, os.path.join(repo, "scripts", "kernel_resources.py")], capture_output=True, text=True,
+                             timeout=1200).stdout
+        print("=" * 150)
+        print("registers, scratch and spills (scripts/kernel_resources.py; scratch without spills in loops = the callee-saved "
+              "registers of a noinline role, saved once per work item)")
+        print(txt)
+    except Exception as exc:  # (no compiler on the box: the table is produced where the library is built)
+        print("kernel_resources.py not run: %r" % (exc,))
 
 
 if __name__ == "__main__":
