@@ -157,13 +157,6 @@ typedef struct caf_outputs {
     float* d_cqf;          /* [T][F][num_shifts] complex64 QF = r / (||tmpl|| * ||rx window||), i.e.   */
                            /* hypothesis-major like TemplateCrossCorrelator.correlate (:352-357) and   */
                            /* fastXcorr(absResult=False) (:533-548)                                    */
-    float* d_surface_t;    /* [T][F][num_shifts] float32 QF2, HYPOTHESIS-major: the same numbers as d_surface, */
-                           /* bit for bit, transposed per template (not the reference's CAF layout,         */
-                           /* xcorrRoutines.py:553-566; it is what a frequency-row consumer -- a zoom, a       */
-                           /* results store, a per-bin detector -- reads contiguously).  Written by the FFT    */
-                           /* work items of the PERSISTENT engine with 16384-point blocks themselves: no       */
-                           /* |y|^2 tiles, no transposition (C2: 10 ms against 13.5).  Not together with      */
-                           /* d_surface or d_cqf; F == 1: any engine (the two layouts coincide).               */
 } caf_outputs;
 
 /* d_rx: device complex64 [rx_len].  Requires shift_start >= 0 and
@@ -174,6 +167,21 @@ typedef struct caf_outputs {
  * reference's stateful correlator objects, IppXcorrFFT.h, xcorrRoutines.py:277-371). */
 CAF_EXPORT int32_t caf_plan_execute(caf_plan plan, const float* d_rx, int64_t rx_len, int64_t shift_start,
                                     int64_t num_shifts, const caf_outputs* out, void* stream);
+
+/* The same call with the outputs added after ABI 1.4 (caf_outputs keeps its seven pointers: clients built against it --
+ * INTEGRATION.md's ctypes stub, examples/c_client -- stay valid).  `base` as above (may be NULL); zero the struct first. */
+typedef struct caf_outputs2 {
+    caf_outputs base;
+    float* d_surface_t;    /* [T][F][num_shifts] float32 QF2, HYPOTHESIS-major: the same numbers as d_surface, bit for  */
+                           /* bit, transposed per template (not the reference's CAF layout, xcorrRoutines.py:553-566;  */
+                           /* it is what a frequency-row consumer -- a zoom, a results store, a per-bin detector --     */
+                           /* reads contiguously).  Written by the FFT work items of the PERSISTENT engine with        */
+                           /* 16384-point blocks themselves: no |y|^2 tiles, no transposition (C2: 10.9 ms against     */
+                           /* 13.6).  Not together with d_surface or d_cqf; F == 1: any engine (the layouts coincide). */
+    void* reserved[3];     /* must be NULL */
+} caf_outputs2;
+CAF_EXPORT int32_t caf_plan_execute2(caf_plan plan, const float* d_rx, int64_t rx_len, int64_t shift_start,
+                                     int64_t num_shifts, const caf_outputs2* out, void* stream);
 
 /* Diagnostic of the one-launch (persistent) engine: marks[0..1] = the watchdog words of the work-queue block. Both
  * are 0 unless a tile item waited ~10 s for its block to be published -- which the protocol rules out (the launch

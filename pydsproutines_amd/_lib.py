@@ -83,8 +83,11 @@ class CafOutputs(ct.Structure):
         ("d_peak_delay", ct.c_void_p),
         ("d_peak_freq", ct.c_void_p),
         ("d_cqf", ct.c_void_p),
-        ("d_surface_t", ct.c_void_p),
     ]
+
+
+class CafOutputs2(ct.Structure):
+    _fields_ = [("base", CafOutputs), ("d_surface_t", ct.c_void_p), ("reserved", ct.c_void_p * 3)]
 
 
 class CafZoomOutputs(ct.Structure):
@@ -127,6 +130,7 @@ _SIGNATURES = {
     "caf_plan_info": [_P, ct.POINTER(_I32), ct.POINTER(_I32), ct.POINTER(_I32), ct.POINTER(_I64)],
     "caf_plan_engine": [_P, ct.POINTER(_I32)],
     "caf_plan_execute": [_P, _P, _I64, _I64, _I64, ct.POINTER(CafOutputs), _P],
+    "caf_plan_execute2": [_P, _P, _I64, _I64, _I64, ct.POINTER(CafOutputs2), _P],
     "caf_plan_watchdog": [_P, ct.POINTER(_I32)],
     "caf_plan_profile": [_P, _I32],
     "caf_plan_profile_get": [_P, ct.POINTER(ct.c_double), ct.POINTER(_I64)],

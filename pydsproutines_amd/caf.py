@@ -162,17 +162,18 @@ class CAFPlan:
             res.peak_freq = empty((self.T,), np.int32)
         if cqf and res.cqf is None:
             res.cqf = empty((self.T, self.F, S), np.complex64)
-        o = _lib.CafOutputs()
+        o2 = _lib.CafOutputs2()
+        o = o2.base
         o.d_cqf = res.cqf.ptr if cqf else None
         o.d_surface = res.surface.ptr if surface else None
         o.d_row_max = res.row_max.ptr if rows else None
         o.d_row_arg = res.row_arg.ptr if want_arg and not skip_arg else None
-        o.d_surface_t = res.surface_t.ptr if surface_t else None
+        o2.d_surface_t = res.surface_t.ptr if surface_t else None
         o.d_peak_val = res.peak_val.ptr if peak else None
         o.d_peak_delay = res.peak_delay.ptr if peak else None
         o.d_peak_freq = res.peak_freq.ptr if peak else None
         _lib.check(
-            _lib.load().caf_plan_execute(self._h, ct.c_void_p(ptr), rx_len, int(shift_start), S, ct.byref(o),
+            _lib.load().caf_plan_execute2(self._h, ct.c_void_p(ptr), rx_len, int(shift_start), S, ct.byref(o2),
                                          ct.c_void_p(stream) if stream else None),
             "caf_plan_execute",
         )

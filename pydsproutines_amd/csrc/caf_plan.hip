@@ -823,7 +823,24 @@ int32_t caf_plan_profile_get(caf_plan plan, double* ms, int64_t* launches) {
 
 int32_t caf_plan_execute(caf_plan p, const float* d_rx, int64_t rx_len, int64_t shift_start, int64_t num_shifts,
                          const caf_outputs* out, void* stream) {
-    CAF_REQUIRE(p && d_rx && out, "caf_plan_execute: NULL argument");
+    CAF_REQUIRE(out, "caf_plan_execute: NULL argument");
+    caf_outputs2 o2;
+    std::memset(&o2, 0, sizeof(o2));
+    o2.base = *out;
+    return caf_plan_execute2(p, d_rx, rx_len, shift_start, num_shifts, &o2, stream);
+}
+
+int32_t caf_plan_execute2(caf_plan p, const float* d_rx, int64_t rx_len, int64_t shift_start, int64_t num_shifts,
+                          const caf_outputs2* out2, void* stream) {
+    CAF_REQUIRE(p && d_rx && out2, "caf_plan_execute: NULL argument");
+    CAF_REQUIRE(!out2->reserved[0] && !out2->reserved[1] && !out2->reserved[2], "caf_outputs2.reserved must be NULL");
+    // (the engine below works on one flat view of the outputs)
+    struct AllOutputs : caf_outputs {
+        float* d_surface_t;
+    } all;
+    static_cast<caf_outputs&>(all) = out2->base;
+    all.d_surface_t = out2->d_surface_t;
+    const AllOutputs* out = &all;
     CAF_REQUIRE(rx_len >= p->N && rx_len <= p->max_rx, "rx_len outside [template_len, max_rx_len]");
     CAF_REQUIRE(shift_start >= 0 && num_shifts >= 1, "need shift_start >= 0 and num_shifts >= 1");
     CAF_REQUIRE(shift_start + num_shifts - 1 + p->N <= rx_len, "delays run past the end of rx");
@@ -836,13 +853,10 @@ int32_t caf_plan_execute(caf_plan p, const float* d_rx, int64_t rx_len, int64_t 
     const int T = p->T, F = p->F;
     const bool want_peak = out->d_peak_val || out->d_peak_delay || out->d_peak_freq;
     // hypothesis-major surface [T][F][S]: with one hypothesis per template it IS the delay-major one
-    caf_outputs out_f1;
-    if (out->d_surface_t && F == 1) {
-        CAF_REQUIRE(!out->d_surface, "d_surface and d_surface_t cannot both be given");
-        out_f1 = *out;
-        out_f1.d_surface = out->d_surface_t;
-        out_f1.d_surface_t = nullptr;
-        out = &out_f1;
+    if (all.d_surface_t && F == 1) {
+        CAF_REQUIRE(!all.d_surface, "d_surface and d_surface_t cannot both be given");
+        all.d_surface = all.d_surface_t;
+        all.d_surface_t = nullptr;
     }
     const bool surf_t = out->d_surface_t != nullptr;
     CAF_REQUIRE(!surf_t || (p->persistent && p->B == 16384 && !out->d_surface && !out->d_cqf),

@@ -35,7 +35,8 @@ def test_struct_layouts_match_header():
     # caf_plan_desc: 2 i32, ptr, 2 i32, 2 ptr, 2 i32, ptr, i32(+pad), ptr, i64, 4 i32
     assert ctypes.sizeof(_lib.CafPlanDesc) == 96
     assert _lib.CafPlanDesc.engine.offset == 88
-    assert ctypes.sizeof(_lib.CafOutputs) == 8 * ctypes.sizeof(ctypes.c_void_p)  # (the eighth: d_surface_t, ABI minor 5)
+    assert ctypes.sizeof(_lib.CafOutputs) == 7 * ctypes.sizeof(ctypes.c_void_p)  # (never grows: old clients pass exactly this)
+    assert ctypes.sizeof(_lib.CafOutputs2) == 11 * ctypes.sizeof(ctypes.c_void_p) and _lib.CafOutputs2.d_surface_t.offset == 56
     assert _lib.CafPlanDesc.max_rx_len.offset == 72
 
 

@@ -274,7 +274,7 @@ def test_engines_agree_with_oracle(engine, golden):
         with pytest.raises(ValueError):
             plan3.run(asarray(rxg), cqf=True)  # complex QF is a rocFFT-engine output
         with pytest.raises(ValueError):
-            CAFPlan(np.ones(17000, np.complex64), max_rx_len=40000, bins=[0], grid=16384, engine=engine)
+            CAFPlan(np.ones(33000, np.complex64), max_rx_len=80000, bins=[0], grid=16384, engine=engine)  # (> 32768 samples)
 
     # 2 templates x 128 bins (whole 128-hypothesis chunks: the full-tile path of the transposers), 3 blocks,
     # run twice on different data through the same plan: the second result must not see the first one's tiles
