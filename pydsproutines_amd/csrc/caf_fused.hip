@@ -814,13 +814,12 @@ __device__ __forceinline__ void fused_item4(float2* __restrict__ s_d, const floa
             hb_cur = fp_hbase(m2, sh);
         }
     };
-    float2 xn[16], hn[16];  // inputs of the NEXT sub-transform
+    float2 pr[16];  // X * Hc of the NEXT sub-transform: formed at the end of pass 4, so that only these 32 registers and the
+                    // 32 of the accumulators cross into its pass 1 (with the 64 of x and h alive there as well the register
+                    // allocator kept the accumulators in scratch -- 115 MB of it, i.e. in HBM: 56 ms instead of 40 at C2)
     row_of(h0);
 #pragma unroll
-    for (int a = 0; a < 16; ++a) {
-        xn[a] = ld2(xp, 1024u * a + tid);
-        hn[a] = ld2(hrow_cur, (1024u * a + hb_cur) & (FB - 1));
-    }
+    for (int a = 0; a < 16; ++a) pr[a] = cmul(ld2(xp, 1024u * a + tid), ld2(hrow_cur, (1024u * a + hb_cur) & (FB - 1)));
     float2 acc[16];  // register 4 i + n4 <-> n3 = q + 4 i, n4
 
     for (int h = h0; h < h1; ++h) {
@@ -834,7 +833,7 @@ __device__ __forceinline__ void fused_item4(float2* __restrict__ s_d, const floa
             {
                 float2 v1[16];
 #pragma unroll
-                for (int a = 0; a < 16; ++a) v1[a] = cmul(xn[a], hn[a]);
+                for (int a = 0; a < 16; ++a) v1[a] = pr[a];
                 idft16(v1);
                 // e^{+j 2 pi c / 65536}, c = 1, 2, 3
                 float2 p = c == 0   ? w
@@ -897,6 +896,7 @@ __device__ __forceinline__ void fused_item4(float2* __restrict__ s_d, const floa
             __syncthreads();
             // ---- pass 4: DFT4 over d and the accumulation; the next sub-transform's inputs go out at its end ----
             if (c == 3) row_of(h + 1 < h1 ? h + 1 : h);
+            const int cn = (c + 1) & 3;
             const uint32_t rd4 = fp_rd4((uint32_t)tid), rd4i = fp_im(rd4);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -922,6 +922,10 @@ __device__ __forceinline__ void fused_item4(float2* __restrict__ s_d, const floa
                         acc[4 * i + n4] = z;
                     else
                         acc[4 * i + n4] = cadd(acc[4 * i + n4], z);
+                    // (pinned: left to itself the compiler defers these additions to the last sub-transform, carries z_0, z_1
+                    //  and z_2 separately -- 96 registers -- and keeps them in scratch: 115 MB of it, i.e. in HBM; 56 ms
+                    //  instead of 40 at the C2 shape)
+                    if (c < 3) asm volatile("" : "+v"(acc[4 * i + n4].x), "+v"(acc[4 * i + n4].y));
                     if (c == 3) {
                         const int tile_u = 16 * i + 64 * n4 + 256 * Q;
                         const int tile_t = (n2o >> 2) + 4 * qo;
@@ -933,15 +937,20 @@ __device__ __forceinline__ void fused_item4(float2* __restrict__ s_d, const floa
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // ... and its share of the block spectrum last, when the sub-steps' temporaries are gone: accumulators + row + these
-            // = 96 registers.  (All 64 registers of inputs in flight during the sub-steps spilled the accumulators to scratch in
-            // every sub-transform -- 56 ms at the C2 shape --; fetched before pass 3 instead they spilled that pass.)
+            // the next sub-transform's inputs, fetched when the sub-steps' temporaries are gone, and multiplied here
             {
-                const int cn = (c + 1) & 3;
+                // (fetched at the START of pass 4 instead -- 64 more registers under the sub-steps -- : 45.4 against 44.8 ms)
+                float2 xn[16], hn[16];
 #pragma unroll
                 for (int a = 0; a < 16; ++a) {
                     xn[a] = ld2(xp, FB * cn + 1024u * a + tid + lz);
                     hn[a] = ld2(hrow_cur, FB * cn + ((1024u * a + hb_cur) & (FB - 1)) + lz);
+                }
+                // (one product at a time, in the order the loads return: each frees four registers and takes two)
+#pragma unroll
+                for (int a = 0; a < 16; ++a) {
+                    pr[a] = cmul(xn[a], hn[a]);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
