@@ -652,6 +652,14 @@ def main():
     got = (int(pk[0]), int(bins[pk[1]]), float(pk[2:3].view(np.float32)[0]))
     if got[:2] != (D0, K0):
         raise SystemExit("rank %d: wrong peak after the timed steps %r, expected (%d, %d)" % (rank, got, D0, K0))
+    # ... and the surface they wrote must hold it: the peak's row (1 KB of the 17 GB) has its maximum at the planted bin, equal
+    # to the reported peak value and to the per-delay result; a noise-only row far from it stays at the 1/N level
+    if surface_on:
+        row = t_surface[0, D0].cpu().numpy()
+        far = t_surface[0, (D0 + S // 2) % S].cpu().numpy()
+        if int(np.argmax(row)) != int(pk[1]) or row.max() != np.float32(got[2]) or row.max() != t_rowmax[0, D0].item() \
+                or not (0.0 <= far.max() < 20.0 / N_TMPL):
+            raise SystemExit("rank %d: the surface written by the timed steps does not hold the reported peak" % rank)
 
     # side figure (not the metric): the same job when only the per-delay argmax and the peak are wanted
     extra = None
