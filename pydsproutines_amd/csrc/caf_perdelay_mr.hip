@@ -56,9 +56,13 @@ __device__ __forceinline__ void mr_idft(float2* v) {
 // switch, and the last pass' outputs into a per-radix epilogue, every body spilled 10 .. 20 registers at 128).
 // A thread's butterflies past the end (j >= N / R: floor(20 / R) tpr may exceed N / R) are CLAMPED to the last one instead
 // of being branched around: they recompute it and store the same values to the same places.
+// last_reg (the last pass of a row whose planes are not wanted): the outputs are not written back; |z|^2 and the thread's
+// (maximum, first index) come straight from the registers -- register (c, t) <-> spectrum index j + t N / R, visited t-major,
+// i.e. ascending (a clamped butterfly offers the last one's value at the last one's index again: the strict comparison
+// ignores it) -- and the row saves a round trip through the image and two barriers.
 template <int R, bool FIRST>
 __device__ __forceinline__ void mr_pass(const MrPlan& pl, int p, float2* __restrict__ buf, const float2* __restrict__ tw, int l_in,
-                                        bool active, float2 (&v)[MR_PT]) {
+                                        bool active, float2 (&v)[MR_PT], bool last_reg, float inv, float& bv, uint32_t& bi) {
     constexpr int CNT = MR_PT / R;
     const int nb = pl.n / R, ns = pl.ns[p], tpr = pl.tpr;
     // (an opaque copy of the lane's index: the image addresses of a radix depend on nothing that changes from row to row,
@@ -100,6 +104,20 @@ __device__ __forceinline__ void mr_pass(const MrPlan& pl, int p, float2* __restr
     for (int c = 0; c < CNT; ++c) {
         mr_idft<R>(&v[c * R]);
         if (CNT > 1) __builtin_amdgcn_sched_barrier(0);  // (one butterfly's temporaries at a time)
+    }
+    if (last_reg) {
+#pragma unroll
+        for (int t = 0; t < R; ++t)
+#pragma unroll
+            for (int c = 0; c < CNT; ++c) {
+                const int j = min(l + c * tpr, nb - 1);
+                const float zr = v[c * R + t].x * inv, zi = v[c * R + t].y * inv;
+                const float val = __builtin_fmaf(zr, zr, zi * zi);
+                const bool up = val > bv;
+                bv = up ? val : bv;
+                bi = up ? (uint32_t)(j + t * nb) : bi;
+            }
+        return;
     }
     if (active) {
 #pragma unroll
@@ -149,6 +167,11 @@ __global__ __launch_bounds__(WGMAX, 4) void k_perdelay_mr(MrPlan pl, const float
             b = b < 0 ? 0 : (b > ylen ? ylen : b);
             inv = (float)(1.0 / (sqrt(prefix[b] - prefix[a]) * xn));
         }
+        // rows whose planes are not wanted finish in the registers of the last pass (mr_pass, last_reg); with planes the
+        // finished spectrum goes through the image once more and leaves in contiguous runs
+        const bool reg_tail = !plane && !cplane;
+        float bv = -1.f;
+        uint32_t bi = 0;
         {
             float2 v[MR_PT];
             // (the cutout is re-read per row -- it stays in the L1 / L2 --: twenty more resident points per thread do not fit
@@ -181,27 +204,26 @@ __global__ __launch_bounds__(WGMAX, 4) void k_perdelay_mr(MrPlan pl, const float
                     }
                 }
             }
-            mr_pass<R0, true>(pl, 0, buf, tw, l, active, v);
+            mr_pass<R0, true>(pl, 0, buf, tw, l, active, v, reg_tail && pl.npass == 1, inv, bv, bi);
         }
         for (int p = 1; p < pl.npass; ++p) {
             float2 v[MR_PT];
+            const bool lastr = reg_tail && p + 1 == pl.npass;
             switch (pl.radix[p]) {  // (uniform)
-                case 2: mr_pass<2, false>(pl, p, buf, tw, l, active, v); break;
-                case 3: mr_pass<3, false>(pl, p, buf, tw, l, active, v); break;
-                case 4: mr_pass<4, false>(pl, p, buf, tw, l, active, v); break;
-                case 5: mr_pass<5, false>(pl, p, buf, tw, l, active, v); break;
-                case 8: mr_pass<8, false>(pl, p, buf, tw, l, active, v); break;
-                case 10: mr_pass<10, false>(pl, p, buf, tw, l, active, v); break;
-                default: mr_pass<16, false>(pl, p, buf, tw, l, active, v); break;
+                case 2: mr_pass<2, false>(pl, p, buf, tw, l, active, v, lastr, inv, bv, bi); break;
+                case 3: mr_pass<3, false>(pl, p, buf, tw, l, active, v, lastr, inv, bv, bi); break;
+                case 4: mr_pass<4, false>(pl, p, buf, tw, l, active, v, lastr, inv, bv, bi); break;
+                case 5: mr_pass<5, false>(pl, p, buf, tw, l, active, v, lastr, inv, bv, bi); break;
+                case 8: mr_pass<8, false>(pl, p, buf, tw, l, active, v, lastr, inv, bv, bi); break;
+                case 10: mr_pass<10, false>(pl, p, buf, tw, l, active, v, lastr, inv, bv, bi); break;
+                default: mr_pass<16, false>(pl, p, buf, tw, l, active, v, lastr, inv, bv, bi); break;
             }
         }
-        // The finished spectrum is in the image in natural order: thread l takes indices l, l + tpr, ... (ascending, so a
-        // strict comparison keeps the first maximum); planes leave as contiguous runs.
-        float bv = -1.f;
-        uint32_t bi = 0;
+        // With planes: the finished spectrum is in the image in natural order: thread l takes indices l, l + tpr, ... (ascending,
+        // so a strict comparison keeps the first maximum); planes leave as contiguous runs.
         float* prow = (plane && live) ? plane + row * N : nullptr;
         float2* crow = (cplane && live) ? cplane + row * N : nullptr;
-        if (active) {
+        if (active && !reg_tail) {
 #pragma unroll 4
             for (int i = 0; i < 16; ++i) {
                 const int idx = l + i * tpr;
@@ -229,7 +251,7 @@ __global__ __launch_bounds__(WGMAX, 4) void k_perdelay_mr(MrPlan pl, const float
                 if (fidx) fidx[row] = kk ? ~(uint32_t)kk : 0u;
                 *slot = 0ull;  // (next used two rows from now, behind the barriers of the row in between)
             }
-        } else {
+        } else if (!reg_tail) {
             __syncthreads();  // the image is read to the end before the next row's first pass overwrites it
         }
     }
