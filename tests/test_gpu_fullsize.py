@@ -332,3 +332,73 @@ def test_c5_full_size_zoom(c2):
                          step_bins=1.0 / 8)
     assert len(more) == 3 and more[0]["delay"] == D0
     assert more[0]["coarse_qf2"] >= more[1]["coarse_qf2"] >= more[2]["coarse_qf2"] > 0.0045
+
+
+@pytest.mark.parametrize("n", [16385, 32768])
+def test_long_templates_full_size_on_the_chained_role(n):
+    """Templates of 16385 / 32768 samples at the C2 shape (2^24-sample rx, 256 bins, full surface): 65536-point blocks as four
+    chained transforms, two work items (output quarters) per block and hypothesis group -- planted (delay, bin) exact, sampled
+    rows (block boundaries at multiples of 32768, quarter boundaries at 16384, both ends) against the oracle, row results ==
+    the surface written, agreement with the rocfft engine on the per-delay maxima."""
+    from pydsproutines_amd import CAFPlan, asarray
+
+    rng = np.random.default_rng(n)
+    t = qpsk(rng, n)
+    rx = cn(rng, M)
+    d0, k0, grid = 7_000_123, -21, 16384
+    rx[d0 : d0 + n] += (0.5 * t * np.exp(2j * np.pi * k0 * np.arange(n) / grid)).astype(np.complex64)
+    bins = np.arange(-F // 2, F // 2)
+    d_rx = asarray(rx)
+    plan = CAFPlan(t, max_rx_len=M, bins=bins, grid=grid)
+    assert plan.engine_used == "persistent" and plan.block == 65536 and plan.step == 32768
+    res = plan.run(d_rx, surface=True)
+    S = M - n + 1
+    assert (int(res.peak_delay.get()[0]), int(bins[res.peak_freq.get()[0]])) == (d0, k0)
+    rows = np.unique(np.concatenate((np.arange(0, 3), [16383, 16384, 32767, 32768, 49151, 49152, 65535, 65536], np.arange(d0 - 2, d0 + 3),
+                                     [255 * 32768 - 1, 255 * 32768, 255 * 32768 + 16384, S - 2, S - 1], rng.integers(0, S, 24))))
+    from test_gpu_engine_fuzz import _oracle_rows
+
+    ref = _oracle_rows(t, rx, bins / grid, rows)
+    got = np.stack([res.surface[0][int(r)].get() for r in rows])
+    tol = 1e-4 * ref.max()
+    assert np.max(np.abs(got - ref)) <= tol
+    rmax, rarg = res.row_max.get()[0], res.row_arg.get()[0]
+    np.testing.assert_array_equal(rmax[rows], got.max(axis=1))
+    np.testing.assert_array_equal(rarg[rows], np.argmax(got, axis=1))
+    assert float(res.peak_val.get()[0]) == rmax.max() and int(np.argmax(rmax)) == d0
+    other = CAFPlan(t, max_rx_len=M, bins=bins, grid=grid, engine="rocfft")
+    r2 = other.run(d_rx, surface=False, rows=True, peak=True)
+    assert np.max(np.abs(r2.row_max.get()[0] - rmax)) <= 3e-6
+    assert int(r2.peak_delay.get()[0]) == d0
+    other.close()
+    plan.close()
+
+
+def test_mixed_radix_per_delay_kernel_at_a_million_delays():
+    """k_perdelay_mr at the size the reference's benchmark runs its per-delay calls (10^6 delays): cutout of 1200 samples, a
+    planted (delay, bin), every row result against the definition on a sample, and the (NaN, 0) rule on a zero stretch."""
+    import ctypes as ct
+
+    from pydsproutines_amd import _lib, asarray
+    from pydsproutines_amd.devarray import empty
+
+    rng = np.random.default_rng(12)
+    n, num = 1200, 1_000_000
+    rx = cn(rng, n + num)
+    d0, k0 = 654_321, 777
+    cut = (rx[d0 : d0 + n] * np.exp(-2j * np.pi * k0 * np.arange(n) / n)).astype(np.complex64)
+    rx = (rx + 0.2 * cn(rng, rx.size)).astype(np.complex64)
+    rx[200_000 : 200_000 + 3 * n] = 0
+    d_rx, d_cut = asarray(rx), asarray(cut.conj().copy())
+    q, fi = empty(num, np.float32), empty(num, np.int32)
+    p = lambda a: ct.c_void_p(a.ptr)  # noqa: E731
+    _lib.check(_lib.load().caf_xcorr_perdelay(p(d_cut), n, p(d_rx), rx.size, 0, 1, num, 0, p(q), p(fi), None, None, 0, None))
+    q, fi = q.get(), fi.get()
+    dead = slice(200_000, 200_000 + 2 * n + 1)
+    assert np.all(np.isnan(q[dead])) and np.all(fi[dead] == 0)
+    assert int(np.nanargmax(q)) == d0 and int(fi[d0]) == k0 and q[d0] > 0.9
+    sh = np.concatenate(([0, 1, num - 1, d0 - 1, d0, d0 + 1], rng.integers(0, num, 60)))
+    sh = sh[(sh < 200_000 - n) | (sh > 200_000 + 3 * n)]
+    rq, rf = O.fastXcorr(cut, rx, freqsearch=True, shifts=sh)
+    assert np.max(np.abs(q[sh] - rq)) <= 2e-5
+    assert int(fi[d0]) == int(rf[list(sh).index(d0)])
