@@ -127,6 +127,20 @@ def _take_u32(d_i32, rel, out=None):
 # ------------------------------------------------------------------------------------------
 # fastXcorr and relatives (host-array signatures)
 # ------------------------------------------------------------------------------------------
+def _complex_qf_plan(templates, max_rx_len, grid):
+    """The plan behind the complex-QF plane (`caf_outputs.d_cqf`: fastXcorr(absResult=False), TemplateCrossCorrelator.correlate):
+    the one-launch in-LDS engine writes it from its own work items -- with 16384-point blocks only, i.e. templates of up to
+    8192 samples (and not under the CAF_FUSED_LB15 / CAF_PERSISTENT switches) --, the rocFFT engine otherwise.  Decided from
+    the template length first, so that the common cases build ONE plan; the engine actually chosen is checked."""
+    n = templates.shape[-1]
+    if n <= 8192:
+        plan = CAFPlan(templates, max_rx_len=max_rx_len, bins=[0], grid=grid)
+        if plan.engine_used == "persistent" and plan.block == 16384:
+            return plan
+        plan.close()
+    return CAFPlan(templates, max_rx_len=max_rx_len, bins=[0], grid=grid, engine="rocfft")
+
+
 def fastXcorr(cutout, rx, freqsearch=False, outputCAF=False, shifts=None, absResult=True):
     """ref: xcorrRoutines.py:460-580 -- all six branches, same return dtypes:
     A float64[S]; A' complex128[S]; B (float64[S], uint32[S]); B' (complex128[S], uint32[S]);
@@ -149,11 +163,8 @@ def fastXcorr(cutout, rx, freqsearch=False, outputCAF=False, shifts=None, absRes
         lo, cnt, rel = _engine_range(shifts)
         # (the complex QF plane comes from the one-launch in-LDS engine's own work items for cutouts of up to 8192 samples --
         #  fused_item MODE 4 -- and from the rocFFT engine beyond)
-        plan = CAFPlan(_c64(cutout), max_rx_len=len(rx), bins=[0], grid=1 << int(np.ceil(np.log2(max(n, 2)))),
-                       engine="auto" if absResult or n <= 8192 else "rocfft")
-        if not absResult and plan.engine_used != "persistent":
-            plan.close()
-            plan = CAFPlan(_c64(cutout), max_rx_len=len(rx), bins=[0], grid=1 << int(np.ceil(np.log2(max(n, 2)))), engine="rocfft")
+        grid = 1 << int(np.ceil(np.log2(max(n, 2))))
+        plan = CAFPlan(_c64(cutout), max_rx_len=len(rx), bins=[0], grid=grid) if absResult else _complex_qf_plan(_c64(cutout), len(rx), grid)
         res = plan.run(d_rx, shift_start=lo, num_shifts=cnt, rows=absResult, peak=False, cqf=not absResult)
         if absResult:
             out[:] = res.row_max.get()[0][rel]
@@ -436,13 +447,7 @@ class TemplateCrossCorrelator:
         if self._plan is None:
             # templates of up to 8192 samples: the one-launch in-LDS engine writes the complex rows itself (one transform
             # = one row segment; config C3: 3.x ms for 8.6 GB of output); longer ones: multiply -> rocFFT -> normalise
-            if self._templateOrigLength <= 8192:
-                self._plan = CAFPlan(self._tm, max_rx_len=self._inputSize, bins=[0], grid=self._grid)
-                if self._plan.engine_used != "persistent" or self._plan.block != 16384:
-                    self._plan.close()
-                    self._plan = None
-            if self._plan is None:
-                self._plan = CAFPlan(self._tm, max_rx_len=self._inputSize, bins=[0], grid=self._grid, engine="rocfft")
+            self._plan = _complex_qf_plan(self._tm, self._inputSize, self._grid)
         res = self._plan.run(x, rows=False, peak=False, cqf=True)
         nout = res.cqf.reshape(T, S)
         if not returnMax:

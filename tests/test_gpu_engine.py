@@ -416,6 +416,39 @@ def test_long_template_explicit_frequencies_and_many_hypotheses():
         np.testing.assert_allclose(a[i][rows], ref, atol=1e-4 * ref.max())
 
 
+def test_65536_point_role_explicit_frequencies_and_several_templates():
+    """65536-point blocks (templates of 16385 .. 32768 samples) with an explicit frequency table (table mode: one residue-major
+    row per hypothesis), more hypotheses than one work item takes and an odd number of them, two templates, a sub-range: against
+    the rocfft engine and the oracle."""
+    from pydsproutines_amd import CAFPlan, asarray
+    from test_gpu_engine_fuzz import _oracle_rows
+
+    rng = np.random.default_rng(6)
+    n, m = 20_000, 200_000
+    tm = np.stack([qpsk(rng, n) for _ in range(2)])
+    rx = cn(rng, m)
+    freqs = np.linspace(-1.7e-4, 1.6e-4, 75)
+    truth = [(30_000, 11), (140_017, 70)]
+    for i, (d, f) in enumerate(truth):
+        rx[d : d + n] += (tm[i] * np.exp(2j * np.pi * freqs[f] * np.arange(n))).astype(np.complex64)
+    d_rx = asarray(rx)
+    p = CAFPlan(tm, max_rx_len=m, freqs_norm=freqs)
+    assert p.engine_used == "persistent" and p.block == 65536
+    r = p.run(d_rx, surface=True)
+    q = CAFPlan(tm, max_rx_len=m, freqs_norm=freqs, engine="rocfft").run(d_rx, surface=True)
+    a, b = r.surface.get(), q.surface.get()
+    assert np.max(np.abs(a - b)) <= 3e-6 * max(1.0, b.max())
+    for i, (d, f) in enumerate(truth):
+        assert (int(r.peak_delay.get()[i]), int(r.peak_freq.get()[i])) == (d, f)
+        rows = np.array([d - 1, d, d + 1, 32767, 32768, 100_000])
+        ref = _oracle_rows(tm[i], rx, freqs, rows)
+        np.testing.assert_allclose(a[i][rows], ref, atol=1e-4 * ref.max())
+    sub = p.run(d_rx, shift_start=25_000, num_shifts=40_001, surface=False)
+    np.testing.assert_allclose(sub.row_max.get(), r.row_max.get()[:, 25_000:65_001], atol=2e-6)
+    assert int(sub.peak_delay.get()[0]) == 30_000
+    p.close()
+
+
 def test_direct_engine_for_templates_with_a_handful_of_samples():
     """Composite templates whose groups cover fewer than 64 samples go to the direct (time-domain) engine: the
     overlap-save engines' float32 error follows the energy of a whole 16384-sample block, which for a normalisation
@@ -608,7 +641,7 @@ def test_zero_energy_windows_are_nan_and_never_win(engine):
 
 
 @pytest.mark.parametrize("T,F,n,m", [(1, 5, 128, 40000), (2, 32, 300, 30000), (3, 200, 64, 20000), (1, 256, 4096, 70000),
-                                     (2, 64, 8192, 50000)])
+                                     (2, 64, 8192, 50000), (3, 2, 256, 30000), (5, 3, 100, 20000), (1, 130, 512, 30000)])
 def test_hypothesis_major_surface_is_the_transposed_surface_bit_for_bit(T, F, n, m):
     """caf_outputs.d_surface_t (T, F, S): written by the FFT work items themselves (fused_item MODE 5); the same numbers as
     the delay-major surface the tile role writes, and row_max / row_arg / the peak are the maximum / first argmax of them."""
