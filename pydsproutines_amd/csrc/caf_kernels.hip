@@ -27,92 +27,150 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
     return v;
 }
 
-__global__ __launch_bounds__(PFX_THREADS) void k_power_tile_sums(const float2* __restrict__ rx, int64_t m,
-                                                                 double* __restrict__ tile_sums) {
-    __shared__ double s_part[PFX_THREADS / 64];
-    const int64_t base = (int64_t)blockIdx.x * PFX_TILE + (int64_t)threadIdx.x * PFX_PER_THREAD;
-    double acc = 0.0;
-#pragma unroll
-    for (int j = 0; j < PFX_PER_THREAD; ++j) {
-        const int64_t i = base + j;
-        if (i < m) {
-            const float2 v = rx[i];
-            acc += (double)v.x * (double)v.x + (double)v.y * (double)v.y;
-        }
-    }
-    acc = wave_sum_f64(acc);
-    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = 0.0;
-#pragma unroll
-        for (int w = 0; w < PFX_THREADS / 64; ++w) t += s_part[w];
-        tile_sums[blockIdx.x] = t;
-    }
-}
-
-// Exclusive scan of the tile sums in place, one workgroup, sequential over chunks of 1024.
+// Exclusive scan of the tile sums in place, one workgroup: a thread owns up to 16 consecutive entries, so up to 16384
+// tiles take one trip through the wave scan and the two barriers (one entry per thread and a trip per 1024 tiles took
+// 17.6 us on the 16384 tiles of a 1.7e7-sample record); longer arrays carry the total from chunk to chunk.
 __global__ __launch_bounds__(1024) void k_scan_tile_sums(double* __restrict__ tile_sums, int64_t ntiles) {
+    constexpr int MAXPER = 16;
     __shared__ double s_wave[16];
     __shared__ double s_carry;
     if (threadIdx.x == 0) s_carry = 0.0;
-    __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int64_t c = 0; c < ntiles; c += 1024) {
-        const int64_t i = c + threadIdx.x;
-        const double v = (i < ntiles) ? tile_sums[i] : 0.0;
-        double incl = v;
+    const int per = (int)((ntiles + 1023) / 1024 < MAXPER ? (ntiles + 1023) / 1024 : MAXPER);
+    for (int64_t c = 0; c < ntiles; c += (int64_t)1024 * per) {
+        const int64_t i0 = c + (int64_t)threadIdx.x * per;
+        double v[MAXPER];
+        double tot = 0.0;
+#pragma unroll
+        for (int j = 0; j < MAXPER; ++j) {
+            v[j] = (j < per && i0 + j < ntiles) ? tile_sums[i0 + j] : 0.0;
+            tot += v[j];
+        }
+        double incl = tot;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const double u = __shfl_up(incl, o, 64);
             if (lane >= o) incl += u;
         }
+        __syncthreads();  // (s_carry of the previous chunk is in place; s_wave is free)
         if (lane == 63) s_wave[wave] = incl;
         __syncthreads();
-        double woff = 0.0;
-        for (int w = 0; w < wave; ++w) woff += s_wave[w];
-        const double carry = s_carry;
-        if (i < ntiles) tile_sums[i] = carry + woff + (incl - v);
+        double run = s_carry + (incl - tot);
+        for (int w = 0; w < wave; ++w) run += s_wave[w];
+#pragma unroll
+        for (int j = 0; j < MAXPER; ++j) {
+            if (j < per && i0 + j < ntiles) tile_sums[i0 + j] = run;
+            run += v[j];
+        }
         __syncthreads();
-        if (threadIdx.x == 1023) s_carry = carry + woff + incl;
-        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = run;
     }
 }
 
-// prefix[i] for i in [0, m]  (m+1 entries); tile_off = exclusive-scanned tile sums.
-__global__ __launch_bounds__(PFX_THREADS) void k_prefix_write(const float2* __restrict__ rx, int64_t m,
-                                                              const double* __restrict__ tile_off,
-                                                              double* __restrict__ prefix) {
-    __shared__ double s_wave[PFX_THREADS / 64];
+// prefix[i] for i in [0, m] (m + 1 entries) in two launches of ONE kernel body: WRITE = false leaves the total of every
+// tile in tile_sums, WRITE = true adds up the totals of the tiles before its own (a fixed summation order; tile_sums
+// already scanned when there are more than PFX_DIRECT_TILES of them) and writes the tile's prefix; the values do not
+// depend on timing.  A tile = 256 threads x 8 samples x SUB sub-tiles, a thread's samples staying in registers (16-byte loads, 16-byte
+// stores).  24 B of traffic per sample against the 16 B of a one-launch scan -- which was built and measured
+// (scripts/ubench/tilescan_model.hip, profiles/r04/ubench/tilescan_model.log: ticketed tiles + look-back through
+// device-scope atomics, 57 us for 10^7 samples however the tiles were sized) and is not used.
+constexpr int PF_NT = 256, PF_PER = 8;
+constexpr int PFX_DIRECT_TILES = 1024;
+
+template <int SUB, bool ALIGNED, bool WRITE>
+__global__ __launch_bounds__(PF_NT) void k_prefix_tiles(const float2* __restrict__ rx, int64_t m, double* __restrict__ tile_sums,
+                                                        int32_t scanned, double* __restrict__ prefix) {
+    constexpr int NW = PF_NT / 64;
+    __shared__ double s_wave[SUB][NW];  // wave totals, then (WRITE, wave 0) what precedes each wave in the whole record
+    __shared__ double s_part[NW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t base = (int64_t)blockIdx.x * PFX_TILE + (int64_t)threadIdx.x * PFX_PER_THREAD;
-    double p[PFX_PER_THREAD];
-    double tot = 0.0;
+    const int64_t tbase = (int64_t)blockIdx.x * (PF_NT * PF_PER * SUB) + (int64_t)threadIdx.x * PF_PER;
+    float2 v[SUB][PF_PER];
 #pragma unroll
-    for (int j = 0; j < PFX_PER_THREAD; ++j) {
-        const int64_t i = base + j;
-        double e = 0.0;
-        if (i < m) {
-            const float2 v = rx[i];
-            e = (double)v.x * (double)v.x + (double)v.y * (double)v.y;
+    for (int k = 0; k < SUB; ++k) {
+        const int64_t base = tbase + (int64_t)k * PF_NT * PF_PER;
+        if (base + PF_PER <= m) {
+            if (ALIGNED) {
+#pragma unroll
+                for (int j = 0; j < PF_PER; j += 2) {
+                    const float4 q = *reinterpret_cast<const float4*>(rx + base + j);
+                    v[k][j] = make_float2(q.x, q.y);
+                    v[k][j + 1] = make_float2(q.z, q.w);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < PF_PER; ++j) v[k][j] = rx[base + j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < PF_PER; ++j) v[k][j] = base + j < m ? rx[base + j] : make_float2(0.f, 0.f);
         }
-        p[j] = tot;  // exclusive within the thread
-        tot += e;
     }
-    double incl = tot;
+    // (WRITE) the totals of the preceding tiles, while the loads are in flight: thread t adds tiles t, t + 256, ...
+    double before = 0.0;
+    if (WRITE) {
+        if (scanned) {
+            before = tile_sums[blockIdx.x];
+        } else {
+            double c = 0.0;
+            for (int t = threadIdx.x; t < (int)blockIdx.x; t += PF_NT) c += tile_sums[t];
+            c = wave_sum_f64(c);
+            if (lane == 0) s_part[wave] = c;
+        }
+    }
+    double tot[SUB], incl[SUB];
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const double u = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += u;
+    for (int k = 0; k < SUB; ++k) {
+        double t = 0.0;
+#pragma unroll
+        for (int j = 0; j < PF_PER; ++j) t += (double)v[k][j].x * (double)v[k][j].x + (double)v[k][j].y * (double)v[k][j].y;
+        tot[k] = t;
+        double in = t;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const double u = __shfl_up(in, o, 64);
+            if (lane >= o) in += u;
+        }
+        incl[k] = in;
+        if (lane == 63) s_wave[k][wave] = in;
     }
-    if (lane == 63) s_wave[wave] = incl;
     __syncthreads();
-    double off = tile_off[blockIdx.x] + (incl - tot);
-    for (int w = 0; w < wave; ++w) off += s_wave[w];
+    if (wave == 0) {
+        if (WRITE && !scanned) {
 #pragma unroll
-    for (int j = 0; j < PFX_PER_THREAD; ++j) {
-        const int64_t i = base + j;
-        if (i <= m) prefix[i] = off + p[j];
+            for (int w = 0; w < NW; ++w) before += s_part[w];
+        }
+        double run = before;  // sequential over sub-tiles and waves, the same order in every lane and in both launches
+#pragma unroll
+        for (int k = 0; k < SUB; ++k)
+            for (int w = 0; w < NW; ++w) {
+                const double t = s_wave[k][w];
+                if (WRITE && lane == w) s_wave[k][w] = run;
+                run += t;
+            }
+        if (!WRITE && lane == 0) tile_sums[blockIdx.x] = run;
+    }
+    if (!WRITE) return;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < SUB; ++k) {
+        const int64_t base = tbase + (int64_t)k * PF_NT * PF_PER;
+        const double off = s_wave[k][wave] + (incl[k] - tot[k]);
+        double p[PF_PER];
+        double t = 0.0;
+#pragma unroll
+        for (int j = 0; j < PF_PER; ++j) {
+            p[j] = off + t;  // (t: the exclusive sum within the thread, the same additions as tot[k])
+            t += (double)v[k][j].x * (double)v[k][j].x + (double)v[k][j].y * (double)v[k][j].y;
+        }
+        if (base + PF_PER <= m + 1) {
+#pragma unroll
+            for (int j = 0; j < PF_PER; j += 2) *reinterpret_cast<double2*>(prefix + base + j) = make_double2(p[j], p[j + 1]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < PF_PER; ++j)
+                if (base + j <= m) prefix[base + j] = p[j];
+        }
     }
 }
 
@@ -490,13 +548,27 @@ void launch_rows_peak(const float* rows, int32_t ntmpl, int64_t num_shifts, int6
                        num_shifts, shift_start, partial, partial_per_tmpl);
 }
 
-int64_t prefix_num_tiles(int64_t m) { return (m + 1 + PFX_TILE - 1) / PFX_TILE; }
+// doubles of scratch the prefix needs (one total per tile of the smaller tile size, + the scan's own total)
+int64_t prefix_num_tiles(int64_t m) { return (m + 1 + PF_NT * PF_PER - 1) / (PF_NT * PF_PER) + 1; }
+
+template <int SUB>
+static void launch_prefix_tiles(const float2* rx, int64_t m, double* tile_sums, double* prefix, hipStream_t st) {
+    const int64_t nt = (m + 1 + PF_NT * PF_PER * SUB - 1) / (PF_NT * PF_PER * SUB);
+    const int scanned = nt > PFX_DIRECT_TILES;
+    const dim3 g((unsigned)nt), b(PF_NT);
+    if ((reinterpret_cast<uintptr_t>(rx) & 15) == 0) {
+        hipLaunchKernelGGL((k_prefix_tiles<SUB, true, false>), g, b, 0, st, rx, m, tile_sums, 0, prefix);
+        if (scanned) hipLaunchKernelGGL(k_scan_tile_sums, dim3(1), dim3(1024), 0, st, tile_sums, nt);
+        hipLaunchKernelGGL((k_prefix_tiles<SUB, true, true>), g, b, 0, st, rx, m, tile_sums, scanned, prefix);
+    } else {
+        hipLaunchKernelGGL((k_prefix_tiles<SUB, false, false>), g, b, 0, st, rx, m, tile_sums, 0, prefix);
+        if (scanned) hipLaunchKernelGGL(k_scan_tile_sums, dim3(1), dim3(1024), 0, st, tile_sums, nt);
+        hipLaunchKernelGGL((k_prefix_tiles<SUB, false, true>), g, b, 0, st, rx, m, tile_sums, scanned, prefix);
+    }
+}
 
 void launch_energy_prefix(const float2* rx, int64_t m, double* tile_sums, double* prefix, hipStream_t st) {
-    const int64_t nt = prefix_num_tiles(m);
-    hipLaunchKernelGGL(k_power_tile_sums, dim3((unsigned)nt), dim3(PFX_THREADS), 0, st, rx, m, tile_sums);
-    hipLaunchKernelGGL(k_scan_tile_sums, dim3(1), dim3(1024), 0, st, tile_sums, nt);
-    hipLaunchKernelGGL(k_prefix_write, dim3((unsigned)nt), dim3(PFX_THREADS), 0, st, rx, m, tile_sums, prefix);
+    launch_prefix_tiles<1>(rx, m, tile_sums, prefix, st);
 }
 
 void scan_tiles(double* tile_sums, int64_t ntiles, hipStream_t st) {

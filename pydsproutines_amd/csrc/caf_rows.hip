@@ -341,35 +341,44 @@ __global__ __launch_bounds__(256) void k_moving_from_prefix(const double* __rest
     out[i] = sum_instead ? (float)s : (float)(s / (double)L);
 }
 
-// Causal moving sum / mean in ONE launch for windows up to MAT_MAXL: a workgroup stages its MAT_TILE outputs' inputs
-// (tile + L - 1 samples, zeros before the start) in LDS, builds their float64 prefix there and writes differences.
-// No global prefix array, no scratch allocation, 4 B read + 4 B written per sample (plus the halo).
-constexpr int MAT_TILE = 2048;
-constexpr int MAT_MAXL = 1024;  // (tile + window in LDS as float32 + float64 prefix: 64 KB of dynamic LDS)
+// Causal moving sum / mean in ONE launch for windows up to MAT_MAXL: a workgroup covers MAT_SPAN consecutive samples
+// (its outputs preceded by a halo of the window, zeros before the start), each thread 8 of them straight from two
+// 16-byte loads; their float64 inclusive prefix is built in registers (thread, wave shuffle, wave totals) and only the
+// prefix goes through LDS, once: out[i] = P[i] - P[i - L].  No global prefix array, no scratch; 4 B read + 4 B written
+// per sample plus the halo.  (The form this replaces staged the samples in LDS as well and read them twice: six LDS
+// operations per sample against three, 47 us against the time in profiles/ for 2^24 samples.)
+constexpr int MAT_NT = 256, MAT_PER = 8;
+constexpr int MAT_SPAN = MAT_NT * MAT_PER;
+constexpr int MAT_MAXL = 1024;
+// prefix through slot t lives at s_p[mat_slot(t + 1)]: one pad per 8 entries, so that the 8-consecutive writes of a
+// thread (stride 9 doubles across lanes) and the consecutive reads of the output loop both spread over the banks
+__device__ __forceinline__ int mat_slot(int t) { return t + (t >> 3); }
+__host__ __device__ inline int mat_halo(int L) { return (L - 1 + 3) & ~3; }       // slots before the first output
+__host__ __device__ inline int mat_outputs(int L) { return MAT_SPAN - mat_halo(L); }  // outputs per workgroup (multiple of 4)
 
-// MAT_NT threads: with 256 the three serial per-thread loops ran 17 dependent steps each (L = 100) and a workgroup's
-// critical path was latency, not bandwidth (58 us for 2^24 samples); 1024 threads own 5 samples each
-constexpr int MAT_NT = 512;
 __global__ __launch_bounds__(MAT_NT) void k_moving_tile(const float* __restrict__ x, int64_t n, int32_t L, int32_t sum_instead,
                                                         float* __restrict__ out) {
-    extern __shared__ double s_mat[];
-    const int W = MAT_TILE + L - 1;                 // samples i0 - L + 1 .. i0 + MAT_TILE - 1
-    const int per = ((W + MAT_NT - 1) / MAT_NT) | 1;  // samples per thread, odd (LDS banks)
-    double* s_p = s_mat;                            // exclusive prefix, MAT_NT * per + 1 entries
-    float* s_x = reinterpret_cast<float*>(s_mat + MAT_NT * per + 1);
+    __shared__ double s_p[MAT_SPAN + MAT_SPAN / 8 + 2];
     __shared__ double s_wave[MAT_NT / 64];
     const float* xr = x + (int64_t)blockIdx.y * n;
     float* outr = out + (int64_t)blockIdx.y * n;
-    const int64_t i0 = (int64_t)blockIdx.x * MAT_TILE;
-    for (int t = threadIdx.x; t < MAT_NT * per; t += MAT_NT) {
-        const int64_t j = i0 - (L - 1) + t;
-        s_x[t] = (t < W && j >= 0 && j < n) ? xr[j] : 0.f;
-    }
-    __syncthreads();
+    const int H = mat_halo(L), T = MAT_SPAN - H;
+    const int64_t i0 = (int64_t)blockIdx.x * T;  // first output of the workgroup; slot t <-> sample i0 - H + t
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int e0 = threadIdx.x * per;
+    const int t0 = threadIdx.x * MAT_PER;
+    const int64_t j0 = i0 - H + t0;
+    float v[MAT_PER];
+    if (j0 >= 0 && j0 + MAT_PER <= n && (reinterpret_cast<uintptr_t>(xr + j0) & 15) == 0) {
+        const float4 a = *reinterpret_cast<const float4*>(xr + j0), b = *reinterpret_cast<const float4*>(xr + j0 + 4);
+        v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w, v[4] = b.x, v[5] = b.y, v[6] = b.z, v[7] = b.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < MAT_PER; ++k) v[k] = (j0 + k >= 0 && j0 + k < n) ? xr[j0 + k] : 0.f;
+    }
+    double pl[MAT_PER];
     double tot = 0.0;
-    for (int j = 0; j < per; ++j) tot += (double)s_x[e0 + j];
+#pragma unroll
+    for (int k = 0; k < MAT_PER; ++k) pl[k] = (tot += (double)v[k]);
     double incl = tot;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -377,20 +386,18 @@ __global__ __launch_bounds__(MAT_NT) void k_moving_tile(const float* __restrict_
         if (lane >= o) incl += u;
     }
     if (lane == 63) s_wave[wave] = incl;
+    if (threadIdx.x == 0) s_p[0] = 0.0;
     __syncthreads();
-    double run = incl - tot;
-    for (int w = 0; w < wave; ++w) run += s_wave[w];
-    for (int j = 0; j < per; ++j) {
-        s_p[e0 + j] = run;
-        run += (double)s_x[e0 + j];
-    }
-    if (threadIdx.x == MAT_NT - 1) s_p[MAT_NT * per] = run;
+    double off = incl - tot;
+    for (int w = 0; w < wave; ++w) off += s_wave[w];
+#pragma unroll
+    for (int k = 0; k < MAT_PER; ++k) s_p[mat_slot(t0 + k + 1)] = off + pl[k];
     __syncthreads();
-    for (int l = threadIdx.x; l < MAT_TILE; l += MAT_NT) {
+    for (int l = threadIdx.x; l < T; l += MAT_NT) {
         const int64_t i = i0 + l;
         if (i >= n) break;
-        // window of output i: samples i - L + 1 .. i  ->  tile-local l .. l + L - 1
-        const double s = s_p[l + L] - s_p[l];
+        const int t = H + l;  // window of output i: slots t - L + 1 .. t
+        const double s = s_p[mat_slot(t + 1)] - s_p[mat_slot(t + 1 - L)];
         outr[i] = sum_instead ? (float)s : (float)(s / (double)L);
     }
 }
@@ -632,39 +639,59 @@ __global__ __launch_bounds__(256) void k_copy_groups(const float2* __restrict__ 
     for (int i = threadIdx.x; i < lens[b]; i += 256) y[yo + i] = x[xo + i];
 }
 
-// findLocalMaxima: ordered (ascending index) compaction without atomics, in three launches that all fill the chip:
-//   1. every workgroup counts the local maxima of its LM_TILE samples,
-//   2. one workgroup turns the tile counts into exclusive offsets (+ the total),
-//   3. every workgroup recomputes its flags and writes its indices at offset + rank.
-// (x is read twice instead of writing and re-reading a flag array; the single-workgroup compaction this replaces
-// took ~16 ms on a 2^24-sample trace.)
-constexpr int LM_TILE = 4096;  // samples per workgroup (16 per thread)
+// findLocalMaxima (peakfinding.cu:14-58 predicate: above min_height and above both neighbours, zeros beyond the ends):
+// ordered (ascending index) compaction that reads x ONCE.  Launch 1: a thread owns LM_PER consecutive samples
+// (neighbours from the adjacent lanes), keeps its flags as a bit mask (n / 8 bytes of scratch) and the workgroup adds up
+// the tile's count.  Launch 2 never touches x: a workgroup sums the counts of the tiles before its own (or reads the
+// scanned counts when there are many tiles), ranks its masks with a workgroup scan and writes the indices; tiles
+// without a maximum leave at once.  (A single-launch form with a ticketed look-back, scripts/ubench/tilescan_model.hip,
+// costs more than this second launch: same-address tickets are served at ~10 ns each.)
+constexpr int LM_NT = 1024, LM_PER = 16;
+constexpr int LM_TILE = LM_NT * LM_PER;
+constexpr int LM_DIRECT_TILES = 4096;  // up to here launch 2 adds the preceding counts itself (<= 16 KB per workgroup)
 
-__device__ __forceinline__ bool lm_flag(const float* __restrict__ x, int64_t n, int64_t i, float min_height) {
-    if (i >= n) return false;
-    const float y = x[i];
-    const float l = i > 0 ? x[i - 1] : 0.f;
-    const float r = i + 1 < n ? x[i + 1] : 0.f;
-    return y > min_height && y > l && y > r;
-}
-
-__global__ __launch_bounds__(256) void k_local_max_count(const float* __restrict__ x, int64_t n, float min_height,
-                                                         int32_t* __restrict__ tile_count) {
-    __shared__ int32_t s_w[4];
-    const int64_t i0 = (int64_t)blockIdx.x * LM_TILE;
-    int c = 0;
+template <bool ALIGNED>
+__global__ __launch_bounds__(LM_NT) void k_local_max_flags(const float* __restrict__ x, int64_t n, float min_height,
+                                                           uint16_t* __restrict__ masks, int32_t* __restrict__ tile_count) {
+    __shared__ int32_t s_w[LM_NT / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t base = (int64_t)blockIdx.x * LM_TILE + (int64_t)threadIdx.x * LM_PER;
+    float v[LM_PER];
+    if (ALIGNED && base + LM_PER <= n) {
 #pragma unroll
-    for (int k = 0; k < LM_TILE / 256; ++k) c += lm_flag(x, n, i0 + k * 256 + threadIdx.x, min_height) ? 1 : 0;
+        for (int j = 0; j < LM_PER; j += 4) {
+            const float4 q = *reinterpret_cast<const float4*>(x + base + j);
+            v[j] = q.x, v[j + 1] = q.y, v[j + 2] = q.z, v[j + 3] = q.w;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < LM_PER; ++j) v[j] = base + j < n ? x[base + j] : 0.f;
+    }
+    float left = __shfl_up(v[LM_PER - 1], 1, 64), right = __shfl_down(v[0], 1, 64);
+    if (lane == 0) left = base > 0 && base - 1 < n ? x[base - 1] : 0.f;
+    if (lane == 63) right = base + LM_PER < n ? x[base + LM_PER] : 0.f;
+    uint32_t mask = 0;
+#pragma unroll
+    for (int j = 0; j < LM_PER; ++j) {
+        const float l = j ? v[j - 1] : left, r = j + 1 < LM_PER ? v[j + 1] : right;
+        if (base + j < n && v[j] > min_height && v[j] > l && v[j] > r) mask |= 1u << j;
+    }
+    masks[(int64_t)blockIdx.x * LM_NT + threadIdx.x] = (uint16_t)mask;
+    int c = __popc(mask);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
+    if (lane == 0) s_w[wave] = c;
     __syncthreads();
-    if (threadIdx.x == 0) tile_count[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    if (threadIdx.x == 0) {
+        int t = 0;
+#pragma unroll
+        for (int w = 0; w < LM_NT / 64; ++w) t += s_w[w];
+        tile_count[blockIdx.x] = t;
+    }
 }
 
-// in place: tile_count[t] -> number of maxima before tile t; tile_count[ntiles] and *count = the total
-__global__ __launch_bounds__(1024) void k_local_max_scan(int32_t* __restrict__ tile_count, int64_t ntiles,
-                                                         int32_t* __restrict__ count) {
+// in place: tile_count[t] -> number of maxima before tile t; tile_count[ntiles] = the total (many tiles only)
+__global__ __launch_bounds__(1024) void k_local_max_scan(int32_t* __restrict__ tile_count, int64_t ntiles) {
     __shared__ int32_t s_wave[16];
     __shared__ int32_t s_base;
     if (threadIdx.x == 0) s_base = 0;
@@ -688,35 +715,61 @@ __global__ __launch_bounds__(1024) void k_local_max_scan(int32_t* __restrict__ t
         if (threadIdx.x == 1023) s_base = off + incl;
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
-        tile_count[ntiles] = s_base;
-        *count = s_base;
-    }
+    if (threadIdx.x == 0) tile_count[ntiles] = s_base;
 }
 
-__global__ __launch_bounds__(256) void k_local_max_write(const float* __restrict__ x, int64_t n, float min_height,
-                                                         const int32_t* __restrict__ tile_base, int32_t max_out,
-                                                         int32_t* __restrict__ idx) {
-    __shared__ int32_t s_w[4];
-    __shared__ int32_t s_run;
-    const int64_t i0 = (int64_t)blockIdx.x * LM_TILE;
-    if (tile_base[blockIdx.x + 1] == tile_base[blockIdx.x]) return;  // nothing in this tile (uniform)
-    if (threadIdx.x == 0) s_run = tile_base[blockIdx.x];
-    __syncthreads();
+__global__ __launch_bounds__(LM_NT) void k_local_max_write(const uint16_t* __restrict__ masks, const int32_t* __restrict__ tile_count,
+                                                           int32_t scanned, int32_t max_out, int32_t* __restrict__ idx,
+                                                           int32_t* __restrict__ count) {
+    __shared__ int32_t s_w[LM_NT / 64];
+    __shared__ int32_t s_before;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int k = 0; k < LM_TILE / 256; ++k) {  // ascending index order: chunk k holds samples i0 + 256 k ...
-        const int64_t i = i0 + k * 256 + threadIdx.x;
-        const bool f = lm_flag(x, n, i, min_height);
-        const unsigned long long m = __ballot(f);
-        const int within = __popcll(m & ((1ull << lane) - 1ull));
-        if (lane == 0) s_w[wave] = __popcll(m);
+    const bool last = blockIdx.x == gridDim.x - 1;
+    int mine, before;
+    if (scanned) {
+        before = tile_count[blockIdx.x];
+        mine = tile_count[blockIdx.x + 1] - before;
+        if (last && threadIdx.x == 0) *count = before + mine;
+        if (mine == 0) return;  // (uniform)
+    } else {
+        mine = tile_count[blockIdx.x];
+        if (mine == 0 && !last) return;  // (uniform)
+        int c = 0;
+        for (int t = threadIdx.x; t < (int)blockIdx.x; t += LM_NT) c += tile_count[t];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+        if (lane == 0) s_w[wave] = c;
         __syncthreads();
-        int off = s_run;
-        for (int w = 0; w < wave; ++w) off += s_w[w];
-        if (f && off + within < max_out) idx[off + within] = (int32_t)i;
+        if (threadIdx.x == 0) {
+            int t = 0;
+#pragma unroll
+            for (int w = 0; w < LM_NT / 64; ++w) t += s_w[w];
+            s_before = t;
+            if (last) *count = t + mine;
+        }
         __syncthreads();
-        if (threadIdx.x == 0) s_run += s_w[0] + s_w[1] + s_w[2] + s_w[3];
-        __syncthreads();
+        before = s_before;
+        if (mine == 0) return;
+        __syncthreads();  // (s_w is reused below)
+    }
+    uint32_t mask = masks[(int64_t)blockIdx.x * LM_NT + threadIdx.x];
+    const int c = __popc(mask);
+    int incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += u;
+    }
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    int off = before + (incl - c);
+    for (int w = 0; w < wave; ++w) off += s_w[w];
+    const int64_t base = (int64_t)blockIdx.x * LM_TILE + (int64_t)threadIdx.x * LM_PER;
+    while (mask) {
+        const int j = __ffs(mask) - 1;
+        mask &= mask - 1;
+        if (off < max_out) idx[off] = (int32_t)(base + j);
+        ++off;
     }
 }
 
@@ -1495,15 +1548,25 @@ void launch_copy_groups(const float2* x, float2* y, const int32_t* xs, const int
     if (ngroups > 0) hipLaunchKernelGGL(k_copy_groups, dim3(ngroups), dim3(256), 0, st, x, y, xs, ys, lens);
 }
 
-int64_t local_maxima_scratch_ints(int64_t n) { return (n + LM_TILE - 1) / LM_TILE + 1; }
+// scratch: the tile counts (+ the total) followed by one 16-bit mask per thread of launch 1
+int64_t local_maxima_scratch_ints(int64_t n) {
+    const int64_t ntiles = (n + LM_TILE - 1) / LM_TILE;
+    return ((ntiles + 1 + 3) & ~(int64_t)3) + ntiles * LM_NT / 2;
+}
 
 void launch_find_local_maxima(const float* x, int64_t n, float min_height, int32_t* tile_scratch, int32_t max_out,
                               int32_t* idx, int32_t* count, hipStream_t st) {
     const int64_t ntiles = (n + LM_TILE - 1) / LM_TILE;
-    hipLaunchKernelGGL(k_local_max_count, dim3((unsigned)ntiles), dim3(256), 0, st, x, n, min_height, tile_scratch);
-    hipLaunchKernelGGL(k_local_max_scan, dim3(1), dim3(1024), 0, st, tile_scratch, ntiles, count);
-    hipLaunchKernelGGL(k_local_max_write, dim3((unsigned)ntiles), dim3(256), 0, st, x, n, min_height, tile_scratch, max_out,
-                       idx);
+    uint16_t* masks = reinterpret_cast<uint16_t*>(tile_scratch + ((ntiles + 1 + 3) & ~(int64_t)3));
+    if ((reinterpret_cast<uintptr_t>(x) & 15) == 0)
+        hipLaunchKernelGGL(k_local_max_flags<true>, dim3((unsigned)ntiles), dim3(LM_NT), 0, st, x, n, min_height, masks, tile_scratch);
+    else
+        hipLaunchKernelGGL(k_local_max_flags<false>, dim3((unsigned)ntiles), dim3(LM_NT), 0, st, x, n, min_height, masks,
+                           tile_scratch);
+    const int scanned = ntiles > LM_DIRECT_TILES;
+    if (scanned) hipLaunchKernelGGL(k_local_max_scan, dim3(1), dim3(1024), 0, st, tile_scratch, ntiles);
+    hipLaunchKernelGGL(k_local_max_write, dim3((unsigned)ntiles), dim3(LM_NT), 0, st, masks, tile_scratch, scanned, max_out, idx,
+                       count);
 }
 
 void launch_gather_b32(const void* x, int64_t xlen, const int32_t* idx, int64_t n, void* out, hipStream_t st) {
@@ -1520,10 +1583,8 @@ int moving_tile_max_window() { return MAT_MAXL; }
 
 void launch_moving_tile(const float* x, int64_t rows, int64_t n, int32_t L, int32_t sum_instead, float* out,
                         hipStream_t st) {
-    const int W = MAT_TILE + L - 1;
-    const int per = ((W + MAT_NT - 1) / MAT_NT) | 1;
-    const size_t sm = (size_t)(MAT_NT * per + 1) * sizeof(double) + (size_t)(MAT_NT * per) * sizeof(float);
-    hipLaunchKernelGGL(k_moving_tile, dim3(cdiv(n, MAT_TILE), (unsigned)rows), dim3(MAT_NT), sm, st, x, n, L, sum_instead, out);
+    hipLaunchKernelGGL(k_moving_tile, dim3(cdiv(n, mat_outputs(L)), (unsigned)rows), dim3(MAT_NT), 0, st, x, n, L, sum_instead,
+                       out);
 }
 
 bool fir_decim_ok(int32_t ntaps, int32_t dsr) { return dsr >= 1 && dsr <= FIRD_MAXDSR && ntaps <= 2048; }

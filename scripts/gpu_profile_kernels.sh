@@ -20,6 +20,10 @@ for w in $WL; do
   PROFILE_REPS_SCALE=${PROFILE_REPS_SCALE:-5} rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$w/trace -- python3 scripts/profile_workloads.py $w $OUT/$w/manifest.json > $OUT/$w/trace.log 2>&1 || { tail -20 $OUT/$w/trace.log; exit 1; }
   PROFILE_REPS_SCALE=1 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/$w/pmc_fetch -- python3 scripts/profile_workloads.py $w $OUT/$w/manifest_pmc.json > $OUT/$w/fetch.log 2>&1 || { tail -20 $OUT/$w/fetch.log; exit 1; }
   PROFILE_REPS_SCALE=1 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/$w/pmc_write -- python3 scripts/profile_workloads.py $w > $OUT/$w/write.log 2>&1 || { tail -20 $OUT/$w/write.log; exit 1; }
+  # where the waves' cycles go (SQ counters, a pass of their own; asked for with PROFILE_SQ=1: the small kernels)
+  if [ -n "$PROFILE_SQ" ]; then
+    PROFILE_REPS_SCALE=1 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU SQ_WAVES --kernel-trace --output-format csv -d $OUT/$w/pmc_sq -- python3 scripts/profile_workloads.py $w > $OUT/$w/sq.log 2>&1 || { tail -20 $OUT/$w/sq.log; exit 1; }
+  fi
 done
 python3 scripts/summarize_kernels.py $OUT > $OUT/kernels_summary.txt
 cat $OUT/kernels_summary.txt

@@ -325,6 +325,8 @@ def w_kernels_misc():
         multiTemplateSlidingDotProduct(d_x[: 10_000_100], d_t, 0, 10_000_000)
     man.append(("k_multi_template_dot", "20 templates x 100 over 1e7 slides (8 B read + 8 B written per slide; 2*20*100*8 flop per slide)",
                 10_000_000 * 16.0, 10_000_000 * 20 * 100 * 8.0, 2))
+    man.append(("k_prefix_tiles|k_scan_tile_sums", "float64 energy prefix of 1e7 samples: tile totals, their scan, the write (8 B read + 8 B written per sample)",
+                10_000_100 * 16.0, 0.0, 2))
     f = CupyKernelFilter()
     d_tp = asarray((rng.standard_normal(1024) / 32).astype(np.float32))
     for _ in range(3):
@@ -349,7 +351,7 @@ def w_kernels_misc():
                 d_m.size * 8.0 + out.size * 8.0, 0.0, 3))
     for _ in range(3):
         cupyFindLocalMaxima(d_p, 3.0)
-    man.append(("k_local_max", "local maxima of a 2^24 float trace (4 B read per sample x 2 passes)", n * 8.0, 0.0, 3))
+    man.append(("k_local_max", "local maxima of a 2^24 float trace, both launches (4 B read per sample)", n * 4.0, 0.0, 3))
     sync()
     return man
 

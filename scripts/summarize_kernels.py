@@ -15,6 +15,8 @@ import sys
 from collections import defaultdict
 
 HBM_PEAK, F32_PEAK = 8000.0, 157.3
+SQ_COUNTERS = ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_LDS", "SQ_LDS_BANK_CONFLICT",
+               "SQ_ACTIVE_INST_VALU", "SQ_WAVES")
 
 
 def find(root, pattern):
@@ -72,6 +74,8 @@ def main(out):
         trace = load_trace(find(os.path.join(wdir, "trace"), "*kernel_trace.csv"))
         fetch = load_pmc(find(os.path.join(wdir, "pmc_fetch"), "*counter_collection.csv"), "FETCH_SIZE")
         write = load_pmc(find(os.path.join(wdir, "pmc_write"), "*counter_collection.csv"), "WRITE_SIZE")
+        sq_path = find(os.path.join(wdir, "pmc_sq"), "*counter_collection.csv")
+        sq = {c: load_pmc(sq_path, c) for c in SQ_COUNTERS} if sq_path else None
         total_us = sum(v[1] for v in trace.values()) or 1.0
         print("=" * 150)
         print("workload %s   (all kernels of the run: %.1f ms)" % (name, total_us / 1e3))
@@ -103,7 +107,17 @@ def main(out):
                 fb / 1e9, wb / 1e9, ("%.2f" % ratio) if ratio else "-"))
             print("      %s" % e["what"])
             print("      per dispatch: median %.1f us, minimum %.1f us over %d dispatches" % (med_us, min_us, disp))
-            wres["kernels"].append({"kernel": e["kernel"], "what": e["what"], "matched": ks, "dispatches": disp, "calls": calls,
+            sqrec = None
+            if sq:
+                tot = {c: sum(sq[c].get(k, 0.0) for k in ks) for c in SQ_COUNTERS}
+                wc = tot["SQ_WAVE_CYCLES"] or 1.0
+                sqrec = {c: tot[c] for c in SQ_COUNTERS}
+                print("      wave cycles: %.0f %% parked (s_waitcnt / barrier), %.0f %% issue-stalled, %.0f %% issuing (VALU %.0f %%, LDS %.0f %%); "
+                      "LDS bank-conflict cycles = %.0f %% of the LDS-active cycles" % (
+                          100 * tot["SQ_WAIT_ANY"] / wc, 100 * tot["SQ_WAIT_INST_ANY"] / wc, 100 * tot["SQ_ACTIVE_INST_ANY"] / wc,
+                          100 * tot["SQ_ACTIVE_INST_VALU"] / wc, 100 * tot["SQ_ACTIVE_INST_LDS"] / wc,
+                          100 * tot["SQ_LDS_BANK_CONFLICT"] / max(tot["SQ_ACTIVE_INST_LDS"], 1.0)))
+            wres["kernels"].append({"kernel": e["kernel"], "what": e["what"], "matched": ks, "sq": sqrec, "dispatches": disp, "calls": calls,
                                     "total_ms": tus / 1e3, "avg_launch_us": tus / max(disp, 1), "median_launch_us": med_us,
                                     "min_launch_us": min_us, "per_call_us": per_call_us,
                                     "alg_bytes_per_call": ab, "achieved_GBs": gbs, "frac_hbm_peak": gbs / HBM_PEAK,
