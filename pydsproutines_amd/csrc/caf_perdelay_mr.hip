@@ -1,25 +1,30 @@
-// Per-delay correlator for cutouts of N = 2^a 3^b 5^c samples (32 <= N <= 16200, N neither a power of two nor of ten: those
-// have kernels of their own in caf_perdelay.hip): rx window x conj(cutout) -> N-point FFT in LDS -> |.|^2 -> (max, first
+// Per-delay correlator for cutouts of N = 2^a 3^b 5^c 7^d samples (32 <= N <= 16200, N neither a power of two nor of ten:
+// those have kernels of their own in caf_perdelay.hip): rx window x conj(cutout) -> N-point FFT in LDS -> |.|^2 -> (max, first
 // argmax) per delay, in ONE kernel -- the reference's literal per-delay algorithm (fastXcorr branches B / C,
 // xcorrRoutines.py:511-566; cp_fastXcorr :29-167, whose cutout length is a free argument, benchmark_xcorrs.py:62-71;
 // IppXcorrFFT.cpp:94-178) without the (rows, N) product matrix that the product kernel -> rocFFT rows -> argmax chain
 // moves through HBM four times.
 //
-// Mixed-radix Stockham autosort transform, radices from {16, 10, 8, 5, 4, 3, 2}, chosen on the host (fewest passes, the
-// largest first).  The lengths are too many to instantiate one kernel each, so the passes after the first are driven by
+// Mixed-radix Stockham autosort transform, radices from {2 .. 10, 12, 14, 15, 16, 18, 20} (the composite ones as
+// Cooley-Tukey butterflies in registers: 1200 = 15 x 10 x 8 is three exchanges where 16 x 5 x 5 x 3 was four), chosen on
+// the host together with the threads per row by a cost model (mr_plan: butterfly points per thread + a charge per pass,
+// times the threads a row occupies).  The lengths are too many to instantiate one kernel each, so the passes after the first are driven by
 // a small plan in the kernel arguments: a uniform switch picks the butterfly, the trip counts are compile-time bounds with
-// a guard (a thread owns up to MR_PT = 20 points: floor(20 / R) butterflies of radix R), divisions by the pass stride are
-// multiplications by a host-prepared reciprocal.  Only the FIRST radix is a template parameter: that pass is the one with
-// the global loads.  One LDS image per row (padded by one element per sixteen), inputs
-// read before a barrier and outputs written after it; ceil(N / 16) threads per row, several rows per workgroup for short
-// cutouts.  Window energies from the caller's float64 prefix and ||cutout|| from launch_cutout_norm, exactly as the
+// a guard (a thread owns up to MR_PT = 20 points: at most floor(20 / R) butterflies of radix R, ceil(N / R / tpr) of them
+// used), divisions by the pass stride are multiplications by a host-prepared reciprocal.  Only the FIRST radix is a
+// template parameter: that pass is the one with the global loads.  One LDS image per row (padded by one element per
+// sixteen), inputs read before a barrier and outputs written after it; tpr threads per row (N / 16 ... N / 12), several
+// rows per workgroup for short cutouts.  Window energies from the caller's float64 prefix and ||cutout|| from launch_cutout_norm, exactly as the
 // three-kernel form and the radix-10 kernel normalise; same out-of-range and zero-energy rules (include/caf.h).
 #include <algorithm>
 #include <cmath>
 #include <complex>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <mutex>
+#include <string>
 #include <vector>
 
 #include "caf_internal.h"
@@ -34,10 +39,99 @@ constexpr int MR_PT = 20;   // points per thread and pass
 struct MrPlan {
     int32_t n, tpr, rpw, npass, img;      // length, threads per row, rows per workgroup, passes, padded row image (elements)
     int32_t radix[MR_MAXP], ns[MR_MAXP];  // pass p: radix, product of the radices before it
+    int32_t cnt[MR_MAXP];                 // butterflies per thread of pass p: ceil(n / radix / tpr) <= floor(MR_PT / radix)
     uint32_t ns_rcp[MR_MAXP];             // floor(2^32 / ns) + 1: j / ns == umulhi(j, ns_rcp) for j < 2^16
 };
 
 __device__ __forceinline__ int mr_pad(int a) { return a + (a >> 4); }
+
+// e^{+j 2 pi q / R} as compile-time constants (the butterflies below index them with unrolled loop counters)
+constexpr double mr_poly_sin(double x) {  // |x| <= pi / 4
+    const double x2 = x * x;
+    return x * (1.0 + x2 * (-1.0 / 6 + x2 * (1.0 / 120 + x2 * (-1.0 / 5040 + x2 * (1.0 / 362880 + x2 * (-1.0 / 39916800 + x2 * (1.0 / 6227020800.0)))))));
+}
+constexpr double mr_poly_cos(double x) {  // |x| <= pi / 4
+    const double x2 = x * x;
+    return 1.0 + x2 * (-0.5 + x2 * (1.0 / 24 + x2 * (-1.0 / 720 + x2 * (1.0 / 40320 + x2 * (-1.0 / 3628800 + x2 * (1.0 / 479001600 + x2 * (-1.0 / 87178291200.0)))))));
+}
+constexpr double MR_PI = 3.14159265358979323846;
+// cos / sin of 2 pi q / r through the octant of q / r: exact zeros, halves and signs where they belong
+constexpr double mr_cos_frac(int q, int r) {
+    q %= r;
+    if (2 * q > r) return mr_cos_frac(r - q, r);               // cos(2 pi - t) = cos t
+    if (4 * q > r) return -mr_cos_frac(r - 2 * q, 2 * r);      // cos(t) = -cos(pi - t); pi - t = 2 pi (r - 2q) / (2r)
+    if (8 * q > r) return mr_poly_sin(MR_PI / 2 - 2 * MR_PI * q / r);
+    return mr_poly_cos(2 * MR_PI * q / r);
+}
+constexpr double mr_sin_frac(int q, int r) {
+    q %= r;
+    if (2 * q > r) return -mr_sin_frac(r - q, r);
+    if (4 * q > r) return mr_sin_frac(r - 2 * q, 2 * r);
+    if (8 * q > r) return mr_poly_cos(MR_PI / 2 - 2 * MR_PI * q / r);
+    return mr_poly_sin(2 * MR_PI * q / r);
+}
+template <int R>
+struct MrW {
+    float c[R], s[R];
+    constexpr MrW() : c(), s() {
+        for (int q = 0; q < R; ++q) {
+            c[q] = (float)mr_cos_frac(q, R);
+            s[q] = (float)mr_sin_frac(q, R);
+        }
+    }
+};
+template <int R>
+__device__ __forceinline__ void mr_idft(float2* v);
+
+// inverse 7-point DFT (kernel e^{+j 2 pi n k / 7}): X[k], X[7 - k] = a_k +- j b_k from the sums and differences of the pairs
+__device__ __forceinline__ void idft7(float2* v) {
+    constexpr MrW<7> W = MrW<7>();
+    const float2 x0 = v[0];
+    float2 t[3], d[3];
+#pragma unroll
+    for (int m = 1; m <= 3; ++m) t[m - 1] = cadd(v[m], v[7 - m]), d[m - 1] = csub(v[m], v[7 - m]);
+    v[0] = make_float2(x0.x + t[0].x + t[1].x + t[2].x, x0.y + t[0].y + t[1].y + t[2].y);
+#pragma unroll
+    for (int k = 1; k <= 3; ++k) {
+        float2 a = x0, b = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int m = 1; m <= 3; ++m) {
+            const float c = W.c[(m * k) % 7], sn = W.s[(m * k) % 7];
+            a.x = __builtin_fmaf(c, t[m - 1].x, a.x), a.y = __builtin_fmaf(c, t[m - 1].y, a.y);
+            b.x = __builtin_fmaf(sn, d[m - 1].x, b.x), b.y = __builtin_fmaf(sn, d[m - 1].y, b.y);
+        }
+        v[k] = make_float2(a.x - b.y, a.y + b.x);      // a + j b
+        v[7 - k] = make_float2(a.x + b.y, a.y - b.x);  // a - j b
+    }
+}
+
+// Cooley-Tukey butterfly of R = A B points in registers: n = B a + b, k = k1 + A k2;
+//   X[k1 + A k2] = sum_b W_B^{b k2} ( W_R^{b k1} sum_a W_A^{a k1} x[B a + b] )
+template <int A, int B>
+__device__ __forceinline__ void idft_ct(float2* v) {
+    constexpr int R = A * B;
+    constexpr MrW<R> W = MrW<R>();
+    float2 y[R];
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+        float2 t[A];
+#pragma unroll
+        for (int a = 0; a < A; ++a) t[a] = v[B * a + b];
+        mr_idft<A>(t);
+#pragma unroll
+        for (int k1 = 0; k1 < A; ++k1)
+            y[b * A + k1] = (b * k1) ? cmul(t[k1], make_float2(W.c[(b * k1) % R], W.s[(b * k1) % R])) : t[k1];
+    }
+#pragma unroll
+    for (int k1 = 0; k1 < A; ++k1) {
+        float2 u[B];
+#pragma unroll
+        for (int b = 0; b < B; ++b) u[b] = y[b * A + k1];
+        mr_idft<B>(u);
+#pragma unroll
+        for (int k2 = 0; k2 < B; ++k2) v[k1 + A * k2] = u[k2];
+    }
+}
 
 template <int R>
 __device__ __forceinline__ void mr_idft(float2* v) {
@@ -45,12 +139,20 @@ __device__ __forceinline__ void mr_idft(float2* v) {
     if constexpr (R == 3) idft3(v[0], v[1], v[2]);
     if constexpr (R == 4) idft4(v[0], v[1], v[2], v[3]);
     if constexpr (R == 5) idft5(v[0], v[1], v[2], v[3], v[4]);
+    if constexpr (R == 6) idft_ct<3, 2>(v);
+    if constexpr (R == 7) idft7(v);
     if constexpr (R == 8) idft8(*reinterpret_cast<float2(*)[8]>(v));
+    if constexpr (R == 9) idft_ct<3, 3>(v);
     if constexpr (R == 10) idft10(*reinterpret_cast<float2(*)[10]>(v));
+    if constexpr (R == 12) idft_ct<4, 3>(v);
+    if constexpr (R == 14) idft_ct<7, 2>(v);
+    if constexpr (R == 15) idft_ct<5, 3>(v);
     if constexpr (R == 16) idft16(*reinterpret_cast<float2(*)[16]>(v));
+    if constexpr (R == 18) idft_ct<3, 6>(v);
+    if constexpr (R == 20) idft_ct<5, 4>(v);
 }
 
-// One Stockham pass of radix R with ns = the product of the earlier radices: image -> registers, barrier, twiddles,
+// One Stockham pass (any but the first) of radix R with ns = the product of the earlier radices: image -> registers, barrier, twiddles,
 // butterflies, registers -> image, barrier.  Nothing is live across a pass but the image: each of the seven bodies behind the
 // uniform switch gets a register allocation of its own (with the data registers carried from pass to pass through the
 // switch, and the last pass' outputs into a per-radix epilogue, every body spilled 10 .. 20 registers at 128).
@@ -60,48 +162,51 @@ __device__ __forceinline__ void mr_idft(float2* v) {
 // (maximum, first index) come straight from the registers -- register (c, t) <-> spectrum index j + t N / R, visited t-major,
 // i.e. ascending (a clamped butterfly offers the last one's value at the last one's index again: the strict comparison
 // ignores it) -- and the row saves a round trip through the image and two barriers.
-template <int R, bool FIRST>
+template <int R>
 __device__ __forceinline__ void mr_pass(const MrPlan& pl, int p, float2* __restrict__ buf, const float2* __restrict__ tw, int l_in,
                                         bool active, float2 (&v)[MR_PT], bool last_reg, float inv, float& bv, uint32_t& bi) {
     constexpr int CNT = MR_PT / R;
     const int nb = pl.n / R, ns = pl.ns[p], tpr = pl.tpr;
+    const int cnt = pl.cnt[p];  // butterflies per thread that the pass needs (uniform, <= CNT): ceil(nb / tpr)
     // (an opaque copy of the lane's index: the image addresses of a radix depend on nothing that changes from row to row,
     //  and hoisted out of the row loop -- twenty per radix, seven radices -- they were spilled: ~330 registers of scratch)
     int l = l_in;
     asm volatile("" : "+v"(l));
-    if (!FIRST) {
-        // the twiddle bases W_{R ns}^k = W_N^{k N / (R ns)} of all of the thread's butterflies are fetched FIRST: they do not
-        // depend on the image, and their L1 / L2 latency then runs under the image reads and the barrier
-        const int tws = nb / ns;
-        float2 w1[CNT];
+    // the twiddle bases W_{R ns}^k = W_N^{k N / (R ns)} of all of the thread's butterflies are fetched FIRST: they do not
+    // depend on the image, and their L1 / L2 latency then runs under the image reads and the barrier
+    const int tws = nb / ns;
+    float2 w1[CNT];
+#pragma unroll
+    for (int c = 0; c < CNT; ++c) {
+        if (c >= cnt) continue;
+        const int j = min(l + c * tpr, nb - 1);
+        const int k = j - ns * (int)__umulhi((uint32_t)j, pl.ns_rcp[p]);
+        w1[c] = tw[k * tws];
+    }
+    if (active) {
 #pragma unroll
         for (int c = 0; c < CNT; ++c) {
+            if (c >= cnt) continue;
             const int j = min(l + c * tpr, nb - 1);
-            const int k = j - ns * (int)__umulhi((uint32_t)j, pl.ns_rcp[p]);
-            w1[c] = tw[k * tws];
+#pragma unroll
+            for (int t = 0; t < R; ++t) v[c * R + t] = buf[mr_pad(j + t * nb)];
         }
-        if (active) {
+    }
+    __syncthreads();  // every butterfly has its inputs: the image may be overwritten
 #pragma unroll
-            for (int c = 0; c < CNT; ++c) {
-                const int j = min(l + c * tpr, nb - 1);
+    for (int c = 0; c < CNT; ++c) {
+        if (c >= cnt) continue;
+        float2 pw = w1[c];
+        v[c * R + 1] = cmul(v[c * R + 1], pw);
 #pragma unroll
-                for (int t = 0; t < R; ++t) v[c * R + t] = buf[mr_pad(j + t * nb)];
-            }
-        }
-        __syncthreads();  // every butterfly has its inputs: the image may be overwritten
-#pragma unroll
-        for (int c = 0; c < CNT; ++c) {
-            float2 pw = w1[c];
-            v[c * R + 1] = cmul(v[c * R + 1], pw);
-#pragma unroll
-            for (int t = 2; t < R; ++t) {
-                pw = cmul(pw, w1[c]);
-                v[c * R + t] = cmul(v[c * R + t], pw);
-            }
+        for (int t = 2; t < R; ++t) {
+            pw = cmul(pw, w1[c]);
+            v[c * R + t] = cmul(v[c * R + t], pw);
         }
     }
 #pragma unroll
     for (int c = 0; c < CNT; ++c) {
+        if (c >= cnt) continue;
         mr_idft<R>(&v[c * R]);
         if (CNT > 1) __builtin_amdgcn_sched_barrier(0);  // (one butterfly's temporaries at a time)
     }
@@ -110,6 +215,7 @@ __device__ __forceinline__ void mr_pass(const MrPlan& pl, int p, float2* __restr
         for (int t = 0; t < R; ++t)
 #pragma unroll
             for (int c = 0; c < CNT; ++c) {
+                if (c >= cnt) continue;
                 const int j = min(l + c * tpr, nb - 1);
                 const float zr = v[c * R + t].x * inv, zi = v[c * R + t].y * inv;
                 const float val = __builtin_fmaf(zr, zr, zi * zi);
@@ -122,8 +228,9 @@ __device__ __forceinline__ void mr_pass(const MrPlan& pl, int p, float2* __restr
     if (active) {
 #pragma unroll
         for (int c = 0; c < CNT; ++c) {
+            if (c >= cnt) continue;
             const int j = min(l + c * tpr, nb - 1);
-            const int k = FIRST ? 0 : j - ns * (int)__umulhi((uint32_t)j, pl.ns_rcp[p]);
+            const int k = j - ns * (int)__umulhi((uint32_t)j, pl.ns_rcp[p]);
             const int dst = (j - k) * R + k;
 #pragma unroll
             for (int t = 0; t < R; ++t) buf[mr_pad(dst + t * ns)] = v[c * R + t];
@@ -173,50 +280,60 @@ __global__ __launch_bounds__(WGMAX, 4) void k_perdelay_mr(MrPlan pl, const float
         float bv = -1.f;
         uint32_t bi = 0;
         {
-            float2 v[MR_PT];
-            // (the cutout is re-read per row -- it stays in the L1 / L2 --: twenty more resident points per thread do not fit
-            //  beside the transform's twenty.  Butterflies past the end are clamped, see mr_pass.)
+            // First pass, one butterfly at a time from the loads to the image: product with the cutout (re-read per row -- it
+            // stays in the L1 / L2 --), butterfly, R0 stores.  Only R0 points are live at once (all MR_PT of them, their x and y
+            // in flight beside them, spilled up to 50 registers in the radix-10 and radix-20 instances).  A cutout has more than
+            // MR_PT samples, so this is never the last pass.  Butterflies past the end are clamped, see mr_pass.
             int lx = l;  // (opaque: otherwise the cutout loads are hoisted out of the row loop and held -- and spilled -- after all)
             asm volatile("" : "+v"(lx));
-            if (!zero && !oor) {
-                const float2* yrow = y + s;
+            const int cnt0 = pl.cnt[0];
+            const bool inside = !zero && !oor;
 #pragma unroll
-                for (int c = 0; c < CNT0; ++c) {
-                    const int j = min(lx + c * tpr, nb0 - 1);
+            for (int c = 0; c < CNT0; ++c) {
+                if (c >= cnt0) continue;
+                const int j = min(lx + c * tpr, nb0 - 1);
+                float2 v[R0];
+                if (inside) {
+                    const float2* yrow = y + s;
 #pragma unroll
                     for (int t = 0; t < R0; ++t) {
                         const float2 a = x[j + t * nb0], b = yrow[j + t * nb0];
-                        v[c * R0 + t] = make_float2(a.x * b.x - a.y * b.y, -(a.x * b.y + a.y * b.x));  // conj(x y): see k_perdelay_fused
+                        v[t] = make_float2(a.x * b.x - a.y * b.y, -(a.x * b.y + a.y * b.x));  // conj(x y): see k_perdelay_fused
                     }
-                    // (one butterfly's loads in flight at a time: all twenty points' x and y at once are 80 registers)
-                    if (CNT0 > 1) __builtin_amdgcn_sched_barrier(0);
-                }
-            } else {
-#pragma unroll
-                for (int c = 0; c < CNT0; ++c) {
-                    const int j = min(lx + c * tpr, nb0 - 1);
+                } else {
 #pragma unroll
                     for (int t = 0; t < R0; ++t) {
                         const int64_t g = s + j + t * nb0;
                         const float2 a = x[j + t * nb0];
                         const float2 b = (!zero && g >= 0 && g < ylen) ? y[g] : make_float2(0.f, 0.f);
-                        v[c * R0 + t] = make_float2(a.x * b.x - a.y * b.y, -(a.x * b.y + a.y * b.x));
+                        v[t] = make_float2(a.x * b.x - a.y * b.y, -(a.x * b.y + a.y * b.x));
                     }
                 }
+                mr_idft<R0>(v);
+                if (active) {
+#pragma unroll
+                    for (int t = 0; t < R0; ++t) buf[mr_pad(j * R0 + t)] = v[t];
+                }
+                if (CNT0 > 1) __builtin_amdgcn_sched_barrier(0);
             }
-            mr_pass<R0, true>(pl, 0, buf, tw, l, active, v, reg_tail && pl.npass == 1, inv, bv, bi);
+            __syncthreads();
         }
         for (int p = 1; p < pl.npass; ++p) {
             float2 v[MR_PT];
             const bool lastr = reg_tail && p + 1 == pl.npass;
             switch (pl.radix[p]) {  // (uniform)
-                case 2: mr_pass<2, false>(pl, p, buf, tw, l, active, v, lastr, inv, bv, bi); break;
-                case 3: mr_pass<3, false>(pl, p, buf, tw, l, active, v, lastr, inv, bv, bi); break;
-                case 4: mr_pass<4, false>(pl, p, buf, tw, l, active, v, lastr, inv, bv, bi); break;
-                case 5: mr_pass<5, false>(pl, p, buf, tw, l, active, v, lastr, inv, bv, bi); break;
-                case 8: mr_pass<8, false>(pl, p, buf, tw, l, active, v, lastr, inv, bv, bi); break;
-                case 10: mr_pass<10, false>(pl, p, buf, tw, l, active, v, lastr, inv, bv, bi); break;
-                default: mr_pass<16, false>(pl, p, buf, tw, l, active, v, lastr, inv, bv, bi); break;
+                case 2: mr_pass<2>(pl, p, buf, tw, l, active, v, lastr, inv, bv, bi); break;
+                case 3: mr_pass<3>(pl, p, buf, tw, l, active, v, lastr, inv, bv, bi); break;
+                case 4: mr_pass<4>(pl, p, buf, tw, l, active, v, lastr, inv, bv, bi); break;
+                case 5: mr_pass<5>(pl, p, buf, tw, l, active, v, lastr, inv, bv, bi); break;
+                case 6: mr_pass<6>(pl, p, buf, tw, l, active, v, lastr, inv, bv, bi); break;
+                case 7: mr_pass<7>(pl, p, buf, tw, l, active, v, lastr, inv, bv, bi); break;
+                case 8: mr_pass<8>(pl, p, buf, tw, l, active, v, lastr, inv, bv, bi); break;
+                case 9: mr_pass<9>(pl, p, buf, tw, l, active, v, lastr, inv, bv, bi); break;
+                case 10: mr_pass<10>(pl, p, buf, tw, l, active, v, lastr, inv, bv, bi); break;
+                case 15: mr_pass<15>(pl, p, buf, tw, l, active, v, lastr, inv, bv, bi); break;
+                case 20: mr_pass<20>(pl, p, buf, tw, l, active, v, lastr, inv, bv, bi); break;
+                default: mr_pass<16>(pl, p, buf, tw, l, active, v, lastr, inv, bv, bi); break;
             }
         }
         // With planes: the finished spectrum is in the image in natural order: thread l takes indices l, l + tpr, ... (ascending,
@@ -257,27 +374,124 @@ __global__ __launch_bounds__(WGMAX, 4) void k_perdelay_mr(MrPlan pl, const float
     }
 }
 
-// fewest passes with radices from {16, 10, 8, 5, 4, 3, 2}; ties: the lexicographically largest sequence (big radices first)
-bool mr_factor(int32_t n, std::vector<int>& best) {
-    static const int radices[] = {16, 10, 8, 5, 4, 3, 2};
-    std::vector<int> cur;
-    best.clear();
+// The plan of a length: radices (non-increasing; the first from MR_FIRST -- the kernel instances --, the others from
+// MR_LATER) and threads per row, by the smallest modelled cost per row:
+//   threads a row occupies x ( sum over passes of butterflies per thread x points x weight(radix)  +  MR_PASS_COST per pass )
+// The weights are a least-squares fit to the timings of 807 plans of 19 lengths (scripts/sweep_mr_plans.py,
+// scripts/fit_mr_model.py, profiles/r04/mr_plan_fit.log: the model's pick is within 0.5 % of the fastest plan on average, 3 % at
+// worst): a point of a later pass costs 22 .. 40 whatever the radix (the twiddle product, the LDS write and read, the index
+// arithmetic outweigh the butterfly), a point of the first pass -- no twiddles, no image reads -- 7 .. 36, a pass 232 (two
+// barriers and the exchange latency), and rows that do not fill whole waves (tpr not a multiple of 64) 1.4 more per point.
+// A thread holds at most MR_PT points of a pass, so tpr >= N / (floor(20 / R) R) for every radix R of the plan, and >= N / 16
+// (the natural-order epilogue of rows with planes takes 16 points per thread).
+// CAF_MR_PLAN="15,10,8/80" overrides the search (radices / threads per row; checked for validity) -- for measurements.
+constexpr int MR_FIRST[] = {20, 18, 16, 15, 14, 12, 10, 9, 8, 7, 5};
+constexpr int MR_LATER[] = {20, 16, 15, 10, 9, 8, 7, 6, 5, 4, 3, 2};
+constexpr double MR_PASS_COST = 232.2, MR_UNALIGNED = 1.4;
+static double mr_weight(int r, bool first) {
+    if (first) {
+        switch (r) {
+            case 8: return 13.1;
+            case 9: return 14.8;
+            case 10: return 19.4;
+            case 12: return 6.7;
+            case 14: return 6.0;  // (the fit says less than nothing: too few plans to tell it from the pass charge)
+            case 15: return 28.0;
+            case 16: return 16.9;
+            case 18: return 20.4;
+            case 20: return 35.8;
+            default: return 20.0;  // (5 and 7 first: short lengths only, not in the fit)
+        }
+    }
+    switch (r) {
+        case 2: return 29.9;
+        case 3: return 27.7;
+        case 4: return 30.8;
+        case 5: return 28.6;
+        case 6: return 28.6;
+        case 8: return 31.8;
+        case 9: return 22.2;
+        case 10: return 31.1;
+        case 15: return 27.6;
+        case 16: return 40.0;
+        case 20: return 30.1;
+        default: return 28.0;  // (7: too few plans in the fit to tell it from its neighbours)
+    }
+}
+
+struct MrChoice {
+    std::vector<int> rad;
+    int tpr = 0;
+    double cost = 0.0;
+};
+
+static bool mr_valid(int32_t n, const std::vector<int>& rad, int tpr) {
+    if (rad.empty() || (int)rad.size() > MR_MAXP || tpr < 1 || tpr > 1024 || (int64_t)tpr * 16 < n) return false;
+    int64_t prod = 1;
+    for (size_t i = 0; i < rad.size(); ++i) {
+        const int r = rad[i];
+        const int* lo = i ? MR_LATER : MR_FIRST;
+        const int* hi = i ? MR_LATER + sizeof(MR_LATER) / sizeof(int) : MR_FIRST + sizeof(MR_FIRST) / sizeof(int);
+        if (std::find(lo, hi, r) == hi || (i && r > rad[i - 1])) return false;
+        if (((n / r + tpr - 1) / tpr) > MR_PT / r) return false;
+        prod *= r;
+    }
+    return prod == n;
+}
+
+static double mr_cost(int32_t n, const std::vector<int>& rad, int tpr) {
+    const int rpw = std::max(1, 256 / tpr);
+    const double threads = (double)((rpw * tpr + 63) / 64 * 64) / rpw;
+    double per_thread = 0.0;
+    for (size_t i = 0; i < rad.size(); ++i) {
+        const int r = rad[i];
+        per_thread += (double)((n / r + tpr - 1) / tpr) * r * (mr_weight(r, i == 0) + (tpr % 64 ? MR_UNALIGNED : 0.0)) + MR_PASS_COST;
+    }
+    return threads * per_thread;
+}
+
+bool mr_plan(int32_t n, MrChoice& best) {
+    if (const char* ov = std::getenv("CAF_MR_PLAN")) {
+        MrChoice c;
+        const char* q = ov;
+        while (*q && *q != '/') {
+            c.rad.push_back((int)std::strtol(q, const_cast<char**>(&q), 10));
+            if (*q == ',') ++q;
+        }
+        if (*q == '/') c.tpr = (int)std::strtol(q + 1, nullptr, 10);
+        if (mr_valid(n, c.rad, c.tpr)) {
+            c.cost = mr_cost(n, c.rad, c.tpr);
+            best = c;
+            return true;
+        }
+    }
     bool found = false;
-    // (radices in non-increasing order: one representative per multiset; the first sequence with the fewest passes stays)
+    std::vector<int> cur;
     std::function<void(int32_t, int)> rec = [&](int32_t rem, int max_r) {
         if (rem == 1) {
-            if (!found || cur.size() < best.size()) best = cur, found = true;
+            int cap = 16;
+            for (int r : cur) cap = std::min(cap, MR_PT / r * r);
+            const int t0 = (n + cap - 1) / cap;
+            // (the fewest threads, or rows rounded up to quarter, half and whole waves)
+            for (int t : {t0, (t0 + 15) / 16 * 16, (t0 + 31) / 32 * 32, (t0 + 63) / 64 * 64}) {
+                if (!mr_valid(n, cur, t)) continue;
+                const double c = mr_cost(n, cur, t);
+                if (!found || c < best.cost) best.rad = cur, best.tpr = t, best.cost = c, found = true;
+            }
             return;
         }
-        if ((int)cur.size() >= MR_MAXP || (found && cur.size() + 1 >= best.size())) return;
-        for (int r : radices) {
+        if ((int)cur.size() >= MR_MAXP) return;
+        const int* lo = cur.empty() ? MR_FIRST : MR_LATER;
+        const int cnt = cur.empty() ? (int)(sizeof(MR_FIRST) / sizeof(int)) : (int)(sizeof(MR_LATER) / sizeof(int));
+        for (int i = 0; i < cnt; ++i) {
+            const int r = lo[i];
             if (r > max_r || rem % r) continue;
             cur.push_back(r);
             rec(rem / r, r);
             cur.pop_back();
         }
     };
-    rec(n, 16);
+    rec(n, 20);
     return found;
 }
 
@@ -345,19 +559,22 @@ int mr_launch(const MrPlan& pl, size_t lds, int dev, const float2* x, const floa
 bool perdelay_mixed_ok(int32_t n) {
     if (n < 32 || n > 16200) return false;
     int32_t r = n;
-    for (int p : {2, 3, 5})
+    for (int p : {2, 3, 5, 7})
         while (r % p == 0) r /= p;
-    return r == 1;
+    if (r != 1) return false;
+    MrChoice c;
+    return mr_plan(n, c);
 }
 
 int launch_perdelay_mixed(const float2* x, int32_t n, const float2* y, int64_t ylen, const double* prefix, const double* xnorm,
                           int64_t start, int64_t step, int64_t num, int32_t zero_oor, float* qf2, uint32_t* fidx, float* plane,
                           float2* cplane, hipStream_t st) {
-    std::vector<int> rad;
-    if (!perdelay_mixed_ok(n) || !mr_factor(n, rad)) {
+    MrChoice ch;
+    if (n < 32 || n > 16200 || !mr_plan(n, ch)) {
         set_error("launch_perdelay_mixed: unsupported length");
         return CAF_ERR_INVALID;
     }
+    const std::vector<int>& rad = ch.rad;
     int dev = 0;
     CAF_HIP_TRY(hipGetDevice(&dev));
     const float2* tw = nullptr;
@@ -366,7 +583,7 @@ int launch_perdelay_mixed(const float2* x, int32_t n, const float2* y, int64_t y
     MrPlan pl;
     std::memset(&pl, 0, sizeof(pl));
     pl.n = n;
-    pl.tpr = (n + 15) / 16;
+    pl.tpr = ch.tpr;
     pl.rpw = std::max(1, 256 / pl.tpr);
     pl.npass = (int)rad.size();
     pl.img = n + (n >> 4) + 1;
@@ -375,7 +592,13 @@ int launch_perdelay_mixed(const float2* x, int32_t n, const float2* y, int64_t y
         pl.radix[p] = rad[p];
         pl.ns[p] = ns;
         pl.ns_rcp[p] = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)ns + 1);  // exact for j * ns < 2^32 (the first pass, ns = 1, never divides)
+        pl.cnt[p] = (n / rad[p] + pl.tpr - 1) / pl.tpr;
         ns *= rad[p];
+    }
+    if (std::getenv("CAF_MR_DEBUG")) {
+        std::string t;
+        for (int r : rad) t += (t.empty() ? "" : ",") + std::to_string(r);
+        std::fprintf(stderr, "[caf mr] n=%d plan=%s/%d rows_per_workgroup=%d cost=%.0f\n", n, t.c_str(), pl.tpr, pl.rpw, ch.cost);
     }
     const size_t lds = (size_t)pl.rpw * pl.img * sizeof(float2) + (size_t)2 * pl.rpw * sizeof(unsigned long long);
     CAF_REQUIRE(lds <= 163840, "launch_perdelay_mixed: row image does not fit the LDS");
@@ -384,12 +607,16 @@ int launch_perdelay_mixed(const float2* x, int32_t n, const float2* y, int64_t y
                ? mr_launch<R, 512>(pl, lds, dev, x, y, ylen, tw, prefix, xnorm, start, step, num, zero_oor, qf2, fidx, plane, cplane, st) \
                : mr_launch<R, 1024>(pl, lds, dev, x, y, ylen, tw, prefix, xnorm, start, step, num, zero_oor, qf2, fidx, plane, cplane, st)
     switch (rad[0]) {
-        case 2: CAF_MR_GO(2);
-        case 3: CAF_MR_GO(3);
-        case 4: CAF_MR_GO(4);
         case 5: CAF_MR_GO(5);
+        case 7: CAF_MR_GO(7);
         case 8: CAF_MR_GO(8);
+        case 9: CAF_MR_GO(9);
         case 10: CAF_MR_GO(10);
+        case 12: CAF_MR_GO(12);
+        case 14: CAF_MR_GO(14);
+        case 15: CAF_MR_GO(15);
+        case 18: CAF_MR_GO(18);
+        case 20: CAF_MR_GO(20);
         default: CAF_MR_GO(16);
     }
 #undef CAF_MR_GO

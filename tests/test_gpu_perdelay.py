@@ -163,6 +163,26 @@ def test_mixed_radix_cutouts(n):
     _composite_cutout_checks(n)
 
 
+# every butterfly of the mixed-radix kernel as the first pass (the kernel instances) and as a later pass, through forced plans
+# (CAF_MR_PLAN = radices / threads per row; the planner would pick other ones for some of these lengths)
+@pytest.mark.parametrize("n,plan", [(125, "5,5,5/8"), (49, "7,7/4"), (343, "7,7,7/25"), (72, "8,3,3/5"), (81, "9,9/6"), (50, "10,5/4"),
+                                    (36, "12,3/3"), (98, "14,7/7"), (225, "15,15/15"), (1280, "16,16,5/80"), (324, "18,9,2/21"),
+                                    (400, "20,20/25"), (8000, "20,20,20/500"), (96, "16,6/6"), (80, "20,4/5"), (40, "20,2/3"),
+                                    (1200, "15,10,8/80"), (1200, "16,5,5,3/75"), (1400, None), (7000, None), (2401, None),
+                                    (14000, None), (12005, None)])
+def test_mixed_radix_every_butterfly(n, plan, monkeypatch, capfd):
+    """Radices 2 ... 10, 12, 14, 15, 16, 18, 20 (the composite ones as Cooley-Tukey butterflies in registers, radix 7 for
+    7-smooth lengths such as 1400 = 2^3 5^2 7), first and later passes, against the oracle as above."""
+    monkeypatch.setenv("CAF_MR_DEBUG", "1")
+    if plan:
+        monkeypatch.setenv("CAF_MR_PLAN", plan)
+    _composite_cutout_checks(n)
+    err = capfd.readouterr().err
+    assert "[caf mr] n=%d plan=" % n in err
+    if plan:
+        assert "[caf mr] n=%d plan=%s " % (n, plan) in err  # (the forced plan was valid and is the one that ran)
+
+
 def _composite_cutout_checks(n):
     rng = np.random.default_rng(n)
     m = n + 900
