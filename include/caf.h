@@ -221,6 +221,12 @@ CAF_EXPORT int32_t caf_plan_execute_host(caf_plan plan, const float* h_rx, int64
 CAF_EXPORT int32_t caf_xcorr_perdelay(const float* d_cutout, int32_t n, const float* d_rx, int64_t rx_len,
                                       int64_t start, int64_t step, int64_t num, int32_t zero_oor, float* d_qf2,
                                       int32_t* d_fidx, float* d_caf, float* d_ccaf, int64_t batch_rows, void* stream);
+/* 1 when caf_xcorr_perdelay serves cutouts of n samples with ONE kernel (product, N-point transform in LDS, |.|^2, argmax:
+ * powers of two 64 ... 16384, 100 / 1000 / 10000, and the 2^a 3^b 5^c 7^d lengths 32 ... 16200 the mixed-radix planner
+ * finds a plan for), 0 when it runs the product rows -> row FFT -> argmax chain the reference runs for every length
+ * (cp_fastXcorr_v2, xcorrRoutines.py:169-274).  The results are the same either way; callers that batch the chain
+ * themselves (the BATCH argument of cp_fastXcorr_v2) ask this first.  No device work. */
+CAF_EXPORT int32_t caf_xcorr_perdelay_one_kernel(int32_t n);
 
 /* ---- stand-alone kernels (device pointers), one per reference CUDA kernel wrapper ------------- */
 /* batched row FFT, replaces cp.fft.fft(x, axis=1) / ifft (xcorrRoutines.py:135,246,339,352); in place when

@@ -264,6 +264,10 @@ int32_t caf_fft_rows(const float* d_in, float* d_out, int64_t rows, int64_t len,
     return CAF_OK;
 }
 
+int32_t caf_xcorr_perdelay_one_kernel(int32_t n) {
+    return (perdelay_fused_ok(n) || perdelay_decimal_ok(n) || perdelay_mixed_ok(n)) ? 1 : 0;
+}
+
 int32_t caf_xcorr_perdelay(const float* d_cutout, int32_t n, const float* d_rx, int64_t rx_len, int64_t start,
                            int64_t step, int64_t num, int32_t zero_oor, float* d_qf2, int32_t* d_fidx, float* d_caf,
                            float* d_ccaf, int64_t batch_rows, void* stream) {

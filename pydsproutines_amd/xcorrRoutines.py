@@ -495,15 +495,9 @@ def cp_fastXcorr(cutout, rx, freqsearch=True, outputCAF=False, shifts=None, absR
 
 
 def _one_kernel_cutout(n):
-    """Cutout lengths that caf_xcorr_perdelay serves with one fused kernel (perdelay_fused_ok / _decimal_ok / _mixed_ok)."""
-    if 64 <= n <= 16384 and n & (n - 1) == 0:
-        return True
-    if not 32 <= n <= 16200:
-        return False
-    for p in (2, 3, 5):
-        while n % p == 0:
-            n //= p
-    return n == 1
+    """Cutout lengths that caf_xcorr_perdelay serves with one fused kernel (the library's own rule: powers of two, powers
+    of ten, 2^a 3^b 5^c 7^d lengths with a mixed-radix plan)."""
+    return bool(_lib.load().caf_xcorr_perdelay_one_kernel(int(n)))
 
 
 def cp_fastXcorr_v2(cutout, rx, startIdx=0, idxlen=None, THREADS_PER_BLOCK=32, numSlidesPerBlk=None, cztObj=None,
@@ -532,7 +526,7 @@ def cp_fastXcorr_v2(cutout, rx, startIdx=0, idxlen=None, THREADS_PER_BLOCK=32, n
     n = int(cutout.size)
     if (flattenCAF and cztObj is None and _one_kernel_cutout(n) and startIdx >= 0
             and startIdx + idxlen - 1 + n <= rx.size):
-        # power-of-two cutout, 100 / 1000 / 10000 samples (radix-10 passes) or any other 2^a 3^b 5^c length up to 16200
+        # power-of-two cutout, 100 / 1000 / 10000 samples (radix-10 passes) or any other 2^a 3^b 5^c 7^d length up to 16200
         # (mixed-radix passes), every window inside rx: the whole chain (product, row transform, |.|^2, argmax, both norms)
         # is ONE kernel (caf_perdelay.hip, caf_perdelay_mr.hip) -- no (idxlen, N) matrix, no batches
         _lib.check(lib.caf_xcorr_perdelay(ct.c_void_p(cutout.ptr), n, ct.c_void_p(rx.ptr), rx.size, int(startIdx), 1,
