@@ -24,9 +24,10 @@ ROWS = [  # (workload, kernel prefix of the manifest entry, label)
     ("direct_small_support", "k_direct_caf", "`k_direct_caf` (16 samples of support, 64 frequencies, 2²² delays, surface)"),
     ("cp_fastxcorr_1e7", "k_sliding_multiply", "`k_sliding_multiply` (128 rows × 10⁷)"),
     ("perdelay_decimal_1000", "k_perdelay_r10", "`k_perdelay_r10<3>` (1000 × 10⁶, radix 10)"),
-    ("perdelay_mixed_1200", "k_perdelay_mr<16", "`k_perdelay_mr<16>` (1200 × 10⁵, radices 16·5·5·3)"),
+    ("perdelay_mixed_1200", "k_perdelay_mr<16", "`k_perdelay_mr<16>` (1200 × 10⁵, radices 16·15·5)"),
     ("perdelay_mixed_1200", "k_perdelay_mr<10", "`k_perdelay_mr<10>` (5000 × 10⁵, radices 10·10·10·5)"),
-    ("perdelay_rows_1400", "k_sliding_multiply", "`k_sliding_multiply` (10⁵ rows × 1400)"),
+    ("perdelay_mixed_1200", "k_perdelay_mr<14", "`k_perdelay_mr<14>` (1400 × 10⁵, radices 14·10·10)"),
+    ("perdelay_rows_1430", "k_sliding_multiply", "`k_sliding_multiply` (10⁵ rows × 1430)"),
     ("cp_fastxcorr_1e7", "k_rows_argmax", "`k_rows_argmax` (chunked, 128 rows × 10⁷)"),
     ("kernels_misc", "k_magnsq", "`k_magnsq`"),
     ("kernels_misc", "k_iq16_to_c64", "`k_iq16_to_c64`"),
@@ -36,8 +37,8 @@ ROWS = [  # (workload, kernel prefix of the manifest entry, label)
     ("kernels_misc", "k_multi_template_dot", "`k_multi_template_dot_rt` (20 × 100, 10⁷ slides)"),
     ("kernels_misc", "k_moving_tile", "`k_moving_tile` (L = 100, 2²⁴ samples)"),
     ("kernels_misc", "k_upfirdn_poly", "`k_upfirdn_poly` (64 × 2¹⁸, 128 taps, up 5 down 2)"),
-    ("kernels_misc", "k_local_max", "`k_local_max_*` (2²⁴ trace, three launches)"),
-    ("c2_rocfft", "k_power_tile_sums", "`k_power_tile_sums` + `k_scan` + `k_prefix_write`"),
+    ("kernels_misc", "k_local_max", "`k_local_max_flags` + `k_local_max_write` (2²⁴ trace, read once)"),
+    ("kernels_misc", "k_prefix_tiles", "`k_prefix_tiles` × 2 + `k_scan_tile_sums` (energy prefix of 10⁷ samples)"),
     ("c2_rocfft", "k_inv_energy", "`k_inv_energy`"),
     ("c2_rocfft", "k_gather_blocks", "`k_gather_blocks`"),
 ]

@@ -81,7 +81,7 @@ def caf(engine, surface, T=1, F=256, reps=2, rows=True):
         man.append(("k_block_spectra", "block spectra + sliding energies: gather, in-LDS forward FFT, f64 block prefix "
                     "(8 B read + 8 B written per block point, 4 B per delay)", nblk * B * 16.0 + S * 4.0, nblk * 5.0 * B * np.log2(B), reps))
     else:
-        man.append(("k_power_tile_sums|k_prefix_write|k_scan_tile_sums", "f64 energy prefix of |rx|^2 (8 B read + 8 B written per sample)", M * 16.0, 0.0, reps))
+        man.append(("k_prefix_tiles|k_scan_tile_sums", "f64 energy prefix of |rx|^2: tile totals, their scan, the write (8 B read + 8 B written per sample)", M * 16.0, 0.0, reps))
         man.append(("k_inv_energy", "1 / window energy (16 B read + 4 B written per delay)", S * 20.0, 0.0, reps))
         man.append(("k_gather_blocks", "overlap-save blocks (8 B read + 8 B written per block point)", nblk * B * 16.0, 0.0, reps))
     plan.close()
@@ -202,7 +202,7 @@ def w_c5_zoom():
         out = caf_with_zoom(plan, d_rx, res, bins, N, float(N), k=8, min_height=0.004, span_bins=1.0, step_bins=1.0 / 64)
     assert len(out) == 8
     nfft = 4320
-    return [("k_local_max", "local maxima of the 2^24-delay trace (4 B read per delay, all three kernels)", S * 4.0 * 2, 0.0, 3),
+    return [("k_local_max", "local maxima of the 2^24-delay trace, both launches (4 B read per delay)", S * 4.0, 0.0, 3),
             ("k_zoom_topk", "device top-k of the candidates", 0.0, 0.0, 3),
             ("k_zoom_rows", "8 product rows, rotated + pre-chirped + padded (8 B read x2, 8 B written)", 8 * (N * 16.0 + nfft * 8.0), 0.0, 3),
             ("k_rows_mul_vec", "CZT spectral / output chirp multiplies (16 B per element)", 8 * nfft * 16.0 + 8 * 129 * 16.0, 0.0, 3)]
@@ -261,10 +261,10 @@ def w_perdelay_fused_256():
     return [("k_perdelay_fused", "N=256 x 1e6 delays (same accounting)", _perdelay_bytes(n, num), num * 5.0 * n * np.log2(n), 2)]
 
 
-def w_perdelay_rows_1400():
-    """A cutout length with a factor 7 (no in-LDS kernel): product rows -> rocFFT rows -> argmax."""
-    n, num = perdelay(1400, 100_000, "rows")
-    return [("k_sliding_multiply", "normalised product rows, N=1400 x 1e5 (8 B written per element)", num * n * 8.0, 0.0, 2),
+def w_perdelay_rows_1430():
+    """A cutout length with factors 11 and 13 (no in-LDS kernel): product rows -> rocFFT rows -> argmax."""
+    n, num = perdelay(1430, 100_000, "rows")
+    return [("k_sliding_multiply", "normalised product rows, N=1430 x 1e5 (8 B written per element)", num * n * 8.0, 0.0, 2),
             ("k_rows_argmax", "|.|^2 + first argmax per row (8 B read per element)", num * n * 8.0, 0.0, 2)]
 
 
@@ -276,10 +276,13 @@ def w_perdelay_decimal_1000():
 
 
 def w_perdelay_mixed_1200():
-    """2^a 3^b 5^c cutouts: the mixed-radix in-LDS kernel (caf_perdelay_mr.hip), here 1200 = 16.5.5.3 and 5000 = 10.10.10.5."""
+    """2^a 3^b 5^c 7^d cutouts: the mixed-radix in-LDS kernel (caf_perdelay_mr.hip), here 1200 = 16.15.5, 5000 = 10.10.10.5 and
+    1400 = 14.10.10."""
     man = []
-    for n, num in ((1200, 100_000), (5000, 100_000)):
+    for n, num in ((1200, 100_000), (5000, 100_000), (1400, 100_000)):
         perdelay(n, num, "mixed")
+    man.append(("k_perdelay_mr<14", "mixed-radix per-delay correlator, N=1400 x 1e5 rows (f32-bound)", _perdelay_bytes(1400, 100_000),
+                100_000 * 5.0 * 1400 * np.log2(1400), 2))
     man.append(("k_perdelay_mr<16", "mixed-radix per-delay correlator, N=1200 x 1e5 rows (f32-bound)", _perdelay_bytes(1200, 100_000),
                 100_000 * 5.0 * 1200 * np.log2(1200), 2))
     man.append(("k_perdelay_mr<10", "mixed-radix per-delay correlator, N=5000 x 1e5 rows (f32-bound)", _perdelay_bytes(5000, 100_000),
