@@ -81,7 +81,9 @@ __global__ __launch_bounds__(256) void k_sliding_multiply(const float2* __restri
     // four rows at a time: x[t] is loaded once for them, and with consecutive delays (step 1) the four y loads of a thread
     // are the neighbouring threads' lines -- per output 8 + 8 bytes came from L2 / the Infinity Cache, now about a quarter of
     // that (long rows, 128 x 10^7 outputs: 715 -> 665 us per batch; non-temporal stores and one contiguous chunk of t per
-    // workgroup instead of the grid stride were measured too: no change / 10 % slower)
+    // workgroup instead of the grid stride were measured too: no change / 10 % slower; round 4: two outputs per lane with 16-byte
+    // stores: no change on 1430-sample rows, 10 % slower on 10^7-sample ones.  A write-only stream reaches 4.4 .. 6.1 TB/s on this
+    // chip, scripts/ubench/stream_rw.hip: the 4.3 TB/s of the short rows are at that ceiling)
     for (int r = 0; r < rpw && row0 + r < rows; r += 4) {
         int64_t sq[4];
         bool zq[4], live[4];
@@ -161,6 +163,58 @@ __global__ __launch_bounds__(256) void k_rows_argmax(const float2* __restrict__ 
                 bi = s_i[w];
             }
         if (bv < 0.f) {  // empty or all-NaN row: the reference's zero-initialised workspace (argmax.cu:108-109)
+            bv = (nan_empty && len > 0) ? __builtin_nanf("") : 0.f;
+            bi = 0;
+        }
+        if (argmax) argmax[row] = bi;
+        if (maxv) maxv[row] = use_normsq ? bv : sqrtf(bv);
+    }
+}
+
+// Many short rows (the per-delay path's product rows: 10^5 rows of ~10^3 elements): one WAVE per row, four rows per
+// workgroup -- no barrier, no LDS --, 16-byte loads (two elements per lane and instruction, four instructions in flight).
+// A row that starts 8 bytes off a 16-byte boundary gives its first element to lane 0.  Per lane the indices are visited in
+// increasing order, so the strict comparison keeps the first maximum; across lanes the lower index wins ties.
+__global__ __launch_bounds__(256) void k_rows_argmax_wave(const float2* __restrict__ z, int64_t rows, int64_t len, int32_t use_normsq,
+                                                          float scale, uint32_t* __restrict__ argmax, float* __restrict__ maxv,
+                                                          float* __restrict__ plane, int32_t nan_empty) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;  // (wave-uniform)
+    const float2* zr = z + row * len;
+    float* pr = plane ? plane + row * len : nullptr;
+    float bv = -1.f;
+    uint32_t bi = 0;
+    auto offer = [&](float2 a, int64_t t) {
+        const float v = (a.x * a.x + a.y * a.y) * scale;
+        if (pr) pr[t] = v;
+        if (v > bv) {
+            bv = v;
+            bi = (uint32_t)t;
+        }
+    };
+    const int head = (int)((reinterpret_cast<uintptr_t>(zr) >> 3) & 1);
+    if (head && lane == 0 && len > 0) offer(zr[0], 0);
+    const int64_t nv = len > head ? (len - head) >> 1 : 0;
+    const float4* zv = reinterpret_cast<const float4*>(zr + head);
+#pragma unroll 4
+    for (int64_t p = lane; p < nv; p += 64) {
+        const float4 q = zv[p];
+        offer(make_float2(q.x, q.y), head + 2 * p);
+        offer(make_float2(q.z, q.w), head + 2 * p + 1);
+    }
+    if (len > head && ((len - head) & 1) && lane == 0) offer(zr[len - 1], len - 1);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o, 64);
+        const uint32_t oi = __shfl_xor(bi, o, 64);
+        if (ov > bv || (ov == bv && oi < bi)) {
+            bv = ov;
+            bi = oi;
+        }
+    }
+    if (lane == 0) {
+        if (bv < 0.f) {  // empty or all-NaN row: see k_rows_argmax
             bv = (nan_empty && len > 0) ? __builtin_nanf("") : 0.f;
             bi = 0;
         }
@@ -1338,6 +1392,11 @@ void launch_rows_argmax(const float2* z, int64_t rows, int64_t len, int32_t use_
                            plane);
         hipLaunchKernelGGL(k_rows_argmax_fin, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, st, part, chunks, rows, use_normsq,
                            argmax, maxv, nan_empty);
+        return;
+    }
+    if (rows >= 1024 && len <= 32768) {
+        hipLaunchKernelGGL(k_rows_argmax_wave, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, z, rows, len, use_normsq, scale,
+                           argmax, maxv, plane, nan_empty);
         return;
     }
     hipLaunchKernelGGL(k_rows_argmax, dim3((unsigned)rows), dim3(256), 0, st, z, len, use_normsq, scale, argmax, maxv,
