@@ -140,7 +140,7 @@ int launch_perdelay_decimal(const float2* x, int32_t n, const float2* y, int64_t
 int launch_perdelay_fused(const float2* x, int32_t n, const float2* y, int64_t ylen, int64_t start, int64_t step,
                           int64_t num, int32_t zero_oor, float* qf2, uint32_t* fidx, float* plane, float2* cplane,
                           hipStream_t st);
-// cutouts of 2^a 3^b 5^c samples that are neither of the above (32 <= n <= 16200): mixed-radix in-LDS transform (caf_perdelay_mr.hip)
+// cutouts of 2^a 3^b 5^c 7^d samples that are neither of the above (32 <= n <= 16200, a plan exists): mixed-radix in-LDS transform (caf_perdelay_mr.hip)
 bool perdelay_mixed_ok(int32_t n);
 int launch_perdelay_mixed(const float2* x, int32_t n, const float2* y, int64_t ylen, const double* prefix, const double* xnorm,
                           int64_t start, int64_t step, int64_t num, int32_t zero_oor, float* qf2, uint32_t* fidx, float* plane,

@@ -321,7 +321,7 @@ int32_t caf_xcorr_perdelay(const float* d_cutout, int32_t n, const float* d_rx, 
             return e && atoi(e) != 0;
         }();
         if (!unfused10 && (perdelay_decimal_ok(n) || perdelay_mixed_ok(n))) {
-            // (2^a 3^b 5^c lengths that are neither a power of two nor of ten: the mixed-radix kernel, caf_perdelay_mr.hip)
+            // (2^a 3^b 5^c 7^d lengths that are neither a power of two nor of ten: the mixed-radix kernel, caf_perdelay_mr.hip)
             rc = perdelay_decimal_ok(n)
                      ? launch_perdelay_decimal((const float2*)d_cutout, n, yv, ylen_v, prefix, d_norm, start_v, step, num,
                                                zero_oor ? 1 : 0, d_qf2, (uint32_t*)d_fidx, d_caf, (float2*)d_ccaf, st)

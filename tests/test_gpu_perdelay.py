@@ -151,13 +151,13 @@ def test_decimal_cutouts_radix10_kernel(n):
     _composite_cutout_checks(n)
 
 
-# 2^a 3^b 5^c lengths that are neither a power of two nor of ten: every radix of the planner first (48 = 16.3, 60 = 10.3.2,
-# 72 = 8.3.3, 75 = 5.5.3, 36 = 4.3.3, 243 = 3^5, 486 = 3^5.2 -> radix 3 first / radix 2 last), several rows per workgroup and
-# one, both launch-bound variants (> 8192 samples), the benchmark's kind of lengths (1200, 1536, 3000, 5000, 12000)
+# 2^a 3^b 5^c lengths that are neither a power of two nor of ten, with the planner's own plans: short ones (several rows per
+# workgroup) and long ones (one row, both launch-bound variants beyond 8192 samples), odd ones (243 = 3^5, 75 = 5.5.3), the
+# benchmark's kind of lengths (1200, 1536, 3000, 5000, 12000); forced plans: test_mixed_radix_every_butterfly
 @pytest.mark.parametrize("n", [36, 48, 60, 72, 75, 243, 486, 1200, 1536, 3000, 5000, 12000, 15552, 16200])
 def test_mixed_radix_cutouts(n):
     """Cutouts of 2^a 3^b 5^c samples run the per-delay algorithm in ONE kernel too (k_perdelay_mr, caf_perdelay_mr.hip: a
-    mixed-radix Stockham transform in LDS, radices 16 / 10 / 8 / 5 / 4 / 3 / 2) instead of product rows -> rocFFT rows ->
+    mixed-radix Stockham transform in LDS; the planner picks radices and threads per row) instead of product rows -> rocFFT rows ->
     argmax through HBM: the same checks as the other two kernels against the oracle's branches B, C, C'
     (xcorrRoutines.py:511-566)."""
     _composite_cutout_checks(n)
