@@ -25,6 +25,7 @@
 #include <functional>
 #include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "caf_internal.h"
@@ -465,6 +466,17 @@ bool mr_plan(int32_t n, MrChoice& best) {
             return true;
         }
     }
+    // (the search costs 10 .. 50 us: remembered per length -- a call of a few hundred microseconds asks twice)
+    static std::mutex mu;
+    static std::unordered_map<int32_t, MrChoice> memo;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = memo.find(n);
+        if (it != memo.end()) {
+            best = it->second;
+            return best.tpr > 0;
+        }
+    }
     bool found = false;
     std::vector<int> cur;
     std::function<void(int32_t, int)> rec = [&](int32_t rem, int max_r) {
@@ -492,6 +504,11 @@ bool mr_plan(int32_t n, MrChoice& best) {
         }
     };
     rec(n, 20);
+    if (!found) best = MrChoice();
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        memo[n] = best;  // (tpr == 0: no plan)
+    }
     return found;
 }
 

@@ -34,7 +34,9 @@ def test_fastxcorr_random(seed):
     from pydsproutines_amd.xcorrRoutines import fastXcorr
 
     rng = np.random.default_rng(9000 + seed)
-    n = int(rng.choice([1, 2, 3, 17, 30, 64, 100, 257, 512, 1000]))
+    # (64 / 512: the power-of-two kernel; 100 / 1000: radix 10; 36 ... 1400: mixed-radix plans, 7-smooth ones included;
+    #  1 ... 30, 257, 143 = 11 x 13: product rows -> row FFT -> argmax)
+    n = int(rng.choice([1, 2, 3, 17, 30, 64, 100, 257, 512, 1000, 36, 49, 60, 96, 98, 120, 143, 225, 343, 360, 1200, 1400]))
     m = n + int(rng.integers(0, 3000))
     rx = cn(rng, m)
     d = int(rng.integers(0, m - n + 1))
