@@ -152,11 +152,9 @@ template <int LOGN>
 int fos_taps_launch(const float* taps, int32_t ntaps, const float2* tw, float2* ht, hipStream_t st) {
     constexpr int N = 1 << LOGN, NTR = N / 16;
     const size_t lds = (size_t)(N + N / 16) * sizeof(float2);
-    static bool attr_set = false;
-    if (!attr_set) {
-        CAF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fos_taps<LOGN>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+    {
+        const int rc_lds = allow_dynamic_lds(reinterpret_cast<const void*>(k_fos_taps<LOGN>), lds);
+        if (rc_lds) return rc_lds;
     }
     hipLaunchKernelGGL(k_fos_taps<LOGN>, dim3(1), dim3(NTR), lds, st, taps, ntaps, tw, ht);
     return CAF_OK;
@@ -167,11 +165,9 @@ int fos_launch(const TIn* x, int64_t n, const TIn* delay, int32_t dlen, float sc
                int32_t ntaps, int32_t dsr, int32_t phase, float2* out, int64_t nout, hipStream_t st) {
     constexpr int N = 1 << LOGN, NTR = N / 16, WG = NTR > 256 ? NTR : 256, RPW = WG / NTR;
     const size_t lds = (size_t)RPW * (N + N / 16) * sizeof(float2);
-    static bool attr_set = false;
-    if (!attr_set) {
-        CAF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fir_os<LOGN, TIn>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+    {
+        const int rc_lds = allow_dynamic_lds(reinterpret_cast<const void*>(k_fir_os<LOGN, TIn>), lds);
+        if (rc_lds) return rc_lds;
     }
     const int64_t L = N - ntaps + 1;
     const int64_t last = phase + (nout - 1) * (int64_t)dsr;  // last full-rate output wanted

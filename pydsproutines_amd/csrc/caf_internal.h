@@ -5,7 +5,10 @@
 
 #include "caf.h"
 
+#include <map>
+#include <mutex>
 #include <string>
+#include <utility>
 
 namespace caf {
 
@@ -45,6 +48,21 @@ void set_error(const std::string& msg);
             return (_e == hipErrorOutOfMemory) ? CAF_ERR_NOMEM : CAF_ERR_HIP;                      \
         }                                                                                          \
     } while (0)
+
+// MaxDynamicSharedMemorySize is an attribute of a kernel PER DEVICE (a process may drive several): raised once per
+// (kernel, device), remembered under a lock.
+inline int allow_dynamic_lds(const void* kernel, size_t bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<const void*, int>, size_t> granted;
+    int dev = 0;
+    CAF_HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    size_t& have = granted[std::make_pair(kernel, dev)];
+    if (have >= bytes) return CAF_OK;
+    CAF_HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    have = bytes;
+    return CAF_OK;
+}
 
 // caching device allocator (caf_pool.hip)
 int pool_alloc(void** out, int64_t bytes);

@@ -471,11 +471,9 @@ int pd_launch(const float2* x, const float2* y, int64_t ylen, const float2* tw, 
               int32_t zero_oor, float* qf2, uint32_t* fidx, float* plane, float2* cplane, hipStream_t st) {
     constexpr int N = 1 << LOGN, NTR = N / 16, WG = NTR > 256 ? NTR : 256, RPW = WG / NTR;
     const size_t lds = (size_t)RPW * (N + N / 16) * sizeof(float2);
-    static bool attr_set = false;  // (per instantiation; benign race)
-    if (!attr_set) {
-        CAF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_perdelay_fused<LOGN>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+    {
+        const int rc_lds = allow_dynamic_lds(reinterpret_cast<const void*>(k_perdelay_fused<LOGN>), lds);
+        if (rc_lds) return rc_lds;
     }
     // enough workgroups to fill the chip several times over, few enough that the cutout load is amortised
     const int64_t groups = (num + RPW - 1) / RPW;
@@ -651,10 +649,9 @@ int r10_launch(const float2* x, const float2* y, int64_t ylen, const float2* tw1
                float2* cplane, hipStream_t st) {
     constexpr int WG = R10<P>::WG, RPW = R10<P>::RPW;
     const size_t lds = (size_t)RPW * R10<P>::IMG * sizeof(float2);
-    static bool attr_set = false;
-    if (!attr_set) {
-        CAF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_perdelay_r10<P>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+    {
+        const int rc_lds = allow_dynamic_lds(reinterpret_cast<const void*>(k_perdelay_r10<P>), lds);
+        if (rc_lds) return rc_lds;
     }
     const int64_t groups = (num + RPW - 1) / RPW;
     const int32_t rows_per_wg = (int32_t)std::max<int64_t>(1, std::min<int64_t>(16, groups / 4096));
