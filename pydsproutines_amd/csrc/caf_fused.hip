@@ -957,6 +957,251 @@ __device__ __forceinline__ void fused_item4(float2* __restrict__ s_d, const floa
     }
 }
 
+// ----------------------------------------------------------------------------------------
+// Templates of 16385 .. 32768 samples, the FOLDED form: 65536-point blocks whose first 32768 outputs are the only valid delays
+// (step 32768), split by the PARITY OF THE OUTPUT,
+//   y[2 k + r] = sum_{m < 32768} G_r[m] W_32768^{m k},   G_r[m] = (Z[m] + (-1)^r Z[m + 32768]) W_65536^{m r},   Z = X . Hc
+// -- one decimation-in-frequency step on the products -- and each residue r is a 32768-point transform of which only the
+// lower half k < 16384 is wanted: fused_item2 with NVH = 0, i.e. TWO chained 16384-point transforms per residue, FOUR per
+// block and hypothesis where fused_item4 (one output quarter from all four spectral residues, twice) ran eight.
+// G_r[2 m' + c] needs P_c[m'] and P_c[m' + 16384] (P_c = the samples of parity c) of the block spectrum and of the template
+// row: both arrive as PAIRS, [c][16384] x (P_c[m'], P_c[m' + 16384]) with every 1024-chunk of m' in butterfly order
+// (k_parity_pairs), so a point is two 16-byte loads -- the same bytes per hypothesis as fused_item4 reads (4 x 32 loads of 16
+// bytes per thread against 8 x 32 of 8).  A hypothesis shift s (in parity-major elements, mod 32768) moves the template
+// pair to (m' - s) mod 16384 and swaps its halves where bit 14 of (m' - s) mod 32768 is set.
+// Input twiddle (r = 1): W_65536^{2 m' + c} with m' = 1024 a + m2 is a per-thread base e^{j 2 pi (2 m2 + c) / 65536} -- common
+// to the sixteen inputs of the thread's pass-1 butterfly, so it moves behind the butterfly into the start of the pass-1
+// recurrence -- times the compile-time constants W_32^a, applied as the products are folded.
+// Registers decide the schedule.  A point in flight is 8 registers, folded 2.  The E half of a hypothesis has room (its
+// transform's 32 registers + addresses), the O half does not (E's 32 outputs wait beside the transform), so the 32 points
+// a thread needs per hypothesis -- the O half's 16, then the next E half's 16 -- are fetched in the quotas 8 / 6 / 6 / 2 over the
+// four passes of the E half and 4 / 2 / 2 / 2 over those of the O half, each batch issued at the start of its pass and folded
+// at its end.
+// Work item = (block, hypothesis group, r): the host doubles ngroups, group = 2 * (hypothesis group) + r.  Tiles: [r][256]
+// per block, tile 256 r + (k >> 6), column k & 63 <-> delay 2 k + r: the tile roles run with a delay stride of 2 (DS).
+template <int MODE, int R>
+__device__ __forceinline__ void fused_item2f(float2* __restrict__ s_d, const float2* __restrict__ s_tw2,
+                                             const float2* __restrict__ s_tw3, const float2* __restrict__ xb,  // [blocks][2][16384] pairs, butterfly order
+                                             const float2* __restrict__ hc,       // [T][2][16384] pairs or [T*F][2][16384] pairs
+                                             const int32_t* __restrict__ shifts, const float2* __restrict__ tw1,
+                                             int32_t table_mode, int32_t nfreq, int32_t nhyp, int blk, int h0, int h1,
+                                             int32_t tiles_per_blk, float* __restrict__ vt) {
+    constexpr int FB4 = 4 * FB;
+    const int tid = threadIdx.x;
+    const lds_char* img = (const lds_char*)s_d;
+    const uint32_t img0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)img);
+    const uint32_t wave_u = __builtin_amdgcn_readfirstlane((uint32_t)tid >> 6);
+    const uint32_t m0_x1 = img0 + wave_u * 256u, m0_w = img0 + wave_u * (uint32_t)FP_P1;
+    const uint32_t m2 = fp_m2((uint32_t)tid);
+    const float2 w = ld2(tw1, 1024u + m2);  // pass-1 twiddle base e^{+j 2 pi m2 / 16384}
+    float2 base0 = make_float2(1.f, 0.f);   // r = 1: e^{+j 2 pi (2 m2) / 65536}
+    if (R) {
+        float sn, cs;
+        sincospif((float)m2 * (1.0f / 16384.0f), &sn, &cs);
+        base0 = make_float2(cs, sn);
+    }
+    const float* xp = (const float*)(xb + (int64_t)blk * FB4);
+    float* vt_blk = vt + (int64_t)blk * tiles_per_blk * nhyp * 64;
+    const __amdgpu_buffer_rsrc_t rvt = buf_of(uniform_ptr(vt_blk), (uint32_t)tiles_per_blk * (uint32_t)nhyp * 256u);
+    const int n1o = tid & 15, n2o = (tid >> 4) & 15, qo = tid >> 8;  // this thread's pass-4 position
+    // template row of a hypothesis and this thread's base index into it: the shift in parity-major elements (= half the
+    // 65536-point shift) mod 32768; bits 0..13 of 1024 a + hb select the pair, bit 14 swaps its halves
+    const float* hrow_o;  // the row of the hypothesis in progress (its O half's inputs)
+    uint32_t hb_o;
+    const float* hrow_n;  // the next hypothesis' row (its E half's inputs)
+    uint32_t hb_n;
+    auto row_of = [&](int h, const float*& hrow, uint32_t& hb) {
+        if (table_mode) {
+            hrow = (const float*)(hc + (int64_t)h * FB4);
+            hb = (uint32_t)tid;
+        } else {
+            const int t = h / nfreq;
+            const int32_t sh = *((const CAF_AS1 int32_t*)shifts + (h - t * nfreq)) >> 1;
+            hrow = (const float*)(hc + (int64_t)t * FB4);
+            hb = fp_hbase(m2, sh);
+        }
+    };
+    // a batch: NP points a = A0 .. A0 + NP - 1 of parity CC, from row HROW / base HB, into the buffers BX / BH
+#define CAF_F2F_ISSUE(BX, BH, HROW, HB, CC, A0, NP, LZ)                                               \
+    _Pragma("unroll") for (int k_ = 0; k_ < (NP); ++k_) {                                             \
+        const uint32_t a_ = (uint32_t)((A0) + k_);                                                    \
+        const uint32_t hi_ = (1024u * a_ + (HB)) & 16383u;                                            \
+        BX[k_] = gld4(xp, ((uint32_t)(CC) * 16384u + 1024u * a_ + (uint32_t)tid + (LZ)) << 4);       \
+        BH[k_] = gld4((HROW), ((uint32_t)(CC) * 16384u + hi_ + (LZ)) << 4);                           \
+    }
+    // ... folded into PR[A0 ..]: G = (X1 H1 + X2 H2) or (X1 H1 - X2 H2) W_32^a
+#define CAF_F2F_FOLD(PR, BX, BH, HB, A0, NP)                                                                   \
+    _Pragma("unroll") for (int k_ = 0; k_ < (NP); ++k_) {                                                      \
+        constexpr double TWO_PI_ = 6.283185307179586476925;                                                    \
+        const int a_ = (A0) + k_;                                                                              \
+        const bool sw_ = ((1024u * (uint32_t)a_ + (HB)) & 16384u) != 0;                                        \
+        const float2 h1_ = make_float2(sw_ ? BH[k_].z : BH[k_].x, sw_ ? BH[k_].w : BH[k_].y);                 \
+        const float2 h2_ = make_float2(sw_ ? BH[k_].x : BH[k_].z, sw_ ? BH[k_].y : BH[k_].w);                 \
+        const float2 z1_ = cmul(make_float2(BX[k_].x, BX[k_].y), h1_);                                         \
+        const float2 z2_ = cmul(make_float2(BX[k_].z, BX[k_].w), h2_);                                         \
+        if (R == 0)                                                                                            \
+            PR[a_] = cadd(z1_, z2_);                                                                           \
+        else if (a_ == 0)                                                                                      \
+            PR[a_] = csub(z1_, z2_);                                                                           \
+        else if (a_ == 8)                                                                                      \
+            PR[a_] = mulj(csub(z1_, z2_));                                                                     \
+        else                                                                                                   \
+            PR[a_] = cmul(csub(z1_, z2_), make_float2((float)__builtin_cos(TWO_PI_ * a_ / 32.0),               \
+                                                      (float)__builtin_sin(TWO_PI_ * a_ / 32.0)));             \
+    }
+    float2 pro[16], prn[16];  // folded inputs: of the O half of the hypothesis in progress / of the next E half
+    row_of(h0, hrow_o, hb_o);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        float4 bx[8], bh[8];
+        CAF_F2F_ISSUE(bx, bh, hrow_o, hb_o, 0, 8 * b, 8, 0u)
+        CAF_F2F_FOLD(prn, bx, bh, hb_o, 8 * b, 8)
+    }
+    float2 e[16];  // E's outputs (register 4 i + n4 <-> n3 = q + 4 i, n4)
+
+    for (int h = h0; h < h1; ++h) {
+        uint32_t hoff = (uint32_t)h * 256u;  // bytes
+        asm volatile("" : "+s"(hoff));
+        row_of(h + 1 < h1 ? h + 1 : h, hrow_n, hb_n);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            uint32_t lz = 0;
+            asm volatile("" : "+v"(lz));
+            // ---- pass 1: DFT16 over a of the folded products, twiddle (r = 1: the recurrence starts at the input base), write ----
+            {
+                float2 v1[16];
+#pragma unroll
+                for (int a = 0; a < 16; ++a) v1[a] = c == 0 ? prn[a] : pro[a];
+                float4 bx[8], bh[8];
+                if (c == 0) {
+                    CAF_F2F_ISSUE(bx, bh, hrow_o, hb_o, 1, 0, 8, lz)
+                } else {
+                    CAF_F2F_ISSUE(bx, bh, hrow_n, hb_n, 0, 6, 4, lz)
+                }
+                idft16(v1);
+                // e^{+j 2 pi / 32768} on the odd half: the combination twiddle's n1 digit (fused_item2)
+                float2 wj = c == 0 ? w : cmul(w, make_float2(0.99999998161642933f, 1.9174759731070330e-4f));
+                asm volatile("" : "+v"(wj.x), "+v"(wj.y));
+                float2 p;
+                if (R) {
+                    p = c == 0 ? base0 : cmul(base0, make_float2(0.99999999540410733f, 9.5873799095977345e-5f));  // * e^{+j 2 pi / 65536}
+                    v1[0] = cmul(v1[0], p);
+                    p = cmul(p, wj);
+                } else {
+                    p = wj;
+                }
+                v1[1] = cmul(v1[1], p);
+#pragma unroll
+                for (int n1 = 2; n1 < 16; ++n1) {
+                    p = cmul(p, wj);
+                    v1[n1] = cmul(v1[n1], p);
+                }
+                __syncthreads();  // the previous sub-transform's pass-4 reads are done
+                lds_rows16c<FP_P1>(m0_x1, v1);
+                if (c == 0) {
+                    CAF_F2F_FOLD(pro, bx, bh, hb_o, 0, 8)
+                } else {
+                    CAF_F2F_FOLD(prn, bx, bh, hb_n, 6, 4)
+                }
+            }
+            __syncthreads();
+            // ---- pass 2 ----
+            {
+                float2 v[16];
+                const uint32_t rd2 = fp_rd2((uint32_t)(tid + lz)), rd2i = fp_im(rd2);
+                const lds_tw_ptr t2 = tw_base(s_tw2, fp_cd2((uint32_t)(tid + lz)));
+                float4 bx[6], bh[6];
+                if (c == 0) {
+                    CAF_F2F_ISSUE(bx, bh, hrow_o, hb_o, 1, 8, 6, lz)
+                } else {
+                    CAF_F2F_ISSUE(bx, bh, hrow_n, hb_n, 0, 10, 2, lz)
+                }
+#pragma unroll
+                for (int bh_ = 0; bh_ < 4; ++bh_) lds_get4c(img, rd2 + 256u * bh_, rd2i + 256u * bh_, v[4 * bh_], v[4 * bh_ + 1], v[4 * bh_ + 2], v[4 * bh_ + 3]);
+                idft16(v);
+#pragma unroll
+                for (int n2 = 1; n2 < 16; ++n2) v[n2] = cmul(v[n2], tw_ld(t2, 1024 * c + n2 * 64));
+                lds_rows16c_x2(m0_w, v);
+                if (c == 0) {
+                    CAF_F2F_FOLD(pro, bx, bh, hb_o, 8, 6)
+                } else {
+                    CAF_F2F_FOLD(prn, bx, bh, hb_n, 10, 2)
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            // ---- pass 3 ----
+            {
+                float2 v[16];
+                const uint32_t rd3 = fp_rd3((uint32_t)(tid + lz)), rd3i = fp_im(rd3);
+                float4 bx[6], bh[6];
+                if (c == 0) {
+                    CAF_F2F_ISSUE(bx, bh, hrow_o, hb_o, 1, 14, 2, lz)
+                    float4* bxn = bx + 2;
+                    float4* bhn = bh + 2;
+                    CAF_F2F_ISSUE(bxn, bhn, hrow_n, hb_n, 0, 0, 4, lz)
+                } else {
+                    CAF_F2F_ISSUE(bx, bh, hrow_n, hb_n, 0, 12, 2, lz)
+                }
+#pragma unroll
+                for (int ch = 0; ch < 4; ++ch) lds_get4c(img, rd3 + 64u * ch, rd3i + 64u * ch, v[4 * ch], v[4 * ch + 1], v[4 * ch + 2], v[4 * ch + 3]);
+                idft16(v);
+#pragma unroll
+                for (int n3 = 1; n3 < 16; ++n3) v[n3] = cmul(v[n3], tw_ld(tw_base(s_tw3, (uint32_t)((tid & 3) + lz)), 64 * c + n3 * 4));
+                lds_rows16c<256>(m0_w, v);
+                if (c == 0) {
+                    CAF_F2F_FOLD(pro, bx, bh, hb_o, 14, 2)
+                    float4* bxn = bx + 2;
+                    float4* bhn = bh + 2;
+                    CAF_F2F_FOLD(prn, bxn, bhn, hb_n, 0, 4)
+                } else {
+                    CAF_F2F_FOLD(prn, bx, bh, hb_n, 12, 2)
+                }
+            }
+            __syncthreads();
+            // ---- pass 4: DFT4 over d; the E half keeps its outputs, the O half combines and stores the lower half ----
+            const uint32_t rd4 = fp_rd4((uint32_t)tid), rd4i = fp_im(rd4);
+            float4 bx4[2], bh4[2];
+            CAF_F2F_ISSUE(bx4, bh4, hrow_n, hb_n, 0, (c == 0 ? 4 : 14), 2, lz)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                uint32_t lzi = 0;
+                asm volatile("" : "+v"(lzi));
+                float2 a0, a1, a2, a3;
+                lds_get4c(img, rd4 + 1024u * i + lzi, rd4i + 1024u * i + lzi, a0, a1, a2, a3);
+                idft4(a0, a1, a2, a3);
+                const float2 y[4] = {a0, a1, a2, a3};
+                if (c == 0) {
+#pragma unroll
+                    for (int n4 = 0; n4 < 4; ++n4) e[4 * i + n4] = y[n4];
+                } else {
+#pragma unroll
+                    for (int n4 = 0; n4 < 4; ++n4) {
+                        // O' = O * W_8^{n4} (the last factor of the combination twiddle of the 32768-point transform)
+                        constexpr float R2 = 0.70710678118654752f;
+                        const float2 t = n4 == 0   ? y[0]
+                                         : n4 == 1 ? make_float2((y[1].x - y[1].y) * R2, (y[1].x + y[1].y) * R2)
+                                         : n4 == 2 ? mulj(y[2])
+                                                   : make_float2((-y[3].x - y[3].y) * R2, (y[3].x - y[3].y) * R2);
+                        const float2 ylo = cadd(e[4 * i + n4], t);
+                        const int tile_u = 16 * i + 64 * n4 + 256 * R;
+                        const int tile_t = (n2o >> 2) + 4 * qo;
+                        const uint32_t soff = (uint32_t)tile_u * (uint32_t)nhyp * 256u + hoff;  // uniform (scalar) offset
+                        const uint32_t voff = ((uint32_t)tile_t * (uint32_t)nhyp * 64u + (uint32_t)(n1o + 16 * (n2o & 3))) << 2;
+                        tile_store<MODE>(rvt, voff, soff, __builtin_fmaf(ylo.x, ylo.x, ylo.y * ylo.y));
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            CAF_F2F_FOLD(prn, bx4, bh4, hb_n, (c == 0 ? 4 : 14), 2)
+        }
+        hrow_o = hrow_n;
+        hb_o = hb_n;
+    }
+#undef CAF_F2F_ISSUE
+#undef CAF_F2F_FOLD
+}
+
 // natural order -> butterfly order, chunk by chunk of 1024 elements (see fp_tid_of)
 __global__ __launch_bounds__(256) void k_butterfly_order(const float2* __restrict__ in, float2* __restrict__ out, int64_t nchunks) {
     for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x)
@@ -997,6 +1242,25 @@ void launch_residue_major4(const float2* in, float2* out, int64_t rows, int32_t 
     for (int64_t r0 = 0; r0 < rows; r0 += 65535) {
         const int64_t nr = std::min<int64_t>(65535, rows - r0);
         hipLaunchKernelGGL(k_residue_major4, dim3(16, (unsigned)nr), dim3(256), 0, st, in + r0 * 4 * quarter, out + r0 * 4 * quarter, quarter);
+    }
+}
+// rows of B = 4 * quarter complex samples -> PAIRS of the two halves of each parity (fused_item2f):
+// out[r][c][j] = (in[r][2 m + c], in[r][2 (m + quarter) + c]) as one 16-byte element, m = the butterfly-order source of j
+__global__ __launch_bounds__(256) void k_parity_pairs(const float2* __restrict__ in, float4* __restrict__ out, int32_t quarter) {
+    const float2* ir = in + (int64_t)blockIdx.y * 4 * quarter;
+    float4* orow = out + (int64_t)blockIdx.y * 2 * quarter;
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < quarter; j += gridDim.x * 256) {
+        const int m = (int)((j & ~1023) + fp_m2((uint32_t)j & 1023u));
+        const float4 lo = *reinterpret_cast<const float4*>(&ir[2 * m]), hi = *reinterpret_cast<const float4*>(&ir[2 * (m + quarter)]);
+        orow[j] = make_float4(lo.x, lo.y, hi.x, hi.y);
+        orow[quarter + j] = make_float4(lo.z, lo.w, hi.z, hi.w);
+    }
+}
+void launch_parity_pairs(const float2* in, float2* out, int64_t rows, int32_t quarter, hipStream_t st) {
+    for (int64_t r0 = 0; r0 < rows; r0 += 65535) {
+        const int64_t nr = std::min<int64_t>(65535, rows - r0);
+        hipLaunchKernelGGL(k_parity_pairs, dim3(16, (unsigned)nr), dim3(256), 0, st, in + r0 * 4 * quarter,
+                           reinterpret_cast<float4*>(out + r0 * 4 * quarter), quarter);
     }
 }
 void launch_parity_major(const float2* in, float2* out, int64_t rows, int32_t half, hipStream_t st, bool butterfly) {
@@ -1284,7 +1548,8 @@ constexpr int TW_H = 32;              // hypotheses per step
 constexpr int TW_PITCH = TW_H + 1;    // LDS row pitch (floats): conflict-free transposed writes
 constexpr int TW_LDS = 64 * TW_PITCH;  // floats per wave
 
-template <bool SURF>
+// DS: delay stride of a tile (1; 2 for the folded 65536-point role, whose tile 256 r + u holds the delays 2 (64 u + j) + r)
+template <bool SURF, int DS>
 __device__ __forceinline__ void transpose_wave(float* __restrict__ lds, const PersistParams* pp, int z, int tile0) {
     const CAF_AS4 PersistParams* P = params_of(pp);
     const int32_t ntmpl = P->ntmpl, nfreq = P->nfreq, step = P->step, tiles_per_blk = P->tiles_per_blk;
@@ -1295,11 +1560,11 @@ __device__ __forceinline__ void transpose_wave(float* __restrict__ lds, const Pe
     const int tile = tile0 + wave_id;
     if (tile >= tiles_per_blk) return;  // (wave-uniform; no barriers in this role)
     const int blk = P->blk0 + z;
-    const int sl0 = tile * 64;
+    const int sl0 = DS == 2 ? 128 * (tile & 255) + (tile >> 8) : tile * 64;  // the tile's first delay inside the block
     const int64_t rel0 = (int64_t)blk * step + sl0;
     int64_t nv = num_shifts - (int64_t)blk * step;
     if (nv > step) nv = step;
-    const int nrows = sl0 < nv ? (int)min((int64_t)64, nv - sl0) : 0;
+    const int nrows = sl0 < nv ? (int)min((int64_t)64, (nv - sl0 + DS - 1) / DS) : 0;
     const int64_t pidx = (int64_t)blk * tiles_per_blk + tile;
     PeakRec* partial = P->partial;
     const int64_t ppt = P->partial_per_tmpl;
@@ -1322,13 +1587,13 @@ __device__ __forceinline__ void transpose_wave(float* __restrict__ lds, const Pe
         float* srow0 = SURF ? uniform_ptr(P->surface + ((int64_t)t * num_shifts + rel0) * nfreq) : nullptr;
         const float ts = P->tscale[t];
         const __amdgpu_buffer_rsrc_t rin = buf_of(vin, (uint32_t)nfreq * 256u);
-        const __amdgpu_buffer_rsrc_t rout = buf_of(srow0, (uint32_t)(nrows * nfreq) * 4u);  // rows >= nrows: dropped
-        const __amdgpu_buffer_rsrc_t rie = buf_of(uniform_ptr(P->inv_e + rel0), (uint32_t)nrows * 4u);
+        const __amdgpu_buffer_rsrc_t rout = buf_of(srow0, (uint32_t)(((nrows - 1) * DS + 1) * nfreq) * 4u);  // rows >= nrows: dropped
+        const __amdgpu_buffer_rsrc_t rie = buf_of(uniform_ptr(P->inv_e + rel0), (uint32_t)((nrows - 1) * DS + 1) * 4u);
         float g[4], bv[4];
         int32_t bi[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            g[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rie, (s4 + k) * 4, 0, 0)) * ts;
+            g[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rie, (s4 + k) * 4 * DS, 0, 0)) * ts;
             bv[k] = -1.f;
             bi[k] = 0;
         }
@@ -1346,7 +1611,7 @@ __device__ __forceinline__ void transpose_wave(float* __restrict__ lds, const Pe
         const int half = lane >> 5, col = lane & 31;
         const float* srd = s_w + half * TW_PITCH + col;
         float* swr = s_w + s4 * TW_PITCH + fq;
-        const int voff = (half * nfreq + col) * 4;
+        const int voff = (half * DS * nfreq + col) * 4;
         auto do_step = [&](v4f_t(&q)[TW_H / 4], int s) {
             const int f0 = s * TW_H;
 #pragma unroll
@@ -1370,7 +1635,7 @@ __device__ __forceinline__ void transpose_wave(float* __restrict__ lds, const Pe
 #pragma unroll
                 for (int r = 0; r < 64; r += 2)
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, srd[r * TW_PITCH]), rout, vo,
-                                                          (r * nfreq + f0) * 4, CAF_AUX_NT);
+                                                          (r * DS * nfreq + f0) * 4, CAF_AUX_NT);
                 __builtin_amdgcn_wave_barrier();
             }
         };
@@ -1399,12 +1664,12 @@ __device__ __forceinline__ void transpose_wave(float* __restrict__ lds, const Pe
         float best = -1.f;
         int32_t bdel = 0x7fffffff, bfrq = 0;
         if (fq == 0) {
-            const int64_t o = (int64_t)t * num_shifts + rel0 + s4;
+            const int64_t o = (int64_t)t * num_shifts + rel0 + s4 * DS;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if (s4 + k < nrows) {
-                    if (row_max) row_max[o + k] = bv[k] < 0.f ? __builtin_nanf("") : bv[k];  // (zero-energy window: all NaN, as the reference's 0 / 0)
-                    if (row_arg) row_arg[o + k] = bi[k];
+                    if (row_max) row_max[o + k * DS] = bv[k] < 0.f ? __builtin_nanf("") : bv[k];  // (zero-energy window: all NaN, as the reference's 0 / 0)
+                    if (row_arg) row_arg[o + k * DS] = bi[k];
                     if (bv[k] > best) {  // increasing delay: first maximum wins
                         best = bv[k];
                         bdel = s4 + k;
@@ -1428,7 +1693,7 @@ __device__ __forceinline__ void transpose_wave(float* __restrict__ lds, const Pe
             if (lane == 0) {
                 PeakRec r;
                 r.v = best;
-                r.delay = (int32_t)(shift_start + rel0 + bdel);
+                r.delay = (int32_t)(shift_start + rel0 + bdel * DS);
                 r.f = bfrq;
                 partial[(int64_t)t * ppt + pidx] = r;
             }
@@ -1442,6 +1707,7 @@ __device__ __forceinline__ void transpose_wave(float* __restrict__ lds, const Pe
 // template's 64 results as 16-byte pieces straight to row_max (and the (T, S, 1) surface), row_arg = 0, and a
 // (delay, value) record per (tile, template).  One step replaces 32 passes of the general path.
 // (out of line: keeps the general path's register allocation unchanged)
+template <int DS>
 __device__ __attribute__((noinline)) void transpose_wave_f1(const PersistParams* pp_in, int z_in, int tile0_in) {
     const PersistParams* pp = uniform_ptr(pp_in);
     const int z = __builtin_amdgcn_readfirstlane(z_in), tile0 = __builtin_amdgcn_readfirstlane(tile0_in);
@@ -1453,11 +1719,11 @@ __device__ __attribute__((noinline)) void transpose_wave_f1(const PersistParams*
     const int tile = tile0 + wave_id;
     if (tile >= tiles_per_blk) return;
     const int blk = P->blk0 + z;
-    const int sl0 = tile * 64;
+    const int sl0 = DS == 2 ? 128 * (tile & 255) + (tile >> 8) : tile * 64;  // the tile's first delay inside the block
     const int64_t rel0 = (int64_t)blk * step + sl0;
     int64_t nv = num_shifts - (int64_t)blk * step;
     if (nv > step) nv = step;
-    const int nrows = sl0 < nv ? (int)min((int64_t)64, nv - sl0) : 0;
+    const int nrows = sl0 < nv ? (int)min((int64_t)64, (nv - sl0 + DS - 1) / DS) : 0;
     const int64_t pidx = (int64_t)blk * tiles_per_blk + tile;
     PeakRec* partial = P->partial;
     const int64_t ppt = P->partial_per_tmpl;
@@ -1468,11 +1734,11 @@ __device__ __attribute__((noinline)) void transpose_wave_f1(const PersistParams*
     const float* vin = uniform_ptr(P->vt + ((int64_t)z * tiles_per_blk + tile) * (int64_t)nhyp * 64);
     const __amdgpu_buffer_rsrc_t rin = buf_of(vin, (uint32_t)nhyp * 256u);
     const __amdgpu_buffer_rsrc_t rts = buf_of(P->tscale, (uint32_t)nhyp * 4u);
-    const __amdgpu_buffer_rsrc_t rie = buf_of(uniform_ptr(P->inv_e + rel0), (uint32_t)nrows * 4u);
+    const __amdgpu_buffer_rsrc_t rie = buf_of(uniform_ptr(P->inv_e + rel0), nrows > 0 ? (uint32_t)((nrows - 1) * DS + 1) * 4u : 0u);
     float g[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) g[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rie, (s4 + k) * 4, 0, 0));
-    const bool all4 = s4 + 3 < nrows;
+    for (int k = 0; k < 4; ++k) g[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rie, (s4 + k) * 4 * DS, 0, 0));
+    const bool all4 = DS == 1 && s4 + 3 < nrows;  // (16-byte pieces: consecutive delays only)
     for (int h0 = 0; h0 < nhyp; h0 += TW_H) {
         v4f_t q[TW_H / 4];
         float ts[TW_H / 4];
@@ -1490,7 +1756,7 @@ __device__ __attribute__((noinline)) void transpose_wave_f1(const PersistParams*
             const float x[4] = {q[i].x * (g[0] * ts[i]), q[i].y * (g[1] * ts[i]), q[i].z * (g[2] * ts[i]),
                                 q[i].w * (g[3] * ts[i])};
             if (hv && nrows > 0) {
-                const int64_t o = (int64_t)h * num_shifts + rel0 + s4;
+                const int64_t o = (int64_t)h * num_shifts + rel0 + s4 * DS;
                 if (all4) {
                     const v4f_u_t xv = {x[0], x[1], x[2], x[3]};
                     const v4i_u_t zv = {0, 0, 0, 0};
@@ -1501,9 +1767,9 @@ __device__ __attribute__((noinline)) void transpose_wave_f1(const PersistParams*
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
                         if (s4 + k < nrows) {
-                            if (row_max) row_max[o + k] = x[k];
-                            if (surface) surface[o + k] = x[k];
-                            if (row_arg) row_arg[o + k] = 0;
+                            if (row_max) row_max[o + k * DS] = x[k];
+                            if (surface) surface[o + k * DS] = x[k];
+                            if (row_arg) row_arg[o + k * DS] = 0;
                         }
                 }
             }
@@ -1529,7 +1795,7 @@ __device__ __attribute__((noinline)) void transpose_wave_f1(const PersistParams*
                 if (hv && (lane & 15) == 0) {
                     PeakRec r;
                     r.v = best;
-                    r.delay = nrows > 0 && bdel != 0x7fffffff ? (int32_t)(shift_start + rel0 + bdel) : 0x7fffffff;
+                    r.delay = nrows > 0 && bdel != 0x7fffffff ? (int32_t)(shift_start + rel0 + bdel * DS) : 0x7fffffff;
                     r.f = 0;
                     partial[(int64_t)h * ppt + pidx] = r;
                 }
@@ -1672,12 +1938,19 @@ __device__ __attribute__((noinline)) void persistent_tile_run(lds_float* lds_in,
         const int z = item / ipb;
         if (P->nosurf)
             reduce_wave_nosurf(pp, z, (item - z * ipb) * PQ_TILES);
-        else if (P->nfreq == 1)
-            transpose_wave_f1(pp, z, (item - z * ipb) * PQ_TILES);
+        else if (P->dstride == 2) {  // folded 65536-point role: tiles [r][256] of every second delay
+            if (P->nfreq == 1)
+                transpose_wave_f1<2>(pp, z, (item - z * ipb) * PQ_TILES);
+            else if (P->surface)
+                transpose_wave<true, 2>(lds, pp, z, (item - z * ipb) * PQ_TILES);
+            else
+                transpose_wave<false, 2>(lds, pp, z, (item - z * ipb) * PQ_TILES);
+        } else if (P->nfreq == 1)
+            transpose_wave_f1<1>(pp, z, (item - z * ipb) * PQ_TILES);
         else if (P->surface)
-            transpose_wave<true>(lds, pp, z, (item - z * ipb) * PQ_TILES);
+            transpose_wave<true, 1>(lds, pp, z, (item - z * ipb) * PQ_TILES);
         else
-            transpose_wave<false>(lds, pp, z, (item - z * ipb) * PQ_TILES);
+            transpose_wave<false, 1>(lds, pp, z, (item - z * ipb) * PQ_TILES);
         if (wave_id == 0) {
             int32_t* pq = P->pq;
             const int n_fft = P->n_fft, n_tr = P->n_tr, ngroups = P->ngroups;
@@ -1835,6 +2108,27 @@ __device__ __attribute__((noinline)) void persistent_fft_item4(lds_float2* s_d, 
         __hip_atomic_fetch_add(&params_of(pp)->pq[PQ_DONE + blk], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// FFT role for 65536-point blocks, folded form (fused_item2f): work item = (block, hypothesis group, output residue r), group
+// number = 2 * (hypothesis group) + r, same publish sequence
+template <int R>
+__device__ __attribute__((noinline)) void persistent_fft_item2f(lds_float2* s_d, const lds_float2* s_tw2, const lds_float2* s_tw3,
+                                                                const PersistParams* pp_in, int item_in) {
+    const PersistParams* pp = uniform_ptr(pp_in);
+    const int item = __builtin_amdgcn_readfirstlane(item_in);
+    const CAF_AS4 PersistParams* P = params_of(pp);
+    const int ngroups = P->ngroups, hyp_per_wg = P->hyp_per_wg, nhyp = P->nhyp;
+    const int blk = item / ngroups;
+    const int grp = (item - blk * ngroups) >> 1;
+    const int h0 = grp * hyp_per_wg;
+    const int h1 = min(h0 + hyp_per_wg, nhyp);
+    fused_item2f<1, R>((float2*)s_d, (const float2*)s_tw2, (const float2*)s_tw3, P->xb, P->hc, P->shifts, P->tw1, P->table_mode,
+                       P->nfreq, nhyp, blk, h0, h1, P->tiles_per_blk, P->vt);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (threadIdx.x == 0)
+        __hip_atomic_fetch_add(&params_of(pp)->pq[PQ_DONE + blk], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <bool STATS>
 __global__ __launch_bounds__(1024) void k_caf_persistent(const PersistParams* __restrict__ pp) {
     static_assert(16 * TW_LDS * 4 <= F_LDS_DATA * 8, "transposer patches must fit the FFT image");
@@ -1959,7 +2253,12 @@ __global__ __launch_bounds__(1024) void k_caf_persistent(const PersistParams* __
             break;
         }
         if (kind == 1) {
-            if (__builtin_amdgcn_readfirstlane(params_of(pp)->block_log2) == 16) {
+            if (__builtin_amdgcn_readfirstlane(params_of(pp)->block_log2) == 16 && __builtin_amdgcn_readfirstlane(params_of(pp)->dstride) == 2) {
+                if ((item - (item / params_of(pp)->ngroups) * params_of(pp)->ngroups) & 1)
+                    persistent_fft_item2f<1>((lds_float2*)s_d, (const lds_float2*)s_tw2, (const lds_float2*)s_tw3, pp, item);
+                else
+                    persistent_fft_item2f<0>((lds_float2*)s_d, (const lds_float2*)s_tw2, (const lds_float2*)s_tw3, pp, item);
+            } else if (__builtin_amdgcn_readfirstlane(params_of(pp)->block_log2) == 16) {
                 if ((item - (item / params_of(pp)->ngroups) * params_of(pp)->ngroups) & 1)
                     persistent_fft_item4<1>((lds_float2*)s_d, (const lds_float2*)s_tw2, (const lds_float2*)s_tw3, pp, item);
                 else

@@ -68,6 +68,7 @@ struct caf_plan_t {
     int T = 0, N = 0, F = 0, G = 0;
     int freq_mode = 0, mul_mode = 0;
     int B = 0, step = 0, pitch = 0, nb = 0, tiles_per_blk = 0, hyp_per_wg = 16, fwd_chunk = 1;
+    bool fold16 = false;  // 65536-point blocks in the folded form (fused_item2f) instead of fused_item4
     int nb_nosurf = 0;  // persistent engine, no-surface mode: blocks per launch (the pair arrays are ~1/32 of the tiles)
     int64_t max_rx = 0, max_blocks = 0, partial_per_tmpl = 0;
     int device = 0;
@@ -495,6 +496,10 @@ static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
     // block yields 32768 delays whatever the template length in (16384, 32768] (fused_item4: two pending quarters do not fit
     // the registers, and a third quarter would cost what it yields)
     if (p->fused && lb == 16) p->step = 32768;
+    {
+        const char* e = getenv("CAF_LB16_FOLD");  // A/B switch: 0 = fused_item4 (eight sub-transforms per 32768 delays)
+        p->fold16 = p->fused && lb == 16 && (!e || atoi(e));
+    }
     p->pitch = p->B + 64;  // break the power-of-two stride between hypothesis rows
     const int B = p->B;
 
@@ -689,7 +694,10 @@ static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
             float2* tmp = nullptr;
             rc = pool_alloc((void**)&tmp, nspec * (int64_t)B * 8);
             if (rc == CAF_OK) {
-                launch_residue_major4(p->d_hc, tmp, nspec, B / 4, nullptr);
+                if (p->fold16)  // (folded form: pairs of the two halves of each parity)
+                    launch_parity_pairs(p->d_hc, tmp, nspec, B / 4, nullptr);
+                else
+                    launch_residue_major4(p->d_hc, tmp, nspec, B / 4, nullptr);
                 if (hipMemcpyAsync(p->d_hc, tmp, (size_t)nspec * B * 8, hipMemcpyDeviceToDevice, nullptr) != hipSuccess) rc = CAF_ERR_HIP;
                 (void)hipStreamSynchronize(nullptr);
                 (void)pool_free(tmp);
@@ -944,7 +952,9 @@ int32_t caf_plan_execute2(caf_plan p, const float* d_rx, int64_t rx_len, int64_t
     }
     if (p->fused && p->B == 32768 && !lds_fwd32)  // block spectra parity-major for the two chained half-transforms
         launch_parity_major(p->d_xb, p->d_xb2, nfwd * p->fwd_chunk, p->B / 2, st, true);
-    if (p->fused && p->B == 65536)  // ... residue-major for the four chained sub-transforms
+    if (p->fused && p->B == 65536 && p->fold16)  // ... pairs of the halves of each parity for the folded form
+        launch_parity_pairs(p->d_xb, p->d_xb2, nfwd * p->fwd_chunk, p->B / 4, st);
+    else if (p->fused && p->B == 65536)  // ... residue-major for the four chained sub-transforms
         launch_residue_major4(p->d_xb, p->d_xb2, nfwd * p->fwd_chunk, p->B / 4, st);
     if (aux) CAF_HIP_TRY(hipStreamWaitEvent(st, p->ev_join, 0));
     bool f1_direct = false, f1_item_peaks = false;
@@ -1008,6 +1018,7 @@ int32_t caf_plan_execute2(caf_plan p, const float* d_rx, int64_t rx_len, int64_t
             h.nblk = nbk;
             h.tiles_per_blk = p->tiles_per_blk;
             h.block_log2 = p->B == 65536 ? 16 : p->B == 32768 ? 15 : 14;
+            h.dstride = p->fold16 ? 2 : 1;
             h.ntmpl = T;
             h.step = p->step;
             h.blk0 = (int32_t)b0;

@@ -15,10 +15,11 @@ M, F = 1 << 24, 256
 rng = np.random.default_rng(4)
 rx = cn(rng, M)
 d_rx = asarray(rx)
-for n in (4096, 8192, 8193, 16384, 16385, 24576, 32768, 32769):
+LENGTHS = tuple(int(a) for a in sys.argv[1:]) or (4096, 8192, 8193, 16384, 16385, 24576, 32768, 32769)  # (optional: the lengths to time)
+for n in LENGTHS:
     t = qpsk(rng, n)
     grid = min(16384, 1 << int(np.ceil(np.log2(n))))
-    for engine in (("auto",) if n <= 8192 or n > 32768 else ("auto", "rocfft")):
+    for engine in (("auto",) if n <= 8192 or n > 32768 or len(sys.argv) > 1 else ("auto", "rocfft")):
         plan = CAFPlan(t, max_rx_len=M, bins=np.arange(-F // 2, F // 2), grid=grid, engine=engine)
         res = plan.run(d_rx, surface=True)
         _lib.check(_lib.load().caf_stream_sync(None))
