@@ -26,6 +26,7 @@
 // overlaps it with the transpose stage on other CUs in a single work-queue launch.
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "caf_internal.h"
 #include "caf_fft_dev.h"
@@ -595,398 +596,60 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
 }
 
 // ----------------------------------------------------------------------------------------
-// Templates of 8193 .. 16384 samples: 32768-point blocks as TWO chained 16384-point transforms in the same LDS image.
+// Templates of 8193 .. 32768 samples: the CHAINED role -- a 32768-point inverse transform as TWO 16384-point transforms in
+// the same LDS image.
 //   y[n] = sum_m P[m] W^{mn},  W = e^{+j 2 pi / 32768},  m = 2 m' + c:
 //   y[n'] = E[n'] + W^{n'} O[n'],   y[n' + 16384] = E[n'] - W^{n'} O[n'],   E / O = IFFT_16384 of the even / odd samples
-// The block spectra and the template-spectrum rows arrive PARITY-MAJOR ([c][16384] per row: k_parity_major below), so a
-// half-transform reads exactly what fused_item reads for a 16384-point block -- contiguous, and with the (even) shift
-// of an on-grid hypothesis halved.  E's sixteen outputs per thread wait in registers while O runs through the same
-// four passes; both transforms leave a thread the same sixteen positions n' = n1 + 16 n2 + 256 n3 + 4096 n4, so the
-// radix-2 combination is register-local and nothing but |y|^2 leaves the CU.
-// Registers (128): the block spectrum cannot stay resident (two parities = 64); instead the inputs of the O half are
-// fetched before pass 3 of the E half (E's outputs do not exist yet), and the inputs of the next E half are fetched
-// inside pass 4 of the O half, four positions at a time, as the combination frees E's registers.
-// Tiles: n -> tile n >> 6 as before (up to 384 tiles for N = 8193).  Write-through stores (MODE 1) or plain (0).
-// NVH: quarters n4 < NVH of the UPPER half y[n' + 16384] hold valid delays (N = 16384: none -- the block's valid delays are
-// exactly the lower half; N = 8193: two); the others are not combined, squared or stored.
-template <int MODE, int NVH = 4>
-__device__ __forceinline__ void fused_item2(float2* __restrict__ s_d, const float2* __restrict__ s_tw2,
-                                            const float2* __restrict__ s_tw3, const float2* __restrict__ xb,  // [blocks][2][16384], butterfly order
-                                            const float2* __restrict__ hc,       // [T][2][16384] or [T*F][2][16384]
-                                            const int32_t* __restrict__ shifts, const float2* __restrict__ tw1,
-                                            int32_t table_mode, int32_t nfreq, int32_t nhyp, int blk, int h0, int h1,
-                                            int32_t tiles_per_blk, float* __restrict__ vt) {
-    constexpr int FB2 = 2 * FB;
-    const int tid = threadIdx.x;
-    const lds_char* img = (const lds_char*)s_d;
-    const uint32_t img0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)img);
-    const uint32_t wave_u = __builtin_amdgcn_readfirstlane((uint32_t)tid >> 6);
-    const uint32_t m0_x1 = img0 + wave_u * 256u, m0_w = img0 + wave_u * (uint32_t)FP_P1;
-    const uint32_t m2 = fp_m2((uint32_t)tid);            // this thread's pass-1 butterfly (see fp_m2)
-    const float2 w = ld2(tw1, 1024u + m2);  // pass-1 twiddle base e^{+j 2 pi m2 / 16384}
-    // The combination twiddle of the odd half, W^{n'} with n' = n1 + 16 n2 + 256 n3 + 4096 n4, is a product of one factor
-    // per output digit: each pass applies the factor of the digit it produces -- pass 1 through its base (2 m2 + 1
-    // instead of 2 m2 in 32768ths), passes 2 and 3 through the second halves of the twiddle tables, pass 4 as the
-    // constants W_8^{n4} -- so E and O' = W^{n'} O combine with an addition and a subtraction only.
-    const float2 w_odd = cmul(w, make_float2(0.99999998161642933f, 1.9174759731070330e-4f));  // * e^{+j 2 pi / 32768}
-    const float2* xp = xb + (int64_t)blk * FB2;
-    float* vt_blk = vt + (int64_t)blk * tiles_per_blk * nhyp * 64;
-    const __amdgpu_buffer_rsrc_t rvt = buf_of(uniform_ptr(vt_blk), (uint32_t)tiles_per_blk * (uint32_t)nhyp * 256u);
-    const int n1o = tid & 15, n2o = (tid >> 4) & 15, qo = tid >> 8;  // this thread's pass-4 position
-    const float2* hrow_cur;
-    uint32_t hb_cur;  // as in fused_item, with the shift in parity-major elements (= half the 32768-point shift)
-    auto row_of = [&](int h) {
-        if (table_mode) {
-            hrow_cur = hc + (int64_t)h * FB2;
-            hb_cur = (uint32_t)tid;
-        } else {
-            const int t = h / nfreq;
-            const int32_t sh = *((const CAF_AS1 int32_t*)shifts + (h - t * nfreq)) >> 1;
-            hrow_cur = hc + (int64_t)t * FB2;
-            hb_cur = fp_hbase(m2, sh);
-        }
-    };
-    float2 xn[16], hn[16];  // inputs of the NEXT half-transform
-    row_of(h0);
-#pragma unroll
-    for (int a = 0; a < 16; ++a) {
-        xn[a] = ld2(xp, 1024u * a + tid);
-        hn[a] = ld2(hrow_cur, (1024u * a + hb_cur) & (FB - 1));
-    }
-    float2 e[16];  // E's outputs (register 4 i + n4 <-> n3 = q + 4 i, n4)
-
-    for (int h = h0; h < h1; ++h) {
-        uint32_t hoff = (uint32_t)h * 256u;  // bytes
-        asm volatile("" : "+s"(hoff));
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            int lz = 0;
-            asm volatile("" : "+v"(lz));
-            // ---- pass 1 (as fused_item): product, DFT16 over a, twiddle, write ----
-            {
-                float2 v1[16];
-#pragma unroll
-                for (int a = 0; a < 16; ++a) v1[a] = cmul(xn[a], hn[a]);
-                idft16(v1);
-                float2 p = c == 0 ? w : w_odd;
-                asm volatile("" : "+v"(p.x), "+v"(p.y));
-                const float2 wj = p;
-                v1[1] = cmul(v1[1], p);
-#pragma unroll
-                for (int n1 = 2; n1 < 16; ++n1) {
-                    p = cmul(p, wj);
-                    v1[n1] = cmul(v1[n1], p);
-                }
-                __syncthreads();  // the previous half-transform's pass-4 reads are done
-                lds_rows16c<FP_P1>(m0_x1, v1);
-            }
-            __syncthreads();
-            // ---- pass 2 ----
-            {
-                float2 v[16];
-                const uint32_t rd2 = fp_rd2((uint32_t)(tid + lz)), rd2i = fp_im(rd2);
-                const lds_tw_ptr t2 = tw_base(s_tw2, fp_cd2((uint32_t)(tid + lz)));
-#pragma unroll
-                for (int bh = 0; bh < 4; ++bh) lds_get4c(img, rd2 + 256u * bh, rd2i + 256u * bh, v[4 * bh], v[4 * bh + 1], v[4 * bh + 2], v[4 * bh + 3]);
-                idft16(v);
-#pragma unroll
-                for (int n2 = 1; n2 < 16; ++n2) v[n2] = cmul(v[n2], tw_ld(t2, 1024 * c + n2 * 64));
-                lds_rows16c_x2(m0_w, v);
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (c == 0) {
-                // inputs of the O half of this hypothesis: issued here, covered by pass 3 and pass 4
-#pragma unroll
-                for (int a = 0; a < 16; ++a) {
-                    xn[a] = ld2(xp, FB + 1024u * a + tid + lz);
-                    hn[a] = ld2(hrow_cur, FB + ((1024u * a + hb_cur) & (FB - 1)) + lz);
-                }
-            } else {
-                row_of(h + 1 < h1 ? h + 1 : h);  // (the loads of the next E half follow inside pass 4)
-            }
-            // ---- pass 3 ----
-            {
-                float2 v[16];
-                const uint32_t rd3 = fp_rd3((uint32_t)(tid + lz)), rd3i = fp_im(rd3);
-#pragma unroll
-                for (int ch = 0; ch < 4; ++ch) lds_get4c(img, rd3 + 64u * ch, rd3i + 64u * ch, v[4 * ch], v[4 * ch + 1], v[4 * ch + 2], v[4 * ch + 3]);
-                idft16(v);
-#pragma unroll
-                for (int n3 = 1; n3 < 16; ++n3) v[n3] = cmul(v[n3], tw_ld(tw_base(s_tw3, (uint32_t)((tid & 3) + lz)), 64 * c + n3 * 4));
-                lds_rows16c<256>(m0_w, v);
-            }
-            __syncthreads();
-            // ---- pass 4: DFT4 over d; the E half keeps its outputs, the O half combines and stores ----
-            const uint32_t rd4 = fp_rd4((uint32_t)tid), rd4i = fp_im(rd4);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                uint32_t lzi = 0;
-                asm volatile("" : "+v"(lzi));
-                float2 a0, a1, a2, a3;
-                lds_get4c(img, rd4 + 1024u * i + lzi, rd4i + 1024u * i + lzi, a0, a1, a2, a3);
-                idft4(a0, a1, a2, a3);
-                const float2 y[4] = {a0, a1, a2, a3};
-                if (c == 0) {
-#pragma unroll
-                    for (int n4 = 0; n4 < 4; ++n4) e[4 * i + n4] = y[n4];
-                } else {
-#pragma unroll
-                    for (int n4 = 0; n4 < 4; ++n4) {
-                        // O' = O * W_8^{n4} (the last factor of the combination twiddle)
-                        constexpr float R2 = 0.70710678118654752f;
-                        const float2 t = n4 == 0   ? y[0]
-                                         : n4 == 1 ? make_float2((y[1].x - y[1].y) * R2, (y[1].x + y[1].y) * R2)
-                                         : n4 == 2 ? mulj(y[2])
-                                                   : make_float2((-y[3].x - y[3].y) * R2, (y[3].x - y[3].y) * R2);
-                        const float2 ylo = cadd(e[4 * i + n4], t);
-                        const int tile_u = 16 * i + 64 * n4;
-                        const int tile_t = (n2o >> 2) + 4 * qo;
-                        const uint32_t soff = (uint32_t)tile_u * (uint32_t)nhyp * 256u + hoff;  // uniform (scalar) offset
-                        const uint32_t voff = ((uint32_t)tile_t * (uint32_t)nhyp * 64u + (uint32_t)(n1o + 16 * (n2o & 3))) << 2;
-                        const uint32_t voff_hi = voff + (((uint32_t)256 * (uint32_t)nhyp * 64u) << 2);  // n + 16384: tile + 256
-                        const float vlo = __builtin_fmaf(ylo.x, ylo.x, ylo.y * ylo.y);
-                        tile_store<MODE>(rvt, voff, soff, vlo);      // tiles >= tiles_per_blk: dropped by the range check
-                        if (n4 < NVH) {
-                            const float2 yhi = csub(e[4 * i + n4], t);
-                            tile_store<MODE>(rvt, voff_hi, soff, __builtin_fmaf(yhi.x, yhi.x, yhi.y * yhi.y));
-                        }
-                    }
-                    // four positions of the next E half's inputs, into the registers the combination just freed
-#pragma unroll
-                    for (int a = 4 * i; a < 4 * i + 4; ++a) {
-                        xn[a] = ld2(xp, 1024u * a + tid + lzi);
-                        hn[a] = ld2(hrow_cur, ((1024u * a + hb_cur) & (FB - 1)) + lzi);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    }
-}
-
-// ----------------------------------------------------------------------------------------
-// Templates of 16385 .. 32768 samples: 65536-point blocks as FOUR chained 16384-point transforms in the same LDS image.
-//   y[n] = sum_m P[m] W^{mn},  W = e^{+j 2 pi / 65536},  m = 4 m' + c:
-//   y[n' + 16384 q] = sum_c j^{cq} W^{c n'} Y_c[n'],   Y_c = IFFT_16384 of the samples m = c (mod 4)
-// The block spectra and the template-spectrum rows arrive RESIDUE-MAJOR ([c][16384] per row, each residue in butterfly order:
-// k_residue_major below), so a sub-transform reads exactly what fused_item reads, with the shift of an on-grid hypothesis
-// (a multiple of 4 here) divided by 4.  The combination twiddle W^{c n'}, n' = n1 + 16 n2 + 256 n3 + 4096 n4, is applied
-// digit by digit as in fused_item2: pass 1 through its recurrence base (4 m2 + c in 65536ths), passes 2 and 3 through the
-// even / odd twiddle tables (c = 0 / 2 exactly; c = 1 / 3: the same two tables times the constants e^{j 2 pi n2 / 4096},
-// e^{j 2 pi n3 / 256}), pass 4 as the constants W_16^{c n4}.
-// Registers decide the shape.  A thread owns sixteen positions n'; two pending output quarters would be 64 registers of
-// accumulators beside the 32 of a transform and the 64 of the next sub-transform's inputs in flight.  So an item
-// accumulates ONE quarter q (template parameter: acc += j^{cq} W^{c n'} Y_c, 32 registers -- the budget of fused_item2) and
-// the job runs every (block, hypothesis group) twice, q = 0 and q = 1: the block's step is 32768 delays whatever the
-// template length in (16384, 32768], i.e. 8 sub-transforms per 32768 delays -- the same cost per delay as the 32768-point
-// role has at N = 16384.  The next sub-transform's inputs are fetched at the start of pass 4 (acc + the four values of a
-// sub-step + 64 registers of loads in flight) and multiplied at the start of its pass 1.
-template <int MODE, int Q>
-__device__ __forceinline__ void fused_item4(float2* __restrict__ s_d, const float2* __restrict__ s_tw2,
-                                            const float2* __restrict__ s_tw3, const float2* __restrict__ xb,  // [blocks][4][16384], butterfly order
-                                            const float2* __restrict__ hc,       // [T][4][16384] or [T*F][4][16384]
-                                            const int32_t* __restrict__ shifts, const float2* __restrict__ tw1,
-                                            int32_t table_mode, int32_t nfreq, int32_t nhyp, int blk, int h0, int h1,
-                                            int32_t tiles_per_blk, float* __restrict__ vt) {
-    constexpr int FB4 = 4 * FB;
-    const int tid = threadIdx.x;
-    const lds_char* img = (const lds_char*)s_d;
-    const uint32_t img0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)img);
-    const uint32_t wave_u = __builtin_amdgcn_readfirstlane((uint32_t)tid >> 6);
-    const uint32_t m0_x1 = img0 + wave_u * 256u, m0_w = img0 + wave_u * (uint32_t)FP_P1;
-    const uint32_t m2 = fp_m2((uint32_t)tid);
-    const float2 w = ld2(tw1, 1024u + m2);  // pass-1 twiddle base e^{+j 2 pi m2 / 16384}
-    const float2* xp = xb + (int64_t)blk * FB4;
-    float* vt_blk = vt + (int64_t)blk * tiles_per_blk * nhyp * 64;
-    const __amdgpu_buffer_rsrc_t rvt = buf_of(uniform_ptr(vt_blk), (uint32_t)tiles_per_blk * (uint32_t)nhyp * 256u);
-    const int n1o = tid & 15, n2o = (tid >> 4) & 15, qo = tid >> 8;  // this thread's pass-4 position
-    const float2* hrow_cur;
-    uint32_t hb_cur;  // as in fused_item, with the shift in residue-major elements (= a quarter of the 65536-point shift)
-    auto row_of = [&](int h) {
-        if (table_mode) {
-            hrow_cur = hc + (int64_t)h * FB4;
-            hb_cur = (uint32_t)tid;
-        } else {
-            const int t = h / nfreq;
-            const int32_t sh = *((const CAF_AS1 int32_t*)shifts + (h - t * nfreq)) >> 2;
-            hrow_cur = hc + (int64_t)t * FB4;
-            hb_cur = fp_hbase(m2, sh);
-        }
-    };
-    float2 pr[16];  // X * Hc of the NEXT sub-transform: formed at the end of pass 4, so that only these 32 registers and the
-                    // 32 of the accumulators cross into its pass 1 (with the 64 of x and h alive there as well the register
-                    // allocator kept the accumulators in scratch -- 115 MB of it, i.e. in HBM: 56 ms instead of 40 at C2)
-    row_of(h0);
-#pragma unroll
-    for (int a = 0; a < 16; ++a) pr[a] = cmul(ld2(xp, 1024u * a + tid), ld2(hrow_cur, (1024u * a + hb_cur) & (FB - 1)));
-    float2 acc[16];  // register 4 i + n4 <-> n3 = q + 4 i, n4
-
-    for (int h = h0; h < h1; ++h) {
-        uint32_t hoff = (uint32_t)h * 256u;  // bytes
-        asm volatile("" : "+s"(hoff));
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            int lz = 0;
-            asm volatile("" : "+v"(lz));
-            // ---- pass 1: product, DFT16 over a, twiddle with the base e^{j 2 pi (4 m2 + c) / 65536}, write ----
-            {
-                float2 v1[16];
-#pragma unroll
-                for (int a = 0; a < 16; ++a) v1[a] = pr[a];
-                idft16(v1);
-                // e^{+j 2 pi c / 65536}, c = 1, 2, 3
-                float2 p = c == 0   ? w
-                           : c == 1 ? cmul(w, make_float2(0.99999999540410733f, 9.5873799095977345e-5f))
-                           : c == 2 ? cmul(w, make_float2(0.99999998161642933f, 1.9174759731070330e-4f))
-                                    : cmul(w, make_float2(0.99999995863696604f, 2.8762139372793800e-4f));
-                asm volatile("" : "+v"(p.x), "+v"(p.y));
-                const float2 wj = p;
-                v1[1] = cmul(v1[1], p);
-#pragma unroll
-                for (int n1 = 2; n1 < 16; ++n1) {
-                    p = cmul(p, wj);
-                    v1[n1] = cmul(v1[n1], p);
-                }
-                __syncthreads();  // the previous sub-transform's pass-4 reads are done
-                lds_rows16c<FP_P1>(m0_x1, v1);
-            }
-            __syncthreads();
-            // ---- pass 2: table A (c = 0, 1) or B (c = 2, 3); odd c: times e^{j 2 pi n2 / 4096} ----
-            {
-                float2 v[16];
-                const uint32_t rd2 = fp_rd2((uint32_t)(tid + lz)), rd2i = fp_im(rd2);
-                const lds_tw_ptr t2 = tw_base(s_tw2, fp_cd2((uint32_t)(tid + lz)));
-#pragma unroll
-                for (int bh = 0; bh < 4; ++bh) lds_get4c(img, rd2 + 256u * bh, rd2i + 256u * bh, v[4 * bh], v[4 * bh + 1], v[4 * bh + 2], v[4 * bh + 3]);
-                idft16(v);
-#pragma unroll
-                for (int n2 = 1; n2 < 16; ++n2) {
-                    float2 t = tw_ld(t2, 1024 * (c >> 1) + n2 * 64);
-                    if (c & 1) {
-                        // e^{+j 2 pi n2 / 4096}: cos / sin as compile-time constants
-                        const float cs = (float)__builtin_cos(6.283185307179586476925 * n2 / 4096.0);
-                        const float sn = (float)__builtin_sin(6.283185307179586476925 * n2 / 4096.0);
-                        t = cmul(t, make_float2(cs, sn));
-                    }
-                    v[n2] = cmul(v[n2], t);
-                }
-                lds_rows16c_x2(m0_w, v);
-            }
-            __builtin_amdgcn_wave_barrier();
-            // ---- pass 3: table A / B likewise; odd c: times e^{j 2 pi n3 / 256} ----
-            {
-                float2 v[16];
-                const uint32_t rd3 = fp_rd3((uint32_t)(tid + lz)), rd3i = fp_im(rd3);
-#pragma unroll
-                for (int ch = 0; ch < 4; ++ch) lds_get4c(img, rd3 + 64u * ch, rd3i + 64u * ch, v[4 * ch], v[4 * ch + 1], v[4 * ch + 2], v[4 * ch + 3]);
-                idft16(v);
-#pragma unroll
-                for (int n3 = 1; n3 < 16; ++n3) {
-                    float2 t = tw_ld(tw_base(s_tw3, (uint32_t)((tid & 3) + lz)), 64 * (c >> 1) + n3 * 4);
-                    if (c & 1) {
-                        const float cs = (float)__builtin_cos(6.283185307179586476925 * n3 / 256.0);
-                        const float sn = (float)__builtin_sin(6.283185307179586476925 * n3 / 256.0);
-                        t = cmul(t, make_float2(cs, sn));
-                    }
-                    v[n3] = cmul(v[n3], t);
-                }
-                lds_rows16c<256>(m0_w, v);
-            }
-            __syncthreads();
-            // ---- pass 4: DFT4 over d and the accumulation; the next sub-transform's inputs go out at its end ----
-            if (c == 3) row_of(h + 1 < h1 ? h + 1 : h);
-            const int cn = (c + 1) & 3;
-            const uint32_t rd4 = fp_rd4((uint32_t)tid), rd4i = fp_im(rd4);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                uint32_t lzi = 0;
-                asm volatile("" : "+v"(lzi));
-                float2 a0, a1, a2, a3;
-                lds_get4c(img, rd4 + 1024u * i + lzi, rd4i + 1024u * i + lzi, a0, a1, a2, a3);
-                idft4(a0, a1, a2, a3);
-                const float2 y[4] = {a0, a1, a2, a3};
-#pragma unroll
-                for (int n4 = 0; n4 < 4; ++n4) {
-                    // z = y * e^{j 2 pi c (n4 + 4 Q) / 16}: the last factor of the combination twiddle and j^{cQ} in one constant
-                    constexpr double TWO_PI = 6.283185307179586476925;
-                    const int e16 = (c * (n4 + 4 * Q)) & 15;
-                    float2 z;
-                    if (e16 == 0) z = y[n4];
-                    else if (e16 == 4) z = mulj(y[n4]);
-                    else if (e16 == 8) z = make_float2(-y[n4].x, -y[n4].y);
-                    else if (e16 == 12) z = make_float2(y[n4].y, -y[n4].x);
-                    else z = cmul(y[n4], make_float2((float)__builtin_cos(TWO_PI * e16 / 16.0), (float)__builtin_sin(TWO_PI * e16 / 16.0)));
-                    if (c == 0)
-                        acc[4 * i + n4] = z;
-                    else
-                        acc[4 * i + n4] = cadd(acc[4 * i + n4], z);
-                    // (pinned: left to itself the compiler defers these additions to the last sub-transform, carries z_0, z_1
-                    //  and z_2 separately -- 96 registers -- and keeps them in scratch: 115 MB of it, i.e. in HBM; 56 ms
-                    //  instead of 40 at the C2 shape)
-                    if (c < 3) asm volatile("" : "+v"(acc[4 * i + n4].x), "+v"(acc[4 * i + n4].y));
-                    if (c == 3) {
-                        const int tile_u = 16 * i + 64 * n4 + 256 * Q;
-                        const int tile_t = (n2o >> 2) + 4 * qo;
-                        const uint32_t soff = (uint32_t)tile_u * (uint32_t)nhyp * 256u + hoff;  // uniform (scalar) offset
-                        const uint32_t voff = ((uint32_t)tile_t * (uint32_t)nhyp * 64u + (uint32_t)(n1o + 16 * (n2o & 3))) << 2;
-                        const float2 yy = acc[4 * i + n4];
-                        tile_store<MODE>(rvt, voff, soff, __builtin_fmaf(yy.x, yy.x, yy.y * yy.y));
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            // the next sub-transform's inputs, fetched when the sub-steps' temporaries are gone, and multiplied here
-            {
-                // (fetched at the START of pass 4 instead -- 64 more registers under the sub-steps -- : 45.4 against 44.8 ms)
-                float2 xn[16], hn[16];
-#pragma unroll
-                for (int a = 0; a < 16; ++a) {
-                    xn[a] = ld2(xp, FB * cn + 1024u * a + tid + lz);
-                    hn[a] = ld2(hrow_cur, FB * cn + ((1024u * a + hb_cur) & (FB - 1)) + lz);
-                }
-                // (one product at a time, in the order the loads return: each frees four registers and takes two)
-#pragma unroll
-                for (int a = 0; a < 16; ++a) {
-                    pr[a] = cmul(xn[a], hn[a]);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        }
-    }
-}
-
-// ----------------------------------------------------------------------------------------
-// Templates of 16385 .. 32768 samples, the FOLDED form: 65536-point blocks whose first 32768 outputs are the only valid delays
+// E's sixteen outputs per thread wait in registers while O runs through the same four passes; both transforms leave a
+// thread the same sixteen positions n' = n1 + 16 n2 + 256 n3 + 4096 n4, so the radix-2 combination is register-local and
+// nothing but |y|^2 leaves the CU.  The combination twiddle W^{n'} is a product of one factor per output digit, and each
+// pass of the O half applies the factor of the digit it produces: pass 1 through its recurrence base (2 m2 + 1 instead
+// of 2 m2 in 32768ths), passes 2 and 3 through the second halves of the twiddle tables, pass 4 as the constants W_8^{n4}.
+// Tiles: n -> tile n >> 6 (up to 384 tiles for N = 8193), write-through stores (MODE 1) or plain (0).
+// NVH: quarters n4 < NVH of the UPPER half y[n' + 16384] hold valid delays (N = 16384: none -- the block's valid delays
+// are exactly the lower half; N = 8193: two); the others are not combined, squared or stored.
+//
+// FOLD = false, templates of 8193 .. 16384 samples (32768-point blocks): the block spectra and the template-spectrum
+// rows arrive PARITY-MAJOR ([c][16384] per row, each half in butterfly order: k_block_spectra32 / k_parity_major), so a
+// half-transform reads what fused_item reads for a 16384-point block, with the (even) shift of an on-grid hypothesis
+// halved.  A point = an 8-byte load of X and one of Hc (4 registers in flight), their product 2.
+//
+// FOLD = true, templates of 16385 .. 32768 samples: 65536-point blocks whose first 32768 outputs are the only valid delays
 // (step 32768), split by the PARITY OF THE OUTPUT,
 //   y[2 k + r] = sum_{m < 32768} G_r[m] W_32768^{m k},   G_r[m] = (Z[m] + (-1)^r Z[m + 32768]) W_65536^{m r},   Z = X . Hc
 // -- one decimation-in-frequency step on the products -- and each residue r is a 32768-point transform of which only the
-// lower half k < 16384 is wanted: fused_item2 with NVH = 0, i.e. TWO chained 16384-point transforms per residue, FOUR per
-// block and hypothesis where fused_item4 (one output quarter from all four spectral residues, twice) ran eight.
+// lower half k < 16384 is wanted (NVH = 0): two chained 16384-point transforms per residue, FOUR per block and hypothesis.
+// (Round 4's first form accumulated one output QUARTER from the four spectral residues m mod 4 and ran every block twice:
+// eight sub-transforms for the same 32768 delays, 43 ms at the C2 shape against 24 for this one.)
 // G_r[2 m' + c] needs P_c[m'] and P_c[m' + 16384] (P_c = the samples of parity c) of the block spectrum and of the template
 // row: both arrive as PAIRS, [c][16384] x (P_c[m'], P_c[m' + 16384]) with every 1024-chunk of m' in butterfly order
-// (k_parity_pairs), so a point is two 16-byte loads -- the same bytes per hypothesis as fused_item4 reads (4 x 32 loads of 16
-// bytes per thread against 8 x 32 of 8).  A hypothesis shift s (in parity-major elements, mod 32768) moves the template
-// pair to (m' - s) mod 16384 and swaps its halves where bit 14 of (m' - s) mod 32768 is set.
-// Input twiddle (r = 1): W_65536^{2 m' + c} with m' = 1024 a + m2 is a per-thread base e^{j 2 pi (2 m2 + c) / 65536} -- common
-// to the sixteen inputs of the thread's pass-1 butterfly, so it moves behind the butterfly into the start of the pass-1
-// recurrence -- times the compile-time constants W_32^a, applied as the products are folded.
-// Registers decide the schedule.  A point in flight is 8 registers, folded 2.  The E half of a hypothesis has room (its
-// transform's 32 registers + addresses), the O half does not (E's 32 outputs wait beside the transform), so the 32 points
-// a thread needs per hypothesis -- the O half's 16, then the next E half's 16 -- are fetched in the quotas 8 / 6 / 6 / 2 over the
-// four passes of the E half and 4 / 2 / 2 / 2 over those of the O half, each batch issued at the start of its pass and folded
-// at its end.
+// (k_parity_pairs), so a point is two 16-byte loads (8 registers in flight, folded 2).  A hypothesis shift s (in
+// parity-major elements, mod 32768) moves the template pair to (m' - s) mod 16384 and swaps its halves where bit 14 of
+// (m' - s) mod 32768 is set.  Input twiddle (r = 1): W_65536^{2 m' + c} with m' = 1024 a + m2 is a per-thread base
+// e^{j 2 pi (2 m2 + c) / 65536} -- common to the sixteen inputs of the thread's pass-1 butterfly, so it moves behind the
+// butterfly into the start of the pass-1 recurrence -- times the compile-time constants W_32^a, applied at the fold.
 // Work item = (block, hypothesis group, r): the host doubles ngroups, group = 2 * (hypothesis group) + r.  Tiles: [r][256]
 // per block, tile 256 r + (k >> 6), column k & 63 <-> delay 2 k + r: the tile roles run with a delay stride of 2 (DS).
-template <int MODE, int R>
-__device__ __forceinline__ void fused_item2f(float2* __restrict__ s_d, const float2* __restrict__ s_tw2,
-                                             const float2* __restrict__ s_tw3, const float2* __restrict__ xb,  // [blocks][2][16384] pairs, butterfly order
-                                             const float2* __restrict__ hc,       // [T][2][16384] pairs or [T*F][2][16384] pairs
+//
+// Registers (128) decide the schedule of the loads.  Neither the block spectrum nor a template row can stay resident, so
+// every sub-transform's inputs are fetched while the one before it runs.  The E half of a hypothesis has room (its
+// transform's 32 registers + addresses), the O half does not (E's 32 outputs wait beside the transform), so the 32 points
+// a thread needs per hypothesis -- the O half's 16, then the next E half's 16 -- are fetched in quotas over the eight passes:
+// each batch is issued at the start of its pass and multiplied / folded at its end, and nothing is in flight across a
+// hypothesis boundary.  (Round 3's schedule -- O's inputs in one batch before pass 3 of E, the next E's inside pass 4 of O --
+// left the second batch half a pass to arrive: N = 16384 at the C2 shape 22.2 -> 20.3 ms with the quotas.)
+template <int N_> struct caf_ic { static constexpr int value = N_; };
+template <int MODE, int NVH, bool FOLD, int R>
+__device__ __forceinline__ void fused_item2q(float2* __restrict__ s_d, const float2* __restrict__ s_tw2,
+                                             const float2* __restrict__ s_tw3, const float2* __restrict__ xb,  // FOLD: [blocks][2][16384] pairs; else [blocks][2][16384]
+                                             const float2* __restrict__ hc,       // rows of the same shape, per template or per hypothesis
                                              const int32_t* __restrict__ shifts, const float2* __restrict__ tw1,
                                              int32_t table_mode, int32_t nfreq, int32_t nhyp, int blk, int h0, int h1,
                                              int32_t tiles_per_blk, float* __restrict__ vt) {
-    constexpr int FB4 = 4 * FB;
+    static_assert(FOLD || R == 0, "the output residue exists in the folded form only");
+    static_assert(!FOLD || NVH == 0, "folded form: only the lower half of each residue's transform holds valid delays");
+    constexpr int ROW = FOLD ? 4 * FB : 2 * FB;  // float2 per row (block spectrum, template row)
+    using pt_t = typename std::conditional<FOLD, float4, float2>::type;
     const int tid = threadIdx.x;
     const lds_char* img = (const lds_char*)s_d;
     const uint32_t img0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)img);
@@ -1000,206 +663,231 @@ __device__ __forceinline__ void fused_item2f(float2* __restrict__ s_d, const flo
         sincospif((float)m2 * (1.0f / 16384.0f), &sn, &cs);
         base0 = make_float2(cs, sn);
     }
-    const float* xp = (const float*)(xb + (int64_t)blk * FB4);
+    const float* xp = (const float*)(xb + (int64_t)blk * ROW);
     float* vt_blk = vt + (int64_t)blk * tiles_per_blk * nhyp * 64;
     const __amdgpu_buffer_rsrc_t rvt = buf_of(uniform_ptr(vt_blk), (uint32_t)tiles_per_blk * (uint32_t)nhyp * 256u);
     const int n1o = tid & 15, n2o = (tid >> 4) & 15, qo = tid >> 8;  // this thread's pass-4 position
     // template row of a hypothesis and this thread's base index into it: the shift in parity-major elements (= half the
-    // 65536-point shift) mod 32768; bits 0..13 of 1024 a + hb select the pair, bit 14 swaps its halves
+    // block's shift); FOLD: mod 32768 -- bits 0..13 of 1024 a + hb select the pair, bit 14 swaps its halves
     const float* hrow_o;  // the row of the hypothesis in progress (its O half's inputs)
     uint32_t hb_o;
     const float* hrow_n;  // the next hypothesis' row (its E half's inputs)
     uint32_t hb_n;
     auto row_of = [&](int h, const float*& hrow, uint32_t& hb) {
         if (table_mode) {
-            hrow = (const float*)(hc + (int64_t)h * FB4);
+            hrow = (const float*)(hc + (int64_t)h * ROW);
             hb = (uint32_t)tid;
         } else {
             const int t = h / nfreq;
             const int32_t sh = *((const CAF_AS1 int32_t*)shifts + (h - t * nfreq)) >> 1;
-            hrow = (const float*)(hc + (int64_t)t * FB4);
+            hrow = (const float*)(hc + (int64_t)t * ROW);
             hb = fp_hbase(m2, sh);
         }
     };
-    // a batch: NP points a = A0 .. A0 + NP - 1 of parity CC, from row HROW / base HB, into the buffers BX / BH
-#define CAF_F2F_ISSUE(BX, BH, HROW, HB, CC, A0, NP, LZ)                                               \
-    _Pragma("unroll") for (int k_ = 0; k_ < (NP); ++k_) {                                             \
-        const uint32_t a_ = (uint32_t)((A0) + k_);                                                    \
-        const uint32_t hi_ = (1024u * a_ + (HB)) & 16383u;                                            \
-        BX[k_] = gld4(xp, ((uint32_t)(CC) * 16384u + 1024u * a_ + (uint32_t)tid + (LZ)) << 4);       \
-        BH[k_] = gld4((HROW), ((uint32_t)(CC) * 16384u + hi_ + (LZ)) << 4);                           \
-    }
-    // ... folded into PR[A0 ..]: G = (X1 H1 + X2 H2) or (X1 H1 - X2 H2) W_32^a
-#define CAF_F2F_FOLD(PR, BX, BH, HB, A0, NP)                                                                   \
-    _Pragma("unroll") for (int k_ = 0; k_ < (NP); ++k_) {                                                      \
-        constexpr double TWO_PI_ = 6.283185307179586476925;                                                    \
-        const int a_ = (A0) + k_;                                                                              \
-        const bool sw_ = ((1024u * (uint32_t)a_ + (HB)) & 16384u) != 0;                                        \
-        const float2 h1_ = make_float2(sw_ ? BH[k_].z : BH[k_].x, sw_ ? BH[k_].w : BH[k_].y);                 \
-        const float2 h2_ = make_float2(sw_ ? BH[k_].x : BH[k_].z, sw_ ? BH[k_].y : BH[k_].w);                 \
-        const float2 z1_ = cmul(make_float2(BX[k_].x, BX[k_].y), h1_);                                         \
-        const float2 z2_ = cmul(make_float2(BX[k_].z, BX[k_].w), h2_);                                         \
-        if (R == 0)                                                                                            \
-            PR[a_] = cadd(z1_, z2_);                                                                           \
-        else if (a_ == 0)                                                                                      \
-            PR[a_] = csub(z1_, z2_);                                                                           \
-        else if (a_ == 8)                                                                                      \
-            PR[a_] = mulj(csub(z1_, z2_));                                                                     \
-        else                                                                                                   \
-            PR[a_] = cmul(csub(z1_, z2_), make_float2((float)__builtin_cos(TWO_PI_ * a_ / 32.0),               \
-                                                      (float)__builtin_sin(TWO_PI_ * a_ / 32.0)));             \
-    }
+    // a batch: NP points a = A0 .. A0 + NP - 1 of parity CC, from row hrow / base hb, into bx / bh (lz: an opaque zero that
+    // pins the loads behind their point of issue)
+    auto issue = [&](pt_t* bx, pt_t* bh, const float* hrow, uint32_t hb, auto cc_, auto a0_, auto np_, uint32_t lz) __attribute__((always_inline)) {
+        constexpr int CC = decltype(cc_)::value, A0 = decltype(a0_)::value, NP = decltype(np_)::value;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const uint32_t a = (uint32_t)(A0 + k);
+            const uint32_t hi = (1024u * a + hb) & 16383u;
+            if constexpr (FOLD) {
+                bx[k] = gld4(xp, ((uint32_t)CC * 16384u + 1024u * a + (uint32_t)tid + lz) << 4);
+                bh[k] = gld4(hrow, ((uint32_t)CC * 16384u + hi + lz) << 4);
+            } else {
+                bx[k] = ld2((const float2*)xp, (uint32_t)CC * 16384u + 1024u * a + (uint32_t)tid + lz);
+                bh[k] = ld2((const float2*)hrow, (uint32_t)CC * 16384u + hi + lz);
+            }
+        }
+    };
+    // ... folded into pr[A0 ..]: FOLD: G = (X1 H1 + X2 H2) or (X1 H1 - X2 H2) W_32^a; else X H
+    auto fold = [&](float2* pr, const pt_t* bx, const pt_t* bh, uint32_t hb, auto a0_, auto np_) __attribute__((always_inline)) {
+        constexpr int A0 = decltype(a0_)::value, NP = decltype(np_)::value;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int a = A0 + k;
+            if constexpr (FOLD) {
+                constexpr double TWO_PI = 6.283185307179586476925;
+                const bool sw = ((1024u * (uint32_t)a + hb) & 16384u) != 0;
+                const float2 h1 = make_float2(sw ? bh[k].z : bh[k].x, sw ? bh[k].w : bh[k].y);
+                const float2 h2 = make_float2(sw ? bh[k].x : bh[k].z, sw ? bh[k].y : bh[k].w);
+                const float2 z1 = cmul(make_float2(bx[k].x, bx[k].y), h1);
+                const float2 z2 = cmul(make_float2(bx[k].z, bx[k].w), h2);
+                if (R == 0)
+                    pr[a] = cadd(z1, z2);
+                else if (a == 0)
+                    pr[a] = csub(z1, z2);
+                else if (a == 8)
+                    pr[a] = mulj(csub(z1, z2));
+                else
+                    pr[a] = cmul(csub(z1, z2), make_float2((float)__builtin_cos(TWO_PI * a / 32.0), (float)__builtin_sin(TWO_PI * a / 32.0)));
+            } else {
+                pr[a] = cmul(bx[k], bh[k]);
+            }
+        }
+    };
+    // points fetched per pass: in the E half first the O half's (QEO), then the next E half's (QEN); in the O half QON
+    // (measured at the C2 shape, profiles/r04/ab_quota_schedules.log: fetching earlier -- 16 points in the first pass -- or
+    //  later -- batches in the O half's last pass -- is slower in both forms)
+    constexpr int QEO[4] = {8, FOLD ? 6 : 8, FOLD ? 2 : 0, 0};
+    constexpr int QEN[4] = {0, 0, FOLD ? 4 : 6, FOLD ? 4 : 2};
+    constexpr int QON[4] = {4, 2, 2, 0};
+    static_assert(QEO[0] + QEO[1] + QEO[2] + QEO[3] == 16 && QEN[0] + QEN[1] + QEN[2] + QEN[3] + QON[0] + QON[1] + QON[2] + QON[3] == 16, "quotas");
     float2 pro[16], prn[16];  // folded inputs: of the O half of the hypothesis in progress / of the next E half
     row_of(h0, hrow_o, hb_o);
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        float4 bx[8], bh[8];
-        CAF_F2F_ISSUE(bx, bh, hrow_o, hb_o, 0, 8 * b, 8, 0u)
-        CAF_F2F_FOLD(prn, bx, bh, hb_o, 8 * b, 8)
+    {
+        pt_t bx[8], bh[8];
+        issue(bx, bh, hrow_o, hb_o, caf_ic<0>{}, caf_ic<0>{}, caf_ic<8>{}, 0u);
+        fold(prn, bx, bh, hb_o, caf_ic<0>{}, caf_ic<8>{});
+        issue(bx, bh, hrow_o, hb_o, caf_ic<0>{}, caf_ic<8>{}, caf_ic<8>{}, 0u);
+        fold(prn, bx, bh, hb_o, caf_ic<8>{}, caf_ic<8>{});
     }
     float2 e[16];  // E's outputs (register 4 i + n4 <-> n3 = q + 4 i, n4)
+    uint32_t hoff = 0;
 
-    for (int h = h0; h < h1; ++h) {
-        uint32_t hoff = (uint32_t)h * 256u;  // bytes
-        asm volatile("" : "+s"(hoff));
-        row_of(h + 1 < h1 ? h + 1 : h, hrow_n, hb_n);
+    // one sub-transform: c = 0 the E half (even samples), 1 the O half; PS = pass number for the quota tables
+    auto batch_issue = [&](pt_t* bx, pt_t* bh, auto c_, auto ps_, uint32_t lz) __attribute__((always_inline)) {
+        constexpr int c = decltype(c_)::value, PS = decltype(ps_)::value;
+        if constexpr (c == 0) {
+            constexpr int O0 = (PS > 0 ? QEO[0] : 0) + (PS > 1 ? QEO[1] : 0) + (PS > 2 ? QEO[2] : 0);
+            constexpr int N0 = (PS > 0 ? QEN[0] : 0) + (PS > 1 ? QEN[1] : 0) + (PS > 2 ? QEN[2] : 0);
+            issue(bx, bh, hrow_o, hb_o, caf_ic<1>{}, caf_ic<O0>{}, caf_ic<QEO[PS]>{}, lz);
+            issue(bx + QEO[PS], bh + QEO[PS], hrow_n, hb_n, caf_ic<0>{}, caf_ic<N0>{}, caf_ic<QEN[PS]>{}, lz);
+        } else {
+            constexpr int N0 = QEN[0] + QEN[1] + QEN[2] + QEN[3] + (PS > 0 ? QON[0] : 0) + (PS > 1 ? QON[1] : 0) + (PS > 2 ? QON[2] : 0);
+            issue(bx, bh, hrow_n, hb_n, caf_ic<0>{}, caf_ic<N0>{}, caf_ic<QON[PS]>{}, lz);
+        }
+    };
+    auto batch_fold = [&](const pt_t* bx, const pt_t* bh, auto c_, auto ps_) __attribute__((always_inline)) {
+        constexpr int c = decltype(c_)::value, PS = decltype(ps_)::value;
+        if constexpr (c == 0) {
+            constexpr int O0 = (PS > 0 ? QEO[0] : 0) + (PS > 1 ? QEO[1] : 0) + (PS > 2 ? QEO[2] : 0);
+            constexpr int N0 = (PS > 0 ? QEN[0] : 0) + (PS > 1 ? QEN[1] : 0) + (PS > 2 ? QEN[2] : 0);
+            fold(pro, bx, bh, hb_o, caf_ic<O0>{}, caf_ic<QEO[PS]>{});
+            fold(prn, bx + QEO[PS], bh + QEO[PS], hb_n, caf_ic<N0>{}, caf_ic<QEN[PS]>{});
+        } else {
+            constexpr int N0 = QEN[0] + QEN[1] + QEN[2] + QEN[3] + (PS > 0 ? QON[0] : 0) + (PS > 1 ? QON[1] : 0) + (PS > 2 ? QON[2] : 0);
+            fold(prn, bx, bh, hb_n, caf_ic<N0>{}, caf_ic<QON[PS]>{});
+        }
+    };
+    auto sub = [&](auto c_) __attribute__((always_inline)) {
+        constexpr int c = decltype(c_)::value;
+        uint32_t lz = 0;
+        asm volatile("" : "+v"(lz));
+        // ---- pass 1: DFT16 over a of the (folded) products, twiddle (r = 1: the recurrence starts at the input base), write ----
+        {
+            float2 v1[16];
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            uint32_t lz = 0;
-            asm volatile("" : "+v"(lz));
-            // ---- pass 1: DFT16 over a of the folded products, twiddle (r = 1: the recurrence starts at the input base), write ----
-            {
-                float2 v1[16];
-#pragma unroll
-                for (int a = 0; a < 16; ++a) v1[a] = c == 0 ? prn[a] : pro[a];
-                float4 bx[8], bh[8];
-                if (c == 0) {
-                    CAF_F2F_ISSUE(bx, bh, hrow_o, hb_o, 1, 0, 8, lz)
-                } else {
-                    CAF_F2F_ISSUE(bx, bh, hrow_n, hb_n, 0, 6, 4, lz)
-                }
-                idft16(v1);
-                // e^{+j 2 pi / 32768} on the odd half: the combination twiddle's n1 digit (fused_item2)
-                float2 wj = c == 0 ? w : cmul(w, make_float2(0.99999998161642933f, 1.9174759731070330e-4f));
-                asm volatile("" : "+v"(wj.x), "+v"(wj.y));
-                float2 p;
-                if (R) {
-                    p = c == 0 ? base0 : cmul(base0, make_float2(0.99999999540410733f, 9.5873799095977345e-5f));  // * e^{+j 2 pi / 65536}
-                    v1[0] = cmul(v1[0], p);
-                    p = cmul(p, wj);
-                } else {
-                    p = wj;
-                }
-                v1[1] = cmul(v1[1], p);
-#pragma unroll
-                for (int n1 = 2; n1 < 16; ++n1) {
-                    p = cmul(p, wj);
-                    v1[n1] = cmul(v1[n1], p);
-                }
-                __syncthreads();  // the previous sub-transform's pass-4 reads are done
-                lds_rows16c<FP_P1>(m0_x1, v1);
-                if (c == 0) {
-                    CAF_F2F_FOLD(pro, bx, bh, hb_o, 0, 8)
-                } else {
-                    CAF_F2F_FOLD(prn, bx, bh, hb_n, 6, 4)
-                }
+            for (int a = 0; a < 16; ++a) v1[a] = c == 0 ? prn[a] : pro[a];
+            pt_t bx[8], bh[8];
+            batch_issue(bx, bh, c_, caf_ic<0>{}, lz);
+            idft16(v1);
+            // e^{+j 2 pi / 32768} on the odd half: the n1 digit of the combination twiddle (fused_item2)
+            float2 wj = c == 0 ? w : cmul(w, make_float2(0.99999998161642933f, 1.9174759731070330e-4f));
+            asm volatile("" : "+v"(wj.x), "+v"(wj.y));
+            float2 p;
+            if (R) {
+                p = c == 0 ? base0 : cmul(base0, make_float2(0.99999999540410733f, 9.5873799095977345e-5f));  // * e^{+j 2 pi / 65536}
+                v1[0] = cmul(v1[0], p);
+                p = cmul(p, wj);
+            } else {
+                p = wj;
             }
-            __syncthreads();
-            // ---- pass 2 ----
-            {
-                float2 v[16];
-                const uint32_t rd2 = fp_rd2((uint32_t)(tid + lz)), rd2i = fp_im(rd2);
-                const lds_tw_ptr t2 = tw_base(s_tw2, fp_cd2((uint32_t)(tid + lz)));
-                float4 bx[6], bh[6];
-                if (c == 0) {
-                    CAF_F2F_ISSUE(bx, bh, hrow_o, hb_o, 1, 8, 6, lz)
-                } else {
-                    CAF_F2F_ISSUE(bx, bh, hrow_n, hb_n, 0, 10, 2, lz)
-                }
+            v1[1] = cmul(v1[1], p);
 #pragma unroll
-                for (int bh_ = 0; bh_ < 4; ++bh_) lds_get4c(img, rd2 + 256u * bh_, rd2i + 256u * bh_, v[4 * bh_], v[4 * bh_ + 1], v[4 * bh_ + 2], v[4 * bh_ + 3]);
-                idft16(v);
-#pragma unroll
-                for (int n2 = 1; n2 < 16; ++n2) v[n2] = cmul(v[n2], tw_ld(t2, 1024 * c + n2 * 64));
-                lds_rows16c_x2(m0_w, v);
-                if (c == 0) {
-                    CAF_F2F_FOLD(pro, bx, bh, hb_o, 8, 6)
-                } else {
-                    CAF_F2F_FOLD(prn, bx, bh, hb_n, 10, 2)
-                }
+            for (int n1 = 2; n1 < 16; ++n1) {
+                p = cmul(p, wj);
+                v1[n1] = cmul(v1[n1], p);
             }
-            __builtin_amdgcn_wave_barrier();
-            // ---- pass 3 ----
-            {
-                float2 v[16];
-                const uint32_t rd3 = fp_rd3((uint32_t)(tid + lz)), rd3i = fp_im(rd3);
-                float4 bx[6], bh[6];
-                if (c == 0) {
-                    CAF_F2F_ISSUE(bx, bh, hrow_o, hb_o, 1, 14, 2, lz)
-                    float4* bxn = bx + 2;
-                    float4* bhn = bh + 2;
-                    CAF_F2F_ISSUE(bxn, bhn, hrow_n, hb_n, 0, 0, 4, lz)
-                } else {
-                    CAF_F2F_ISSUE(bx, bh, hrow_n, hb_n, 0, 12, 2, lz)
-                }
+            __syncthreads();  // the previous sub-transform's pass-4 reads are done
+            lds_rows16c<FP_P1>(m0_x1, v1);
+            batch_fold(bx, bh, c_, caf_ic<0>{});
+        }
+        __syncthreads();
+        // ---- pass 2 ----
+        {
+            float2 v[16];
+            const uint32_t rd2 = fp_rd2((uint32_t)(tid + lz)), rd2i = fp_im(rd2);
+            const lds_tw_ptr t2 = tw_base(s_tw2, fp_cd2((uint32_t)(tid + lz)));
+            pt_t bx[8], bh[8];
+            batch_issue(bx, bh, c_, caf_ic<1>{}, lz);
 #pragma unroll
-                for (int ch = 0; ch < 4; ++ch) lds_get4c(img, rd3 + 64u * ch, rd3i + 64u * ch, v[4 * ch], v[4 * ch + 1], v[4 * ch + 2], v[4 * ch + 3]);
-                idft16(v);
+            for (int q4 = 0; q4 < 4; ++q4) lds_get4c(img, rd2 + 256u * q4, rd2i + 256u * q4, v[4 * q4], v[4 * q4 + 1], v[4 * q4 + 2], v[4 * q4 + 3]);
+            idft16(v);
 #pragma unroll
-                for (int n3 = 1; n3 < 16; ++n3) v[n3] = cmul(v[n3], tw_ld(tw_base(s_tw3, (uint32_t)((tid & 3) + lz)), 64 * c + n3 * 4));
-                lds_rows16c<256>(m0_w, v);
-                if (c == 0) {
-                    CAF_F2F_FOLD(pro, bx, bh, hb_o, 14, 2)
-                    float4* bxn = bx + 2;
-                    float4* bhn = bh + 2;
-                    CAF_F2F_FOLD(prn, bxn, bhn, hb_n, 0, 4)
-                } else {
-                    CAF_F2F_FOLD(prn, bx, bh, hb_n, 12, 2)
-                }
-            }
-            __syncthreads();
-            // ---- pass 4: DFT4 over d; the E half keeps its outputs, the O half combines and stores the lower half ----
-            const uint32_t rd4 = fp_rd4((uint32_t)tid), rd4i = fp_im(rd4);
-            float4 bx4[2], bh4[2];
-            CAF_F2F_ISSUE(bx4, bh4, hrow_n, hb_n, 0, (c == 0 ? 4 : 14), 2, lz)
-            __builtin_amdgcn_sched_barrier(0);
+            for (int n2 = 1; n2 < 16; ++n2) v[n2] = cmul(v[n2], tw_ld(t2, 1024 * c + n2 * 64));
+            lds_rows16c_x2(m0_w, v);
+            batch_fold(bx, bh, c_, caf_ic<1>{});
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- pass 3 ----
+        {
+            float2 v[16];
+            const uint32_t rd3 = fp_rd3((uint32_t)(tid + lz)), rd3i = fp_im(rd3);
+            pt_t bx[8], bh[8];
+            batch_issue(bx, bh, c_, caf_ic<2>{}, lz);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                uint32_t lzi = 0;
-                asm volatile("" : "+v"(lzi));
-                float2 a0, a1, a2, a3;
-                lds_get4c(img, rd4 + 1024u * i + lzi, rd4i + 1024u * i + lzi, a0, a1, a2, a3);
-                idft4(a0, a1, a2, a3);
-                const float2 y[4] = {a0, a1, a2, a3};
-                if (c == 0) {
+            for (int ch = 0; ch < 4; ++ch) lds_get4c(img, rd3 + 64u * ch, rd3i + 64u * ch, v[4 * ch], v[4 * ch + 1], v[4 * ch + 2], v[4 * ch + 3]);
+            idft16(v);
 #pragma unroll
-                    for (int n4 = 0; n4 < 4; ++n4) e[4 * i + n4] = y[n4];
-                } else {
+            for (int n3 = 1; n3 < 16; ++n3) v[n3] = cmul(v[n3], tw_ld(tw_base(s_tw3, (uint32_t)((tid & 3) + lz)), 64 * c + n3 * 4));
+            lds_rows16c<256>(m0_w, v);
+            batch_fold(bx, bh, c_, caf_ic<2>{});
+        }
+        __syncthreads();
+        // ---- pass 4: DFT4 over d; the E half keeps its outputs, the O half combines and stores ----
+        const uint32_t rd4 = fp_rd4((uint32_t)tid), rd4i = fp_im(rd4);
+        pt_t bx4[8], bh4[8];
+        batch_issue(bx4, bh4, c_, caf_ic<3>{}, lz);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int n4 = 0; n4 < 4; ++n4) {
-                        // O' = O * W_8^{n4} (the last factor of the combination twiddle of the 32768-point transform)
-                        constexpr float R2 = 0.70710678118654752f;
-                        const float2 t = n4 == 0   ? y[0]
-                                         : n4 == 1 ? make_float2((y[1].x - y[1].y) * R2, (y[1].x + y[1].y) * R2)
-                                         : n4 == 2 ? mulj(y[2])
-                                                   : make_float2((-y[3].x - y[3].y) * R2, (y[3].x - y[3].y) * R2);
-                        const float2 ylo = cadd(e[4 * i + n4], t);
-                        const int tile_u = 16 * i + 64 * n4 + 256 * R;
-                        const int tile_t = (n2o >> 2) + 4 * qo;
-                        const uint32_t soff = (uint32_t)tile_u * (uint32_t)nhyp * 256u + hoff;  // uniform (scalar) offset
-                        const uint32_t voff = ((uint32_t)tile_t * (uint32_t)nhyp * 64u + (uint32_t)(n1o + 16 * (n2o & 3))) << 2;
-                        tile_store<MODE>(rvt, voff, soff, __builtin_fmaf(ylo.x, ylo.x, ylo.y * ylo.y));
+        for (int i = 0; i < 4; ++i) {
+            uint32_t lzi = 0;
+            asm volatile("" : "+v"(lzi));
+            float2 a0, a1, a2, a3;
+            lds_get4c(img, rd4 + 1024u * i + lzi, rd4i + 1024u * i + lzi, a0, a1, a2, a3);
+            idft4(a0, a1, a2, a3);
+            const float2 y[4] = {a0, a1, a2, a3};
+            if (c == 0) {
+#pragma unroll
+                for (int n4 = 0; n4 < 4; ++n4) e[4 * i + n4] = y[n4];
+            } else {
+#pragma unroll
+                for (int n4 = 0; n4 < 4; ++n4) {
+                    // O' = O * W_8^{n4} (the last factor of the combination twiddle of the 32768-point transform)
+                    constexpr float R2 = 0.70710678118654752f;
+                    const float2 t = n4 == 0   ? y[0]
+                                     : n4 == 1 ? make_float2((y[1].x - y[1].y) * R2, (y[1].x + y[1].y) * R2)
+                                     : n4 == 2 ? mulj(y[2])
+                                               : make_float2((-y[3].x - y[3].y) * R2, (y[3].x - y[3].y) * R2);
+                    const float2 ylo = cadd(e[4 * i + n4], t);
+                    const int tile_u = 16 * i + 64 * n4 + 256 * R;
+                    const int tile_t = (n2o >> 2) + 4 * qo;
+                    const uint32_t soff = (uint32_t)tile_u * (uint32_t)nhyp * 256u + hoff;  // uniform (scalar) offset
+                    const uint32_t voff = ((uint32_t)tile_t * (uint32_t)nhyp * 64u + (uint32_t)(n1o + 16 * (n2o & 3))) << 2;
+                    tile_store<MODE>(rvt, voff, soff, __builtin_fmaf(ylo.x, ylo.x, ylo.y * ylo.y));
+                    if (n4 < NVH) {  // (plain form: the upper half y[n' + 16384] = E - O', tile + 256)
+                        const uint32_t voff_hi = voff + (((uint32_t)256 * (uint32_t)nhyp * 64u) << 2);
+                        const float2 yhi = csub(e[4 * i + n4], t);
+                        tile_store<MODE>(rvt, voff_hi, soff, __builtin_fmaf(yhi.x, yhi.x, yhi.y * yhi.y));
                     }
                 }
-                __builtin_amdgcn_sched_barrier(0);
             }
-            CAF_F2F_FOLD(prn, bx4, bh4, hb_n, (c == 0 ? 4 : 14), 2)
+            __builtin_amdgcn_sched_barrier(0);
         }
+        batch_fold(bx4, bh4, c_, caf_ic<3>{});
+    };
+
+    for (int h = h0; h < h1; ++h) {
+        hoff = (uint32_t)h * 256u;  // bytes
+        asm volatile("" : "+s"(hoff));
+        row_of(h + 1 < h1 ? h + 1 : h, hrow_n, hb_n);
+        sub(caf_ic<0>{});
+        sub(caf_ic<1>{});
         hrow_o = hrow_n;
         hb_o = hb_n;
     }
-#undef CAF_F2F_ISSUE
-#undef CAF_F2F_FOLD
 }
 
 // natural order -> butterfly order, chunk by chunk of 1024 elements (see fp_tid_of)
@@ -1223,25 +911,6 @@ __global__ __launch_bounds__(256) void k_parity_major(const float2* __restrict__
         const float4 v = *reinterpret_cast<const float4*>(&ir[2 * m]);
         orow[j] = make_float2(v.x, v.y);
         orow[half + j] = make_float2(v.z, v.w);
-    }
-}
-// rows of B = 4 * quarter complex samples -> residue-major: out[r][c][m'] = in[r][4 m' + c], each residue in butterfly order
-__global__ __launch_bounds__(256) void k_residue_major4(const float2* __restrict__ in, float2* __restrict__ out, int32_t quarter) {
-    const float2* ir = in + (int64_t)blockIdx.y * 4 * quarter;
-    float2* orow = out + (int64_t)blockIdx.y * 4 * quarter;
-    for (int j = blockIdx.x * 256 + threadIdx.x; j < quarter; j += gridDim.x * 256) {
-        const int m = (int)((j & ~1023) + fp_m2((uint32_t)j & 1023u));  // output position j holds source element m
-        const float4 lo = *reinterpret_cast<const float4*>(&ir[4 * m]), hi = *reinterpret_cast<const float4*>(&ir[4 * m + 2]);
-        orow[j] = make_float2(lo.x, lo.y);
-        orow[quarter + j] = make_float2(lo.z, lo.w);
-        orow[2 * quarter + j] = make_float2(hi.x, hi.y);
-        orow[3 * quarter + j] = make_float2(hi.z, hi.w);
-    }
-}
-void launch_residue_major4(const float2* in, float2* out, int64_t rows, int32_t quarter, hipStream_t st) {
-    for (int64_t r0 = 0; r0 < rows; r0 += 65535) {
-        const int64_t nr = std::min<int64_t>(65535, rows - r0);
-        hipLaunchKernelGGL(k_residue_major4, dim3(16, (unsigned)nr), dim3(256), 0, st, in + r0 * 4 * quarter, out + r0 * 4 * quarter, quarter);
     }
 }
 // rows of B = 4 * quarter complex samples -> PAIRS of the two halves of each parity (fused_item2f):
@@ -2067,7 +1736,7 @@ __device__ __attribute__((noinline)) void persistent_fft_item(lds_float2* s_d, c
         __hip_atomic_fetch_add(&params_of(pp)->pq[PQ_DONE + blk], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// FFT role for 32768-point blocks (templates of 8193 .. 16384 samples): fused_item2, same publish sequence
+// FFT role for 32768-point blocks (templates of 8193 .. 16384 samples): fused_item2q, same publish sequence
 template <int NVH>
 __device__ __attribute__((noinline)) void persistent_fft_item2(lds_float2* s_d, const lds_float2* s_tw2, const lds_float2* s_tw3,
                                                                const PersistParams* pp_in, int item_in) {
@@ -2079,36 +1748,15 @@ __device__ __attribute__((noinline)) void persistent_fft_item2(lds_float2* s_d, 
     const int grp = item - blk * ngroups;
     const int h0 = grp * hyp_per_wg;
     const int h1 = min(h0 + hyp_per_wg, nhyp);
-    fused_item2<1, NVH>((float2*)s_d, (const float2*)s_tw2, (const float2*)s_tw3, P->xb, P->hc, P->shifts, P->tw1, P->table_mode,
-                        P->nfreq, nhyp, blk, h0, h1, P->tiles_per_blk, P->vt);
+    fused_item2q<1, NVH, false, 0>((float2*)s_d, (const float2*)s_tw2, (const float2*)s_tw3, P->xb, P->hc, P->shifts, P->tw1, P->table_mode,
+                                   P->nfreq, nhyp, blk, h0, h1, P->tiles_per_blk, P->vt);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (threadIdx.x == 0)
         __hip_atomic_fetch_add(&params_of(pp)->pq[PQ_DONE + blk], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// FFT role for 65536-point blocks (templates of 16385 .. 32768 samples): fused_item4, one output quarter per item -- the
-// host doubles ngroups, group number = 2 * (hypothesis group) + q -- and the same publish sequence
-template <int Q>
-__device__ __attribute__((noinline)) void persistent_fft_item4(lds_float2* s_d, const lds_float2* s_tw2, const lds_float2* s_tw3,
-                                                               const PersistParams* pp_in, int item_in) {
-    const PersistParams* pp = uniform_ptr(pp_in);
-    const int item = __builtin_amdgcn_readfirstlane(item_in);
-    const CAF_AS4 PersistParams* P = params_of(pp);
-    const int ngroups = P->ngroups, hyp_per_wg = P->hyp_per_wg, nhyp = P->nhyp;
-    const int blk = item / ngroups;
-    const int grp = (item - blk * ngroups) >> 1;
-    const int h0 = grp * hyp_per_wg;
-    const int h1 = min(h0 + hyp_per_wg, nhyp);
-    fused_item4<1, Q>((float2*)s_d, (const float2*)s_tw2, (const float2*)s_tw3, P->xb, P->hc, P->shifts, P->tw1, P->table_mode,
-                      P->nfreq, nhyp, blk, h0, h1, P->tiles_per_blk, P->vt);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __syncthreads();
-    if (threadIdx.x == 0)
-        __hip_atomic_fetch_add(&params_of(pp)->pq[PQ_DONE + blk], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// FFT role for 65536-point blocks, folded form (fused_item2f): work item = (block, hypothesis group, output residue r), group
+// FFT role for 65536-point blocks (templates of 16385 .. 32768 samples; fused_item2q<FOLD>): work item = (block, hypothesis group, output residue r), group
 // number = 2 * (hypothesis group) + r, same publish sequence
 template <int R>
 __device__ __attribute__((noinline)) void persistent_fft_item2f(lds_float2* s_d, const lds_float2* s_tw2, const lds_float2* s_tw3,
@@ -2121,8 +1769,8 @@ __device__ __attribute__((noinline)) void persistent_fft_item2f(lds_float2* s_d,
     const int grp = (item - blk * ngroups) >> 1;
     const int h0 = grp * hyp_per_wg;
     const int h1 = min(h0 + hyp_per_wg, nhyp);
-    fused_item2f<1, R>((float2*)s_d, (const float2*)s_tw2, (const float2*)s_tw3, P->xb, P->hc, P->shifts, P->tw1, P->table_mode,
-                       P->nfreq, nhyp, blk, h0, h1, P->tiles_per_blk, P->vt);
+    fused_item2q<1, 0, true, R>((float2*)s_d, (const float2*)s_tw2, (const float2*)s_tw3, P->xb, P->hc, P->shifts, P->tw1, P->table_mode,
+                                P->nfreq, nhyp, blk, h0, h1, P->tiles_per_blk, P->vt);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (threadIdx.x == 0)
@@ -2253,16 +1901,11 @@ __global__ __launch_bounds__(1024) void k_caf_persistent(const PersistParams* __
             break;
         }
         if (kind == 1) {
-            if (__builtin_amdgcn_readfirstlane(params_of(pp)->block_log2) == 16 && __builtin_amdgcn_readfirstlane(params_of(pp)->dstride) == 2) {
+            if (__builtin_amdgcn_readfirstlane(params_of(pp)->block_log2) == 16) {
                 if ((item - (item / params_of(pp)->ngroups) * params_of(pp)->ngroups) & 1)
                     persistent_fft_item2f<1>((lds_float2*)s_d, (const lds_float2*)s_tw2, (const lds_float2*)s_tw3, pp, item);
                 else
                     persistent_fft_item2f<0>((lds_float2*)s_d, (const lds_float2*)s_tw2, (const lds_float2*)s_tw3, pp, item);
-            } else if (__builtin_amdgcn_readfirstlane(params_of(pp)->block_log2) == 16) {
-                if ((item - (item / params_of(pp)->ngroups) * params_of(pp)->ngroups) & 1)
-                    persistent_fft_item4<1>((lds_float2*)s_d, (const lds_float2*)s_tw2, (const lds_float2*)s_tw3, pp, item);
-                else
-                    persistent_fft_item4<0>((lds_float2*)s_d, (const lds_float2*)s_tw2, (const lds_float2*)s_tw3, pp, item);
             } else if (__builtin_amdgcn_readfirstlane(params_of(pp)->block_log2) == 15) {
                 const int tpb2 = __builtin_amdgcn_readfirstlane(params_of(pp)->tiles_per_blk);  // tiles >= 256: upper half
                 if (tpb2 <= 256)

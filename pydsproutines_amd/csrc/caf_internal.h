@@ -211,8 +211,6 @@ void launch_fos_scatter(const float2* rows, int64_t b0, int64_t nb, int64_t L, i
 
 // caf_fused.hip
 void launch_parity_major(const float2* in, float2* out, int64_t rows, int32_t half, hipStream_t st, bool butterfly = false);
-// rows of 4 * quarter samples -> residue-major ([c][quarter], m = 4 m' + c), each residue in butterfly order (fused_item4)
-void launch_residue_major4(const float2* in, float2* out, int64_t rows, int32_t quarter, hipStream_t st);
 // rows of 4 * quarter samples -> [c][quarter] pairs (sample 2 m + c, sample 2 (m + quarter) + c), m in butterfly order (fused_item2f)
 void launch_parity_pairs(const float2* in, float2* out, int64_t rows, int32_t quarter, hipStream_t st);
 void launch_fused_caf(const float2* xb, const float2* hc, const int32_t* shifts, const float2* tw1,
@@ -243,11 +241,10 @@ struct PersistParams {
     const float2* tw23;
     float* vt;
     int32_t table_mode, nfreq, nhyp, hyp_per_wg, nblk, tiles_per_blk;
-    int32_t block_log2;  // 14: one 16384-point transform per hypothesis; 15: 32768 points as two chained halves (fused_item2);
-                         // 16: 65536 points as four chained sub-transforms, one output quarter per item (fused_item4:
-                         // ngroups is then 2 x the hypothesis groups, group = 2 * hypothesis group + quarter)
-    int32_t dstride;     // delay stride of a tile: 1; 2 with block_log2 == 16 in the FOLDED form (fused_item2f: two chained
-                         // transforms per output residue r, group = 2 * hypothesis group + r, tile 256 r + u = delays 2 (64 u + j) + r)
+    int32_t block_log2;  // 14: one 16384-point transform per hypothesis; 15: 32768 points as two chained halves (fused_item2q);
+                         // 16: 65536 points in the folded form: two chained halves per output residue r (fused_item2q<FOLD>:
+                         // ngroups is then 2 x the hypothesis groups, group = 2 * hypothesis group + r)
+    int32_t dstride;     // delay stride of a tile: 1; 2 with block_log2 == 16 (tile 256 r + u = the delays 2 (64 u + j) + r)
     // tile items (same meaning as launch_transpose_norm_argmax)
     int32_t ntmpl, step, blk0;
     int32_t gpt;  // > 0: hypothesis groups are formed per template, gpt per template (group g of template t covers

@@ -68,7 +68,6 @@ struct caf_plan_t {
     int T = 0, N = 0, F = 0, G = 0;
     int freq_mode = 0, mul_mode = 0;
     int B = 0, step = 0, pitch = 0, nb = 0, tiles_per_blk = 0, hyp_per_wg = 16, fwd_chunk = 1;
-    bool fold16 = false;  // 65536-point blocks in the folded form (fused_item2f) instead of fused_item4
     int nb_nosurf = 0;  // persistent engine, no-surface mode: blocks per launch (the pair arrays are ~1/32 of the tiles)
     int64_t max_rx = 0, max_blocks = 0, partial_per_tmpl = 0;
     int device = 0;
@@ -452,8 +451,8 @@ static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
         const char* e = getenv("CAF_FUSED_LB15");
         return e && atoi(e);
     }();
-    // (templates of 16385 .. 32768 samples: 65536-point blocks = four chained transforms, one output quarter per work item,
-    //  fused_item4; CAF_FUSED_LB16=0 sends them to the rocfft engine as before -- A/B switch)
+    // (templates of 16385 .. 32768 samples: 65536-point blocks in the folded form, two chained transforms per output residue,
+    //  fused_item2q<FOLD>; CAF_FUSED_LB16=0 sends them to the rocfft engine as before -- A/B switch)
     static const bool lb16_env = [] {
         const char* e = getenv("CAF_FUSED_LB16");
         return !e || atoi(e);
@@ -492,14 +491,10 @@ static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
     // (1365 of 17745 items at C2) and, in the FFT role, the whole last quarter of the radix-4 pass for one output.
     // Giving up those few delays per block (< 0.33 % more blocks) removes both.
     if (p->fused && p->step % 64 != 0 && (p->step % 64) * 300 <= p->step) p->step -= p->step % 64;
-    // 65536-point blocks: a work item accumulates ONE output quarter of 16384 delays and the job runs quarters 0 and 1, so a
-    // block yields 32768 delays whatever the template length in (16384, 32768] (fused_item4: two pending quarters do not fit
-    // the registers, and a third quarter would cost what it yields)
+    // 65536-point blocks: only the first half of a block's outputs is used -- the folded form computes exactly the two output
+    // residues 2 k + r, k < 16384, each as the lower half of a 32768-point transform (fused_item2q<FOLD>) -- so a block yields
+    // 32768 delays whatever the template length in (16384, 32768]
     if (p->fused && lb == 16) p->step = 32768;
-    {
-        const char* e = getenv("CAF_LB16_FOLD");  // A/B switch: 0 = fused_item4 (eight sub-transforms per 32768 delays)
-        p->fold16 = p->fused && lb == 16 && (!e || atoi(e));
-    }
     p->pitch = p->B + 64;  // break the power-of-two stride between hypothesis rows
     const int B = p->B;
 
@@ -689,15 +684,12 @@ static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
         if (rc == CAF_OK) rc = tmp.exec(p->d_hc, nullptr, nullptr);
         if (rc == CAF_OK) launch_conj_scale(p->d_hc, nspec * B, 1.0f / (float)B, nullptr);
         if (rc == CAF_OK && p->fused && B == 65536) {
-            // the 65536-point engine reads its template-spectrum rows residue-major (m = 4 m' + c) -- and in butterfly order,
-            // which this one pass produces as well (the permutation below is skipped)
+            // the 65536-point engine reads its template-spectrum rows as pairs of the two halves of each parity, every
+            // 1024-chunk in butterfly order, which this one pass produces as well (the permutation below is skipped)
             float2* tmp = nullptr;
             rc = pool_alloc((void**)&tmp, nspec * (int64_t)B * 8);
             if (rc == CAF_OK) {
-                if (p->fold16)  // (folded form: pairs of the two halves of each parity)
-                    launch_parity_pairs(p->d_hc, tmp, nspec, B / 4, nullptr);
-                else
-                    launch_residue_major4(p->d_hc, tmp, nspec, B / 4, nullptr);
+                launch_parity_pairs(p->d_hc, tmp, nspec, B / 4, nullptr);
                 if (hipMemcpyAsync(p->d_hc, tmp, (size_t)nspec * B * 8, hipMemcpyDeviceToDevice, nullptr) != hipSuccess) rc = CAF_ERR_HIP;
                 (void)hipStreamSynchronize(nullptr);
                 (void)pool_free(tmp);
@@ -952,10 +944,8 @@ int32_t caf_plan_execute2(caf_plan p, const float* d_rx, int64_t rx_len, int64_t
     }
     if (p->fused && p->B == 32768 && !lds_fwd32)  // block spectra parity-major for the two chained half-transforms
         launch_parity_major(p->d_xb, p->d_xb2, nfwd * p->fwd_chunk, p->B / 2, st, true);
-    if (p->fused && p->B == 65536 && p->fold16)  // ... pairs of the halves of each parity for the folded form
+    if (p->fused && p->B == 65536)  // ... as pairs of the two halves of each parity for the folded form
         launch_parity_pairs(p->d_xb, p->d_xb2, nfwd * p->fwd_chunk, p->B / 4, st);
-    else if (p->fused && p->B == 65536)  // ... residue-major for the four chained sub-transforms
-        launch_residue_major4(p->d_xb, p->d_xb2, nfwd * p->fwd_chunk, p->B / 4, st);
     if (aux) CAF_HIP_TRY(hipStreamWaitEvent(st, p->ev_join, 0));
     bool f1_direct = false, f1_item_peaks = false;
     if (p->fused) {
@@ -1018,7 +1008,7 @@ int32_t caf_plan_execute2(caf_plan p, const float* d_rx, int64_t rx_len, int64_t
             h.nblk = nbk;
             h.tiles_per_blk = p->tiles_per_blk;
             h.block_log2 = p->B == 65536 ? 16 : p->B == 32768 ? 15 : 14;
-            h.dstride = p->fold16 ? 2 : 1;
+            h.dstride = p->B == 65536 ? 2 : 1;
             h.ntmpl = T;
             h.step = p->step;
             h.blk0 = (int32_t)b0;
@@ -1043,7 +1033,7 @@ int32_t caf_plan_execute2(caf_plan p, const float* d_rx, int64_t rx_len, int64_t
             }
             h.vmax = p->d_vt;
             h.imax = reinterpret_cast<int32_t*>(p->d_vt + (int64_t)nb_launch * h.ngroups * p->tiles_per_blk * 64);
-            if (h.block_log2 == 16) h.ngroups *= 2;  // one work item per (hypothesis group, output quarter): fused_item4
+            if (h.block_log2 == 16) h.ngroups *= 2;  // one work item per (hypothesis group, output residue): fused_item2q<FOLD>
             h.n_fft = nbk * h.ngroups;
             h.ipb = (p->tiles_per_blk + 15) / 16;  // 16 tiles per item (PQ_TILES, caf_fused.hip)
             h.n_tr = nbk * h.ipb;

@@ -9,7 +9,7 @@ ROWS = [  # (workload, kernel prefix of the manifest entry, label)
     ("c2_nosurface", "k_caf_persistent", "`k_caf_persistent` (C2 no surface)"),
     ("c4_share", "k_caf_persistent", "`k_caf_persistent` (C4 share: 64 templates × 512 bins)"),
     ("c2_long_template", "k_caf_persistent", "`k_caf_persistent` (N = 16384, 2 × 16384)"),
-    ("c2_lb16", "k_caf_persistent", "`k_caf_persistent` (N = 32768, 4 × 16384, one output quarter per item)"),
+    ("c2_lb16", "k_caf_persistent", "`k_caf_persistent` (N = 32768, 65536-point blocks folded: 2 × 16384 per output residue)"),
     ("c3", "k_caf_persistent", "`k_caf_persistent` (C3: rows written by the FFT items)"),
     ("c3_complex_rows", "k_caf_persistent", "`k_caf_persistent` (C3 complex-QF rows, `TemplateCrossCorrelator.correlate`)"),
     ("c2_fused", "k_fused_caf", "`k_fused_caf`"),

@@ -172,7 +172,7 @@ def w_c2_surface_t():
 
 
 def w_c2_lb16():
-    """C2 shape with a 32768-sample template: 65536-point blocks = four chained 16384-point transforms, one quarter per item."""
+    """C2 shape with a 32768-sample template: 65536-point blocks in the folded form = two chained 16384-point transforms per output residue."""
     n = 32768
     t = qpsk(rng, n)
     d_rx = asarray(cn(rng, M))
@@ -185,9 +185,9 @@ def w_c2_lb16():
     B, step = plan.block, plan.step
     nblk = -(-Sn // step)
     alg = nblk * ((step // 64) * 64 * 256 * 4.0 + 8.0 * B) + Sn * 256 * 8.0 + Sn * 12.0
-    flops = nblk * 256 * 2 * (4 * 5.0 * 16384 * 14 + 6.0 * B + 3.0 * 16384)
+    flops = nblk * 256 * 2 * (2 * 5.0 * 16384 * 14 + 17.0 * 32768 + 3.0 * 16384)  # per item: two transforms, the fold (2 products + sum [+ twiddle]), |y|^2
     plan.close()
-    return [("k_caf_persistent", "one-launch engine, N=32768 (B=65536 as 4 x 16384, one output quarter per item), F=256, surface",
+    return [("k_caf_persistent", "one-launch engine, N=32768 (B=65536 folded: 2 x 16384 per output residue), F=256, surface",
              alg, flops, 2)]
 
 

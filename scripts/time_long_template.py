@@ -1,6 +1,6 @@
 """The C2 shape (2^24-sample rx, 256 on-grid bins, full surface) for template lengths around the LDS engines' limits:
 N = 4096 / 8192 (16384-point blocks), 8193 / 16384 (32768-point blocks = two chained transforms), 16385 / 24576 / 32768
-(65536-point blocks = four chained transforms, one output quarter per work item), 32769 (rocfft engine)."""
+(65536-point blocks in the folded form: two chained transforms per output residue), 32769 (rocfft engine)."""
 import sys
 import time
 

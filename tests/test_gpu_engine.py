@@ -327,8 +327,8 @@ def test_engines_agree_with_oracle(engine, golden):
 @pytest.mark.parametrize("n", [4095, 8191, 8192, 8193, 12000, 16384, 16385, 24000, 32768, 32769])
 def test_template_lengths_around_the_fused_limits(n):
     """The LDS-resident engines: 16384-point blocks for templates up to 8192 samples (persistent and two-launch fused,
-    bit-identical), 32768-point blocks as two chained 16384-point transforms up to 16384 samples, 65536-point blocks as four
-    chained transforms (one output quarter per work item) up to 32768 samples (persistent only); longer ones go to the
+    bit-identical), 32768-point blocks as two chained 16384-point transforms up to 16384 samples, 65536-point blocks in the
+    folded form (two chained transforms per output residue) up to 32768 samples (persistent only); longer ones go to the
     rocfft engine automatically and are refused by an explicit fused / persistent request."""
     from pydsproutines_amd import CAFPlan, asarray
     from test_gpu_engine_fuzz import _oracle_rows
@@ -417,8 +417,8 @@ def test_long_template_explicit_frequencies_and_many_hypotheses():
 
 
 def test_65536_point_role_explicit_frequencies_and_several_templates():
-    """65536-point blocks (templates of 16385 .. 32768 samples) with an explicit frequency table (table mode: one residue-major
-    row per hypothesis), more hypotheses than one work item takes and an odd number of them, two templates, a sub-range: against
+    """65536-point blocks (templates of 16385 .. 32768 samples) with an explicit frequency table (table mode: one row of
+    parity pairs per hypothesis), more hypotheses than one work item takes and an odd number of them, two templates, a sub-range: against
     the rocfft engine and the oracle."""
     from pydsproutines_amd import CAFPlan, asarray
     from test_gpu_engine_fuzz import _oracle_rows
@@ -447,6 +447,64 @@ def test_65536_point_role_explicit_frequencies_and_several_templates():
     np.testing.assert_allclose(sub.row_max.get(), r.row_max.get()[:, 25_000:65_001], atol=2e-6)
     assert int(sub.peak_delay.get()[0]) == 30_000
     p.close()
+
+
+def test_65536_point_role_tiles_of_every_second_delay():
+    """The folded 65536-point role leaves tiles of every second delay (tile 256 r + u = delays 2 (64 u + j) + r), so each tile
+    role runs with a delay stride: no frequency scan (three templates, one bin: the streaming tile role), per-delay maxima
+    without the surface, and the full surface -- with a ragged last block whose valid count is odd, sub-ranges that start at
+    odd delays and end inside a tile, every template's row checked against the oracle at block / tile / parity boundaries."""
+    from pydsproutines_amd import CAFPlan, asarray
+    from test_gpu_engine_fuzz import _oracle_rows
+
+    rng = np.random.default_rng(65)
+    n, m = 17_001, 17_001 + 2 * 32768 + 4_320  # 69857 delays: two whole blocks + 4321 (an odd count) in the third
+    S = m - n + 1
+    tm = np.stack([qpsk(rng, n) for _ in range(3)])
+    rx = cn(rng, m)
+    truth = [(1, 0), (32_769, -2), (S - 1, 3)]  # the first odd row, the second block's first odd row, the very last row
+    bins = np.arange(-2, 4)
+    for i, (d, b) in enumerate(truth):
+        rx[d : d + n] += (tm[i] * np.exp(2j * np.pi * b / 16384 * np.arange(n))).astype(np.complex64)
+    d_rx = asarray(rx)
+    rows = np.unique(np.concatenate((np.arange(0, 4), [126, 127, 128, 129, 32766, 32767, 32768, 32769, 65535, 65536, 65537],
+                                     np.arange(S - 4, S), rng.integers(0, S, 12))))
+    # (a) no frequency scan: the hypothesis axis of a tile is the template axis
+    p1 = CAFPlan(tm, max_rx_len=m, bins=[0], grid=16384)
+    assert p1.engine_used == "persistent" and p1.block == 65536 and p1.step == 32768
+    r1 = p1.run(d_rx, surface=True)
+    a1, rm1 = r1.surface.get(), r1.row_max.get()
+    assert a1.shape == (3, S, 1) and np.array_equal(a1[:, :, 0], rm1) and not np.any(r1.row_arg.get())
+    for i in range(3):
+        ref = _oracle_rows(tm[i], rx, np.array([0.0]), rows)[:, 0]
+        np.testing.assert_allclose(rm1[i][rows], ref, atol=1e-4 * max(ref.max(), 1e-3))
+    assert int(r1.peak_delay.get()[0]) == truth[0][0]
+    for s0, ns in ((1, S - 1), (32_767, 3), (4_001, 40_002), (S - 65, 65)):
+        sub = p1.run(d_rx, shift_start=s0, num_shifts=ns, surface=False)
+        np.testing.assert_allclose(sub.row_max.get(), rm1[:, s0 : s0 + ns], atol=2e-6)
+        assert int(sub.peak_delay.get()[0]) == s0 + int(np.argmax(rm1[0, s0 : s0 + ns]))
+    p1.close()
+    # (b) six bins: surface, and the same rows / arguments / peaks without it
+    p6 = CAFPlan(tm, max_rx_len=m, bins=bins, grid=16384)
+    r6 = p6.run(d_rx, surface=True)
+    a6 = r6.surface.get()
+    for i, (d, b) in enumerate(truth):
+        ref = _oracle_rows(tm[i], rx, bins / 16384.0, rows)
+        np.testing.assert_allclose(a6[i][rows], ref, atol=1e-4 * ref.max())
+        assert (int(r6.peak_delay.get()[i]), int(bins[r6.peak_freq.get()[i]])) == (d, b)
+    assert np.array_equal(r6.row_max.get(), a6.max(axis=2)) and np.array_equal(r6.row_arg.get(), a6.argmax(axis=2))
+    for s0, ns in ((0, S), (32_769, 32_768), (65_535, S - 65_535)):
+        q = p6.run(d_rx, shift_start=s0, num_shifts=ns, surface=False)
+        if s0 == 0:  # the same blocks: bit for bit; a shifted range cuts rx into other blocks (other roundings)
+            assert np.array_equal(q.row_max.get(), r6.row_max.get()[:, s0 : s0 + ns])
+            assert np.array_equal(q.row_arg.get(), r6.row_arg.get()[:, s0 : s0 + ns])
+        else:
+            np.testing.assert_allclose(q.row_max.get(), r6.row_max.get()[:, s0 : s0 + ns], atol=2e-6)
+            assert np.mean(q.row_arg.get() == r6.row_arg.get()[:, s0 : s0 + ns]) > 0.999
+        for i in range(3):
+            want = s0 + int(np.argmax(r6.row_max.get()[i, s0 : s0 + ns]))
+            assert int(q.peak_delay.get()[i]) == want
+    p6.close()
 
 
 def test_direct_engine_for_templates_with_a_handful_of_samples():

@@ -336,9 +336,9 @@ def test_c5_full_size_zoom(c2):
 
 @pytest.mark.parametrize("n", [16385, 32768])
 def test_long_templates_full_size_on_the_chained_role(n):
-    """Templates of 16385 / 32768 samples at the C2 shape (2^24-sample rx, 256 bins, full surface): 65536-point blocks as four
-    chained transforms, two work items (output quarters) per block and hypothesis group -- planted (delay, bin) exact, sampled
-    rows (block boundaries at multiples of 32768, quarter boundaries at 16384, both ends) against the oracle, row results ==
+    """Templates of 16385 / 32768 samples at the C2 shape (2^24-sample rx, 256 bins, full surface): 65536-point blocks in the
+    folded form, two work items (output residues) per block and hypothesis group -- planted (delay, bin) exact, sampled
+    rows (block boundaries at multiples of 32768, tile boundaries, both ends) against the oracle, row results ==
     the surface written, agreement with the rocfft engine on the per-delay maxima."""
     from pydsproutines_amd import CAFPlan, asarray
 
