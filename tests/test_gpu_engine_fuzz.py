@@ -163,6 +163,97 @@ def test_random_shapes_all_engines(seed):
         plan.close()
 
 
+CHAINED_CASES = list(range(max(10, int(os.environ.get("CAF_FUZZ_CASES", "28")) // 2)))
+
+
+def _chained_case(seed):
+    """Templates of 8193 .. 32768 samples: 32768-point blocks (two chained transforms; one, two or all four quarters of the
+    upper half valid) and 65536-point blocks (folded: tiles of every second delay)."""
+    rng = np.random.default_rng(7000 + seed)
+    n = int(rng.choice([8193, 9000, 12288, 12289, 16383, 16384, 16385, 20000, 24576, 32767, 32768]))
+    t = int(rng.choice([1, 1, 2, 3]))
+    f = int(rng.choice([1, 2, 5, 31, 33, 64, 70]))
+    step = (32768 if n <= 16384 else 65536) - n + 1 if n <= 16384 else 32768
+    nblk = float(rng.choice([0.3, 1.0, 1.7, 2.0, 3.2]))
+    s_total = max(1, int(nblk * step) + int(rng.integers(-70, 70)))
+    m = n + s_total - 1
+    table = bool(rng.integers(0, 2)) and f > 1
+    grid = 16384
+    if table:
+        freqs = np.sort(rng.uniform(-2e-3, 2e-3, f))
+    else:
+        lo = -(f // 2)
+        bins = np.arange(lo, lo + f)
+    tm = np.stack([qpsk(rng, n) for _ in range(t)])
+    gs = gl = None
+    if rng.integers(0, 4) == 0:  # composite template: two groups with a gap
+        a, b = sorted(int(v) for v in rng.choice(np.arange(1000, n - 1000), 2, replace=False))
+        gs, gl = np.array([0, b], np.int32), np.array([a, n - b], np.int32)
+        mask = np.zeros(n, bool)
+        mask[:a] = True
+        mask[b:] = True
+        tm = (tm * mask).astype(np.complex64)
+    rx = cn(rng, m)
+    truth = []
+    for i in range(t):
+        d = int(rng.integers(0, s_total))
+        j = int(rng.integers(0, f))
+        nu = freqs[j] if table else bins[j] / grid
+        rx[d : d + n] += (tm[i] * np.exp(2j * np.pi * nu * np.arange(n))).astype(np.complex64)
+        truth.append((d, j))
+    kw = dict(freqs_norm=freqs) if table else dict(bins=bins, grid=grid)
+    if gs is not None:
+        kw.update(group_starts=gs, group_lens=gl)
+    sub = bool(rng.integers(0, 2))
+    lo_s = int(rng.integers(0, max(1, s_total // 2))) if sub else 0
+    cnt = int(rng.integers(1, s_total - lo_s + 1)) if sub else s_total
+    return dict(n=n, t=t, f=f, m=m, tm=tm, rx=rx, kw=kw, lo=lo_s, cnt=cnt, truth=truth, nu=(freqs if table else bins / grid),
+                gs=gs, gl=gl, nb=int(rng.choice([0, 0, 1])))
+
+
+@pytest.mark.parametrize("seed", CHAINED_CASES)
+def test_random_shapes_chained_roles(seed):
+    """The chained roles of the persistent engine against the rocfft engine and the oracle, and against themselves: the rows
+    and the peak are those of the surface written; without the surface the per-delay results are the same bits."""
+    from pydsproutines_amd import CAFPlan, asarray
+
+    c = _chained_case(seed)
+    d_rx = asarray(c["rx"])
+    plan = CAFPlan(c["tm"], max_rx_len=c["m"], engine="persistent", blocks_per_batch=c["nb"], **c["kw"])
+    assert plan.engine_used == "persistent" and plan.block == (32768 if c["n"] <= 16384 else 65536)
+    r = plan.run(d_rx, shift_start=c["lo"], num_shifts=c["cnt"], surface=True)
+    sp, rmp, rap = r.surface.get(), r.row_max.get(), r.row_arg.get()
+    pvp, pdp, pfp = r.peak_val.get(), r.peak_delay.get(), r.peak_freq.get()
+    assert sp.shape == (c["t"], c["cnt"], c["f"]) and not np.any(np.isnan(sp))
+    np.testing.assert_array_equal(rmp, sp.max(axis=2))
+    np.testing.assert_array_equal(rap, np.argmax(sp, axis=2))
+    for i in range(c["t"]):
+        j = int(np.argmax(rmp[i]))
+        assert pvp[i] == rmp[i][j] and pdp[i] == c["lo"] + j and pfp[i] == rap[i][j]
+        d, fj = c["truth"][i]
+        if c["lo"] <= d < c["lo"] + c["cnt"]:
+            assert int(pdp[i]) == d, "planted delay of template %d" % i
+    r2 = plan.run(d_rx, shift_start=c["lo"], num_shifts=c["cnt"], surface=False, rows=True, peak=True)
+    np.testing.assert_array_equal(r2.row_max.get(), rmp)
+    np.testing.assert_array_equal(r2.row_arg.get(), rap)
+    np.testing.assert_array_equal(r2.peak_delay.get(), pdp)
+    np.testing.assert_array_equal(r2.peak_freq.get(), pfp)
+    r3 = plan.run(d_rx, shift_start=c["lo"], num_shifts=c["cnt"], surface=False, rows=False, peak=True)
+    np.testing.assert_array_equal(r3.peak_delay.get(), pdp)
+    np.testing.assert_array_equal(r3.peak_val.get(), pvp)
+    plan.close()
+    q = CAFPlan(c["tm"], max_rx_len=c["m"], engine="rocfft", **c["kw"])
+    sr = q.run(d_rx, shift_start=c["lo"], num_shifts=c["cnt"], surface=True).surface.get()
+    q.close()
+    scale = float(np.nanmax(sp))
+    assert np.nanmax(np.abs(sp - sr)) <= 2e-5 * max(scale, 1e-3)
+    rng = np.random.default_rng(seed)
+    rows = np.unique(np.concatenate((rng.integers(0, c["cnt"], 6), [0, c["cnt"] - 1])))
+    for i in range(c["t"]):
+        ref = _oracle_rows(c["tm"][i], c["rx"], c["nu"], c["lo"] + rows, c["gs"], c["gl"])
+        assert np.max(np.abs(sp[i][rows] - ref)) <= 1e-4 * max(float(ref.max()), scale)
+
+
 def _oracle_rows(tmpl, rx, nu, shifts, gs=None, gl=None):
     """QF^2 at the given delays and normalised frequencies: the reference's per-delay definition
     (xcorrRoutines.py:511-566) with an explicit DFT row per frequency, float64; with groups, the rx energy is
