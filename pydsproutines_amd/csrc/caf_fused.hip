@@ -402,6 +402,17 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
         lds_rows16c<FP_P1>(m0_x1, v1[0]);  // value n1 -> region n1, row = this wave, position = lane
         __syncthreads();
         row_of(more ? h + 1 : h);  // unconditional refill (the last one is redundant): no select keeps pr alive
+        // Modes 2+ (no |y|^2 tiles: running maxima, finished rows, complex rows, hypothesis-major rows) have 20 registers
+        // less than the tile modes, so the next template-spectrum row cannot be fetched whole before pass 3 as there.
+        // EH positions of it are fetched at the start of pass 2 and EH more at the start of pass 3, each batch multiplied at
+        // the end of its pass (the products wait in pr, dead since pass 1); the rest after pass 3 as before.  C2 without the
+        // surface by EH, one box (profiles/r04/ab_early_template_row.log): 0 -> 9.32 ms, 4 -> 8.99, 5 -> 8.84, 6 -> 8.98,
+        // 8 -> 9.59 (every early arrival beyond the free registers is parked in scratch); hypothesis-major surface
+        // (20 more registers: the normalisation factors): 0 -> 11.04, 2 -> 10.78, 3 -> 10.69 with 11 spilled dwords per hypothesis -- 2 is kept.
+        constexpr int EH = MODE == 5 ? 2 : MODE >= 2 ? 5 : 0;
+        float2 he[2 * EH + 1];
+#pragma unroll
+        for (int a = 0; a < EH; ++a) he[a] = ld2(hrow_cur, ((1024u * a + hb_cur) & (FB - 1)) + lz);
         // ---- pass 2: DFT16 over b, in place (n1 = idx >> 6, col = idx & 63) ----
         // all of a thread's butterflies are read first, so the LDS reads of butterfly j+1 fly under the
         // arithmetic of butterfly j (they touch disjoint addresses)
@@ -416,6 +427,8 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
             for (int n2 = 1; n2 < 16; ++n2) v[n2] = cmul(v[n2], tw_ld(t2, n2 * 64));
             lds_rows16c_x2(m0_w, v);  // value n2 -> row n2 of this wave's region, position = lane
         }
+#pragma unroll
+        for (int a = 0; a < EH; ++a) pr[0][a] = cmul(xr[0][a], he[a]);
         // No workgroup barrier here: plane n1 = idx >> 6 is written in pass 2 and read in pass 3 by the SAME
         // wave (wave w owns planes w, w + FT/64, ...), and a wave's LDS operations complete in order.
         __builtin_amdgcn_wave_barrier();
@@ -429,6 +442,8 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
                 for (int a = 0; a < 16; ++a)
                     hn[j][a] = ld2(hrow_cur, (1024u * a + hb_cur) & (FB - 1));  // (hb_cur changes per hypothesis: nothing to hoist)
         }
+#pragma unroll
+        for (int a = EH; a < 2 * EH; ++a) he[a] = ld2(hrow_cur, ((1024u * a + hb_cur) & (FB - 1)) + lz);
         // ---- pass 3: DFT16 over c, in place (n1 = idx >> 6, n2 = (idx >> 2) & 15, d = idx & 3) ----
         {
             float2 v[16];
@@ -441,6 +456,8 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
             for (int n3 = 1; n3 < 16; ++n3) v[n3] = cmul(v[n3], tw_ld(t3, n3 * 4));
             lds_rows16c<256>(m0_w, v);  // value n3 -> row n3 of this wave's region, position = lane = d + 4 n2
         }
+#pragma unroll
+        for (int a = EH; a < 2 * EH; ++a) pr[0][a] = cmul(xr[0][a], he[a]);
         if (MODE >= 2) {
             // (the 20 registers of the running maxima leave no room for the row during pass 3: it is fetched here,
             // under the barrier and the pass-4 work.  MODE 5, measured: a quarter / half / three quarters of the row
@@ -448,7 +465,7 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
 #pragma unroll
             for (int j = 0; j < BPT; ++j)
 #pragma unroll
-                for (int a = 0; a < 16; ++a)
+                for (int a = 2 * EH; a < 16; ++a)
                     hn[j][a] = ld2(hrow_cur, (1024u * a + hb_cur) & (FB - 1));  // (hb_cur changes per hypothesis: nothing to hoist)
         }
         __syncthreads();
@@ -543,7 +560,7 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
             }
             if (MODE >= 2) {
 #pragma unroll
-                for (int a = 0; a < 16; ++a) pr[j][a] = cmul(xr[j][a], hn[j][a]);
+                for (int a = 2 * EH; a < 16; ++a) pr[j][a] = cmul(xr[j][a], hn[j][a]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
