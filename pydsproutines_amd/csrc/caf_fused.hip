@@ -411,6 +411,16 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
         // (20 more registers: the normalisation factors): 0 -> 11.04, 2 -> 10.78, 3 -> 10.69 with 11 spilled dwords per hypothesis -- 2 is kept.
         constexpr int EH = MODE == 5 ? 2 : MODE >= 2 ? 5 : 0;
         float2 he[2 * EH + 1];
+        // Tile modes: the next row is fetched whole before pass 3 (below) -- except its first HP2 positions, which go out
+        // here, a pass earlier: the same registers in flight at the peak, and the first products of pass 4 find their
+        // operands there.  C2 with the surface by HP2, one box (profiles/r04/ab_template_row_before_pass2.log): 0 -> 13.80
+        // ms, 2 -> 13.65, 3 -> 13.58, 4 -> 13.47, 5 -> 13.36, 6 -> 13.5, 8 -> 13.67, 16 -> 14.1.
+        constexpr int HP2 = 5;
+        float2 hn[BPT][16];
+        if (MODE < 2) {
+#pragma unroll
+            for (int a = 0; a < HP2; ++a) hn[0][a] = ld2(hrow_cur, ((1024u * a + hb_cur) & (FB - 1)) + lz);
+        }
 #pragma unroll
         for (int a = 0; a < EH; ++a) he[a] = ld2(hrow_cur, ((1024u * a + hb_cur) & (FB - 1)) + lz);
         // ---- pass 2: DFT16 over b, in place (n1 = idx >> 6, col = idx & 63) ----
@@ -434,12 +444,11 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
         __builtin_amdgcn_wave_barrier();
         // next hypothesis' template-spectrum row: issued before pass 3 so that the L2 latency is covered by
         // the pass-3 butterfly and the pass-4 work
-        float2 hn[BPT][16];
         if (MODE < 2) {
 #pragma unroll
             for (int j = 0; j < BPT; ++j)
 #pragma unroll
-                for (int a = 0; a < 16; ++a)
+                for (int a = HP2; a < 16; ++a)
                     hn[j][a] = ld2(hrow_cur, (1024u * a + hb_cur) & (FB - 1));  // (hb_cur changes per hypothesis: nothing to hoist)
         }
 #pragma unroll
