@@ -968,6 +968,18 @@ int32_t caf_plan_execute2(caf_plan p, const float* d_rx, int64_t rx_len, int64_t
                 // the two pair arrays must fit the tile buffer they replace (true for >= 2 hypotheses per group)
                 if (2 * (int64_t)T * gpt <= (int64_t)T * F) ns_gpt = gpt;
             }
+            // A work item costs ~13 us beside its hypotheses (claim, parameters, block spectrum, first row:
+            // profiles/r04/c3_items_and_xcd_groups.log), 3 % of an item of 64: groups of up to 256 hypotheses (the running
+            // maxima pack the index into 8 bits) while the launch keeps >= 40 items per CU -- config C4's share of one GPU
+            // (64 templates x 512 bins) 1010 -> 979 ms; C2 (one template, 1365 x 4 items) stays at 64
+            if (ns_gpt && !getenv("CAF_HYP_PER_WG")) {
+                const int64_t blocks_launch = std::min<int64_t>(p->nb_nosurf, nblk);
+                while (ns_gpt > 1) {
+                    const int g2 = (ns_gpt + 1) / 2;
+                    if ((F + g2 - 1) / g2 > 256 || (int64_t)T * g2 * blocks_launch < (int64_t)40 * p->n_cus) break;
+                    ns_gpt = g2;
+                }
+            }
             // the hypothesis-major surface rides on the same per-template groups (F >= 2 here; fewer hypotheses than a
             // group: one group per template)
             if (surf_t) ns_gpt = (F + p->hyp_per_wg - 1) / p->hyp_per_wg;
