@@ -603,7 +603,12 @@ __global__ __launch_bounds__(R10<P>::WG, 4) void k_perdelay_r10(  // (4 waves pe
             const int64_t a = s < 0 ? 0 : (s > ylen ? ylen : s);
             int64_t b = s + N;
             b = b < 0 ? 0 : (b > ylen ? ylen : b);
-            inv = (float)(1.0 / (sqrt(prefix[b] - prefix[a]) * xn));
+            // 1 / (sqrt(E) ||x||) as rsq(E ||x||^2) + one Newton step (2^-45 or better before the rounding to float32), as in
+            // k_perdelay_fused: a float64 square root and a float64 division per row and thread are ~40 half-rate
+            // instructions.  E = 0: rsq = inf, 0 * inf = NaN -> NaN row, as before.
+            const double en = (prefix[b] - prefix[a]) * (xn * xn);
+            const double y0 = __builtin_amdgcn_rsq(en);
+            inv = (float)__builtin_fma(__builtin_fma(-(en * y0), 0.5 * y0, 0.5), y0, y0);
         }
         r10_fft<P>(buf, tw10, l, active, v);
         // outputs: register t <-> spectrum index l + t NTR (ascending in t)
