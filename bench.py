@@ -456,9 +456,6 @@ def launch_ranks(n, argv):
     LOCAL_RANK, with the rendezvous variables torch.distributed reads (127.0.0.1, a free port), wait for all of them,
     print rank 0's JSON line and return non-zero if any rank failed.  The parent never initialises the GPU (children are
     separate processes started with subprocess, never an exec of a process that has touched the device)."""
-    import socket
-    import subprocess
-
     import torch  # device_count() does not initialise the GPU on this image
 
     rehearse = os.environ.get("BENCH_REHEARSE_GLOO") == "1"
@@ -467,6 +464,22 @@ def launch_ranks(n, argv):
         print("bench.py --gpus %d: only %d GPU(s) visible (set BENCH_REHEARSE_GLOO=1 to rehearse the %d-rank code path "
               "on fewer GPUs over gloo)" % (n, have, n), file=sys.stderr)
         return 2
+    # The rendezvous port is found by binding to port 0 and closing again, so another process can take it before rank 0
+    # binds it: a world that fails within its first 30 s is started again on a fresh port (twice at most).
+    for attempt in range(3):
+        t_attempt = time.monotonic()
+        rc = _launch_once(n, argv)
+        if rc == 0 or rc == 3 or time.monotonic() - t_attempt > 30.0 or attempt == 2:
+            return 1 if rc == 3 else rc
+        print("bench.py --gpus %d: the world did not form (attempt %d); trying another port" % (n, attempt + 1), file=sys.stderr)
+    return 1
+
+
+def _launch_once(n, argv):
+    """One attempt of launch_ranks: 0 = rank 0's line printed, 1 = a rank failed, 3 = the world formed with the wrong size."""
+    import socket
+    import subprocess
+
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
@@ -510,7 +523,7 @@ def launch_ranks(n, argv):
         return 1
     if json.loads(line[-1]).get("n_gpus") != n:
         print("bench.py --gpus %d: the world that formed reports n_gpus=%r" % (n, json.loads(line[-1]).get("n_gpus")), file=sys.stderr)
-        return 1
+        return 3
     print(line[-1])
     return 0
 
