@@ -57,6 +57,10 @@ static_assert(fp_row2(15) + 256 <= FP_P1 && FP_P1 % 256 == 32, "planar image geo
 // the accesses global_* (not flat_*) even where the base pointer was rebuilt from scalar halves
 // (uniform_ptr below), whose provenance the address-space inference cannot see.
 #define CAF_AS1 __attribute__((address_space(1)))
+// ... and the constant address space for read-only values at wave-uniform addresses: SCALAR loads (s_load, counted by lgkmcnt).
+// A vector load of such a value inside a hypothesis loop is followed by s_waitcnt vmcnt(0) -- which also waits for every
+// tile store still on its way to memory, and then for the load's own round trip.
+#define CAF_AS4 __attribute__((address_space(4)))
 typedef float v2f_t __attribute__((ext_vector_type(2)));
 typedef float v4f_t __attribute__((ext_vector_type(4)));
 typedef int v2i_t __attribute__((ext_vector_type(2)));
@@ -327,7 +331,7 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
             hb_cur = (uint32_t)tid;
         } else {
             const int t = h / nfreq;
-            const int32_t sh = *((const CAF_AS1 int32_t*)shifts + (h - t * nfreq));
+            const int32_t sh = *((const CAF_AS4 int32_t*)shifts + (h - t * nfreq));
             hrow_cur = hc + (int64_t)t * FB;
             hb_cur = fp_hbase(m2, sh);
         }
@@ -360,7 +364,7 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
         __amdgpu_buffer_rsrc_t f1_r0 = rvt, f1_r1 = rvt;
         float f1_ts = 0.f;
         if (MODE == 3) {
-            f1_ts = *((const CAF_AS1 float*)f1->tscale + h);
+            f1_ts = *((const CAF_AS4 float*)f1->tscale + h);
             f1_r0 = buf_of(uniform_ptr(f1->out0 + (int64_t)h * f1->num_shifts + f1_rel0), f1->out0 ? f1_bytes : 0u);  // past the block's
             if (f1->out1)                                                                            // delays: dropped
                 f1_r1 = buf_of(uniform_ptr(f1->out1 + (int64_t)h * f1->num_shifts + f1_rel0), f1_bytes);
@@ -368,11 +372,11 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
         float pk_v[4] = {-1.f, -1.f, -1.f, -1.f};
         uint32_t pk_i[4] = {0u, 0u, 0u, 0u};
         if (MODE == 4) {
-            f1_ts = __builtin_sqrtf(*((const CAF_AS1 float*)f1->tscale + h / nfreq));
+            f1_ts = __builtin_sqrtf(*((const CAF_AS4 float*)f1->tscale + h / nfreq));
             f1_r0 = buf_of(uniform_ptr(f1->out0 + 2 * ((int64_t)h * f1->num_shifts + f1_rel0)), 2u * f1_bytes);
         }
         if (MODE == 5) {  // row h = t * nfreq + f of the hypothesis-major surface
-            f1_ts = *((const CAF_AS1 float*)f1->tscale + h / nfreq);
+            f1_ts = *((const CAF_AS4 float*)f1->tscale + h / nfreq);
             f1_r0 = buf_of(uniform_ptr(f1->out0 + (int64_t)h * f1->num_shifts + f1_rel0), f1_bytes);
         }
         // ---- pass 1: P = X * Hc_h ; DFT16 over a ; twiddle w^n1 ; write A[n1][m2] ----
@@ -705,7 +709,7 @@ __device__ __forceinline__ void fused_item2q(float2* __restrict__ s_d, const flo
             hb = (uint32_t)tid;
         } else {
             const int t = h / nfreq;
-            const int32_t sh = *((const CAF_AS1 int32_t*)shifts + (h - t * nfreq)) >> 1;
+            const int32_t sh = *((const CAF_AS4 int32_t*)shifts + (h - t * nfreq)) >> 1;
             hrow = (const float*)(hc + (int64_t)t * ROW);
             hb = fp_hbase(m2, sh);
         }
@@ -1212,7 +1216,6 @@ __global__ __launch_bounds__(256) void k_transpose_norm_argmax(
 // item of each XCD's own list (see the claim), [12 + b] finished hypothesis groups of block b
 constexpr int PQ_FFT_NEXT = 0, PQ_TR_NEXT = 1, PQ_FFT_XCD = 4, PQ_DONE = 12;
 constexpr int PQ_TILES = 16;  // a tile item = 16 delay tiles of one block, one per wave (~2 MB of HBM traffic at F = 256)
-#define CAF_AS4 __attribute__((address_space(4)))
 
 __device__ __forceinline__ int32_t pq_load(const int32_t* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
