@@ -3,6 +3,8 @@ and the committed golden vectors.  Tolerance: CAF surface within 1e-
 maximum; global (delay, frequency) peak exact; per-delay argmax exact wherever the oracle's top-2
 margin exceeds the tolerance."""
 
+import os
+
 import numpy as np
 import pytest
 
@@ -447,6 +449,45 @@ def test_65536_point_role_explicit_frequencies_and_several_templates():
     np.testing.assert_allclose(sub.row_max.get(), r.row_max.get()[:, 25_000:65_001], atol=2e-6)
     assert int(sub.peak_delay.get()[0]) == 30_000
     p.close()
+
+
+def test_no_surface_items_of_up_to_256_hypotheses():
+    """A launch without |y|^2 tiles that has work items to spare (>= 40 per CU) takes groups of up to 256 hypotheses instead of
+    64 (the running maxima pack the index of a hypothesis within its group into 8 bits).  The same job with the groups pinned
+    to 64 (CAF_HYP_PER_WG) must give the same per-delay maxima bit for bit, the same arguments (float32 ties between two
+    hypotheses of one group aside) and the same peaks -- with planted peaks at hypotheses 0, 124, 125 and 249 of a template,
+    i.e. at both ends of the two groups of 125 the rule forms for 250 bins (from five of 50)."""
+    from pydsproutines_amd import CAFPlan, asarray
+
+    rng = np.random.default_rng(256)
+    n, T, F = 4096, 32, 250
+    m = n + 176 * 12288
+    bins = np.arange(-125, 125)
+    tm = np.stack([qpsk(rng, n) for _ in range(T)])
+    rx = cn(rng, m)
+    truth = {0: (1_000, 0), 5: (500_000, 124), 17: (1_200_345, 125), 31: (m - n, 249)}
+    for i, (d, j) in truth.items():
+        rx[d : d + n] += (tm[i] * np.exp(2j * np.pi * bins[j] / n * np.arange(n))).astype(np.complex64)
+    d_rx = asarray(rx)
+    out = {}
+    for tag, env in (("auto", None), ("pinned", "64")):
+        if env is None:
+            os.environ.pop("CAF_HYP_PER_WG", None)
+        else:
+            os.environ["CAF_HYP_PER_WG"] = env
+        try:
+            p = CAFPlan(tm, max_rx_len=m, bins=bins, grid=n)
+            assert p.engine_used == "persistent"
+            r = p.run(d_rx, surface=False, rows=True, peak=True)
+            out[tag] = (r.row_max.get(), r.row_arg.get(), r.peak_val.get(), r.peak_delay.get(), r.peak_freq.get())
+            p.close()
+        finally:
+            os.environ.pop("CAF_HYP_PER_WG", None)
+    a, b = out["auto"], out["pinned"]
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+    assert np.mean(a[1] == b[1]) > 0.9999 and np.array_equal(a[4], b[4])
+    for i, (d, j) in truth.items():
+        assert (int(a[3][i]), int(a[4][i])) == (d, j) and int(a[1][i][d]) == j
 
 
 def test_65536_point_role_tiles_of_every_second_delay():
