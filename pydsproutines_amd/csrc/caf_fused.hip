@@ -813,7 +813,7 @@ __device__ __forceinline__ void fused_item2q(float2* __restrict__ s_d, const flo
             pt_t bx[8], bh[8];
             batch_issue(bx, bh, c_, caf_ic<0>{}, lz);
             idft16(v1);
-            // e^{+j 2 pi / 32768} on the odd half: the n1 digit of the combination twiddle (fused_item2)
+            // e^{+j 2 pi / 32768} on the odd half: the n1 digit of the combination twiddle
             float2 wj = c == 0 ? w : cmul(w, make_float2(0.99999998161642933f, 1.9174759731070330e-4f));
             asm volatile("" : "+v"(wj.x), "+v"(wj.y));
             float2 p;
@@ -930,7 +930,7 @@ void launch_butterfly_order(const float2* in, float2* out, int64_t nchunks, hipS
 }
 
 // rows of B = 2 * half complex samples -> parity-major: out[r][c][m'] = in[r][2 m' + c]; BFLY: each parity half also in
-// butterfly order (see fp_tid_of), the order in which fused_item2 reads its block spectra once per half-transform
+// butterfly order (see fp_tid_of), the order in which fused_item2q reads its block spectra once per half-transform
 template <bool BFLY>
 __global__ __launch_bounds__(256) void k_parity_major(const float2* __restrict__ in, float2* __restrict__ out, int32_t half) {
     const float2* ir = in + (int64_t)blockIdx.y * 2 * half;
@@ -943,7 +943,7 @@ __global__ __launch_bounds__(256) void k_parity_major(const float2* __restrict__
         orow[half + j] = make_float2(v.z, v.w);
     }
 }
-// rows of B = 4 * quarter complex samples -> PAIRS of the two halves of each parity (fused_item2f):
+// rows of B = 4 * quarter complex samples -> PAIRS of the two halves of each parity (fused_item2q<FOLD>):
 // out[r][c][j] = (in[r][2 m + c], in[r][2 (m + quarter) + c]) as one 16-byte element, m = the butterfly-order source of j
 __global__ __launch_bounds__(256) void k_parity_pairs(const float2* __restrict__ in, float4* __restrict__ out, int32_t quarter) {
     const float2* ir = in + (int64_t)blockIdx.y * 4 * quarter;

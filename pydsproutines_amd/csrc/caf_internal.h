@@ -211,7 +211,7 @@ void launch_fos_scatter(const float2* rows, int64_t b0, int64_t nb, int64_t L, i
 
 // caf_fused.hip
 void launch_parity_major(const float2* in, float2* out, int64_t rows, int32_t half, hipStream_t st, bool butterfly = false);
-// rows of 4 * quarter samples -> [c][quarter] pairs (sample 2 m + c, sample 2 (m + quarter) + c), m in butterfly order (fused_item2f)
+// rows of 4 * quarter samples -> [c][quarter] pairs (sample 2 m + c, sample 2 (m + quarter) + c), m in butterfly order (fused_item2q<FOLD>)
 void launch_parity_pairs(const float2* in, float2* out, int64_t rows, int32_t quarter, hipStream_t st);
 void launch_fused_caf(const float2* xb, const float2* hc, const int32_t* shifts, const float2* tw1,
                       const float2* tw23, int32_t table_mode, int32_t nfreq, int32_t nhyp, int32_t hyp_per_wg,

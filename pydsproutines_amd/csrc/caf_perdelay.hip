@@ -377,7 +377,7 @@ int launch_block_spectra(const float2* rx, int64_t rx_len, int64_t src0, int32_t
 }
 
 // ----------------------------------------------------------------------------------------
-// The same for the 32768-point blocks of fused_item2 (templates of 8193 ... 16384 samples), written directly in the
+// The same for the 32768-point blocks of fused_item2q (templates of 8193 ... 16384 samples), written directly in the
 // layout that role reads: [block][parity c][16384], element m of a half (= X[2 m + c]) at (m & ~1023) + fp_tid_of(m & 1023)
 // ("butterfly order", caf_fft_dev.h).  One decimation-in-frequency step in registers, then the shared 16384-point
 // transform per half:

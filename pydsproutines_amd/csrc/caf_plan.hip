@@ -80,7 +80,7 @@ struct caf_plan_t {
     double* d_prefix = nullptr;
     float* d_inv_e = nullptr;
     float2* d_xb = nullptr;
-    float2* d_xb2 = nullptr;  // 32768-point blocks: the block spectra parity-major (fused_item2)
+    float2* d_xb2 = nullptr;  // 32768-point blocks: the block spectra parity-major (fused_item2q); 65536-point blocks: as parity pairs
     float2* d_pbuf = nullptr;
     PeakRec* d_partial = nullptr;
     bool fused = false;
@@ -194,7 +194,7 @@ static int fused_twiddles(int device, float2** tw1_out, float2** tw23_out) {
             for (int c = 0; c < 64; ++c) tw23[n2 * 64 + c] = cis((double)n2 * c, 1024.0);
         for (int n3 = 0; n3 < 16; ++n3)
             for (int dd = 0; dd < 4; ++dd) tw23[1024 + n3 * 4 + dd] = cis((double)n3 * dd, 64.0);
-        // the same two tables for the ODD half-transform of a 32768-point block (fused_item2): its outputs carry the
+        // the same two tables for the ODD half-transform of a 32768-point block (fused_item2q): its outputs carry the
         // combination twiddle W_32768^{n'}, factor by factor in the pass that produces each output digit
         for (int n2 = 0; n2 < 16; ++n2)
             for (int c = 0; c < 64; ++c) tw23[1088 + n2 * 64 + c] = cis((double)n2 * (2 * c + 1), 2048.0);
