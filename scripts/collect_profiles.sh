@@ -14,7 +14,7 @@ for w in $SRC/*/; do
   mkdir -p $DST/rocprofv3/$n
   cp $w/manifest.json $DST/rocprofv3/$n/
   [ -f $w/manifest_pmc.json ] && cp $w/manifest_pmc.json $DST/rocprofv3/$n/
-  f=$(find $w/trace -name "*kernel_stats.csv" | head -1)
+  f=$(ls -t $(find $w/trace -name "*kernel_stats.csv") 2>/dev/null | head -1)  # the newest (earlier calls' files stay beside it)
   [ -n "$f" ] && cp $f $DST/rocprofv3/$n/trace_kernel_stats.csv
 done
 echo "collected into $DST"

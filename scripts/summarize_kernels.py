@@ -20,8 +20,9 @@ SQ_COUNTERS = ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_I
 
 
 def find(root, pattern):
+    # (the NEWEST match: gpurun merges a call's files into gpurun_out/ beside those of earlier calls, whose process ids differ)
     r = glob.glob(os.path.join(root, "**", pattern), recursive=True)
-    return r[0] if r else None
+    return max(r, key=os.path.getmtime) if r else None
 
 
 def short(name):
