@@ -30,21 +30,38 @@ def sync():
     _lib.check(lib.caf_stream_sync(None))
 
 
+# The trace pass repeats a workload (PROFILE_REPS_SCALE).  Plans, inputs and result buffers of the big launches are kept
+# across the repetitions: a 17 GB surface allocated afresh is touched for the first time by the dispatch that is being timed,
+# and rocprofv3's AVERAGE over the dispatches then reads ~10 % above what a resident buffer gives (median 15.3 ms, minimum
+# 13.7 ms for the C2 launch) -- which is not what bench.py, a pipeline or the kernel's roofline sees.
+_KEEP = {}
+
+
+def keep(key, make):
+    if key not in _KEEP:
+        _KEEP[key] = make()
+    return _KEEP[key]
+
+
 def c2_inputs():
-    t = qpsk(rng, N)
-    rx = cn(rng, M)
-    rx[5_000_000 : 5_000_000 + N] += (t * np.exp(2j * np.pi * 37 * np.arange(N) / N)).astype(np.complex64)
-    return t, asarray(rx)
+    def make():
+        t = qpsk(rng, N)
+        rx = cn(rng, M)
+        rx[5_000_000 : 5_000_000 + N] += (t * np.exp(2j * np.pi * 37 * np.arange(N) / N)).astype(np.complex64)
+        return t, asarray(rx)
+
+    return keep("c2_inputs", make)
 
 
 def caf(engine, surface, T=1, F=256, reps=2, rows=True):
     t, d_rx = c2_inputs()
-    tm = t if T == 1 else np.stack([qpsk(rng, N) for _ in range(T)])
+    key = ("caf", engine, surface, T, F, rows)
     bins = np.arange(-F // 2, F // 2) if F > 1 else [0]
-    plan = CAFPlan(tm, max_rx_len=M, bins=bins, grid=N, engine=engine)
-    res = None
+    plan = keep(key + ("plan",), lambda: CAFPlan(t if T == 1 else np.stack([qpsk(rng, N) for _ in range(T)]), max_rx_len=M,
+                                                 bins=bins, grid=N, engine=engine))
+    st = keep(key + ("res",), dict)
     for _ in range(reps):
-        res = plan.run(d_rx, surface=surface, rows=rows, peak=True, out=res)
+        st["res"] = plan.run(d_rx, surface=surface, rows=rows, peak=True, out=st.get("res"))
     sync()
     B, step, nb = plan.block, plan.step, plan.blocks_per_batch
     nblk = -(-S // step)
@@ -84,7 +101,6 @@ def caf(engine, surface, T=1, F=256, reps=2, rows=True):
         man.append(("k_prefix_tiles|k_scan_tile_sums", "f64 energy prefix of |rx|^2: tile totals, their scan, the write (8 B read + 8 B written per sample)", M * 16.0, 0.0, reps))
         man.append(("k_inv_energy", "1 / window energy (16 B read + 4 B written per delay)", S * 20.0, 0.0, reps))
         man.append(("k_gather_blocks", "overlap-save blocks (8 B read + 8 B written per block point)", nblk * B * 16.0, 0.0, reps))
-    plan.close()
     return man
 
 
@@ -133,12 +149,11 @@ def w_c4_share():
 def w_c2_long_template():
     """C2 shape with a 16384-sample template: 32768-point blocks = two chained 16384-point in-LDS transforms."""
     n = 16384
-    t = qpsk(rng, n)
-    d_rx = asarray(cn(rng, M))
-    plan = CAFPlan(t, max_rx_len=M, bins=np.arange(-128, 128), grid=16384)
-    res = None
+    d_rx = keep("lt_rx", lambda: asarray(cn(rng, M)))
+    plan = keep("lt_plan", lambda: CAFPlan(qpsk(rng, n), max_rx_len=M, bins=np.arange(-128, 128), grid=16384))
+    st = keep("lt_res", dict)
     for _ in range(2):
-        res = plan.run(d_rx, surface=True, out=res)
+        st["res"] = plan.run(d_rx, surface=True, out=st.get("res"))
     sync()
     Sn = M - n + 1
     B, step = plan.block, plan.step
@@ -148,7 +163,6 @@ def w_c2_long_template():
     # re-reads are L2 / Infinity-Cache traffic: visible in FETCH_SIZE, not algorithmic)
     alg = nblk * (tiles * 64 * 256 * 4.0 + 8.0 * B) + Sn * 256 * 8.0 + Sn * 12.0
     flops = nblk * 256 * (2 * 5.0 * 16384 * 14 + 6.0 * B + 10.0 * 16384 + 3.0 * step)
-    plan.close()
     return [("k_caf_persistent", "one-launch engine, N=16384 (B=32768 as 2 x 16384), F=256, surface", alg, flops, 2),
             ("k_block_spectra32", "32768-point block spectra, parity-major + butterfly order: gather, one DIF step, two in-LDS "
              "16384-point transforms (8 B read + 8 B written per point)", nblk * B * 16.0, nblk * (2 * 5.0 * 16384 * 14 + 10.0 * B), 2)]
@@ -157,36 +171,33 @@ def w_c2_long_template():
 def w_c2_surface_t():
     """C2 with the hypothesis-major surface (caf_outputs.d_surface_t): rows written by the FFT items, no tiles."""
     t, d_rx = c2_inputs()
-    plan = CAFPlan(t, max_rx_len=M, bins=np.arange(-128, 128), grid=N)
-    res = None
+    plan = keep("st_plan", lambda: CAFPlan(t, max_rx_len=M, bins=np.arange(-128, 128), grid=N))
+    st = keep("st_res", dict)
     for _ in range(2):
-        res = plan.run(d_rx, surface_t=True, out=res)
+        st["res"] = plan.run(d_rx, surface_t=True, out=st.get("res"))
     sync()
     B, step = plan.block, plan.step
     nblk = -(-S // step)
     # surface written once, (value, hypothesis) pairs per delay and group written + read, traces written, block spectra read
     alg = S * 256 * 4.0 + nblk * (-(-step // 64) * 64 * 4 * 8.0 * 2 + 8.0 * B * 5) + S * 12.0
     flops = nblk * 256 * (5.0 * B * np.log2(B) + 6.0 * B + 3.0 * step)
-    plan.close()
     return [("k_caf_persistent", "one-launch engine, hypothesis-major surface [F][S] written by the FFT items (no tiles)", alg, flops, 2)]
 
 
 def w_c2_lb16():
     """C2 shape with a 32768-sample template: 65536-point blocks in the folded form = two chained 16384-point transforms per output residue."""
     n = 32768
-    t = qpsk(rng, n)
-    d_rx = asarray(cn(rng, M))
-    plan = CAFPlan(t, max_rx_len=M, bins=np.arange(-128, 128), grid=16384)
-    res = None
+    d_rx = keep("lb16_rx", lambda: asarray(cn(rng, M)))
+    plan = keep("lb16_plan", lambda: CAFPlan(qpsk(rng, n), max_rx_len=M, bins=np.arange(-128, 128), grid=16384))
+    st = keep("lb16_res", dict)
     for _ in range(2):
-        res = plan.run(d_rx, surface=True, out=res)
+        st["res"] = plan.run(d_rx, surface=True, out=st.get("res"))
     sync()
     Sn = M - n + 1
     B, step = plan.block, plan.step
     nblk = -(-Sn // step)
     alg = nblk * ((step // 64) * 64 * 256 * 4.0 + 8.0 * B) + Sn * 256 * 8.0 + Sn * 12.0
     flops = nblk * 256 * 2 * (2 * 5.0 * 16384 * 14 + 17.0 * 32768 + 3.0 * 16384)  # per item: two transforms, the fold (2 products + sum [+ twiddle]), |y|^2
-    plan.close()
     return [("k_caf_persistent", "one-launch engine, N=32768 (B=65536 folded: 2 x 16384 per output residue), F=256, surface",
              alg, flops, 2)]
 
