@@ -376,6 +376,13 @@ CAF_EXPORT int32_t caf_steer_dot(const float* d_vec, const double* d_steer, int6
 CAF_EXPORT int32_t caf_sum_planes_qf2(const float* d_planes, int32_t num_planes, int64_t rows, int32_t cols,
                                       const int32_t* h_sel, int32_t num_sel, const double* d_row_norm, double ynormsq,
                                       double* d_out, void* stream);
+/* The coherent sum over the groups of ONE composite template on the per-delay path (GroupXcorrCZT.xcorr,
+ * xcorrRoutines.py:996-1039; GroupXcorrCZT.cpp:106-329): d_planes[num_groups][rows][cols] complex64 = the chirp-Z rows of
+ * every group's products as if the group began at sample 0, d_phase[num_groups][cols] complex64 = e^{-j 2 pi f_col start_g / fs}
+ * (NULL: all ones); d_out[rows][cols] (float64) = |sum_g phase planes|^2 / d_row_norm[row] / ynormsq.  Any number of groups. */
+CAF_EXPORT int32_t caf_sum_groups_qf2(const float* d_planes, int32_t num_groups, int64_t rows, int32_t cols,
+                                      const float* d_phase, const double* d_row_norm, double ynormsq, double* d_out,
+                                      void* stream);
 
 #ifdef __cplusplus
 }

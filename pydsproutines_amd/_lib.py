@@ -162,6 +162,7 @@ _SIGNATURES = {
     "caf_mul_conj": [_P, _P, _I64, _P, _P],
     "caf_steer_dot": [_P, _P, _I64, _I64, ct.c_double, _P, _P],
     "caf_sum_planes_qf2": [_P, _I32, _I64, _I32, _P, _I32, _P, ct.c_double, _P, _P],
+    "caf_sum_groups_qf2": [_P, _I32, _I64, _I32, _P, _P, ct.c_double, _P, _P],
     "caf_comm_unique_id": [_P],
     "caf_comm_create": [ct.POINTER(_P), _I32, _I32, _P],
     "caf_comm_destroy": [_P],

@@ -229,6 +229,8 @@ void launch_steer_dot(const float2* vec, const double2* steer, int64_t rows, int
                       hipStream_t st);
 void launch_sum_planes_qf2(const float2* planes, int64_t plane_elems, int32_t cols, const int32_t* h_idx, int32_t nsel,
                            const double* row_norm, double ynormsq, double* out, hipStream_t st);
+void launch_sum_groups_qf2(const float2* planes, int32_t ngroups, int64_t plane_elems, int32_t cols, const float2* phase,
+                           const double* row_norm, double ynormsq, double* out, hipStream_t st);
 
 // Arguments of the work-queue kernel k_caf_persistent, kept in device memory: each role reads the fields it
 // needs at the start of a work item (scalar loads), so the other role's arguments do not occupy SGPRs.

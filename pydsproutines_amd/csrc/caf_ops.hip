@@ -661,6 +661,16 @@ int32_t caf_sum_planes_qf2(const float* d_planes, int32_t num_planes, int64_t ro
     return CAF_OK;
 }
 
+int32_t caf_sum_groups_qf2(const float* d_planes, int32_t num_groups, int64_t rows, int32_t cols, const float* d_phase,
+                           const double* d_row_norm, double ynormsq, double* d_out, void* stream) {
+    CAF_REQUIRE(d_planes && d_row_norm && d_out && num_groups >= 1 && rows >= 1 && cols >= 1, "caf_sum_groups_qf2: bad arguments");
+    CAF_REQUIRE(ynormsq > 0.0, "caf_sum_groups_qf2: ynormsq must be positive");
+    launch_sum_groups_qf2((const float2*)d_planes, num_groups, rows * cols, cols, (const float2*)d_phase, d_row_norm, ynormsq, d_out,
+                          (hipStream_t)stream);
+    CAF_HIP_TRY(hipGetLastError());
+    return CAF_OK;
+}
+
 int32_t caf_zoom_num_bins(double span, double step, int32_t* num_bins) {
     CAF_REQUIRE(num_bins && span > 0.0 && step > 0.0 && span / step < 1e6, "caf_zoom_num_bins: bad span/step");
     *num_bins = zoom_num_bins(span, step);

@@ -247,7 +247,7 @@ int32_t caf_last_error(char* buf, int32_t len) {
     return CAF_OK;
 }
 
-int32_t caf_abi_version(void) { return (1 << 16) | 6; }  // minor: +1 per batch of added entry points
+int32_t caf_abi_version(void) { return (1 << 16) | 7; }  // minor: +1 per batch of added entry points
 
 int32_t caf_device_count(int32_t* count) {
     CAF_REQUIRE(count, "count is NULL");

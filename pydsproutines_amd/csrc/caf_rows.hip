@@ -1476,6 +1476,38 @@ void launch_sum_planes_qf2(const float2* planes, int64_t plane_elems, int32_t co
                        out);
 }
 
+// Coherent sum over the GROUPS of a composite template on the per-delay path (GroupXcorrCZT.xcorr, xcorrRoutines.py:996-1039;
+// GroupXcorrCZT.cpp:106-329): planes[g][row][col] = the chirp-Z transform of group g's product row at delay `row`, evaluated
+// as if the group began at sample 0; phase[g][col] = e^{-j 2 pi f_col start_g / fs} moves it to where the group lies.
+//   out[row][col] = | sum_g phase[g][col] planes[g][row][col] |^2 / row_norm[row] / ynormsq
+// (float32 products and sum like the upstream complex64 arithmetic, float64 normalisation).  Any number of groups.
+__global__ __launch_bounds__(256) void k_sum_groups_qf2(const float2* __restrict__ planes, int32_t ngroups, int64_t plane_elems,
+                                                        int32_t cols, const float2* __restrict__ phase,
+                                                        const double* __restrict__ row_norm, double ynormsq,
+                                                        double* __restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < plane_elems; e += stride) {
+        const int64_t row = e / cols;
+        const int col = (int)(e - row * cols);
+        float2 acc = make_float2(0.f, 0.f);
+        for (int g = 0; g < ngroups; ++g) {
+            const float2 v = planes[(int64_t)g * plane_elems + e];
+            const float2 p = phase ? phase[(int64_t)g * cols + col] : make_float2(1.f, 0.f);
+            acc.x += v.x * p.x - v.y * p.y;
+            acc.y += v.x * p.y + v.y * p.x;
+        }
+        const float m = acc.x * acc.x + acc.y * acc.y;
+        out[e] = (double)m / row_norm[row] / ynormsq;
+    }
+}
+
+void launch_sum_groups_qf2(const float2* planes, int32_t ngroups, int64_t plane_elems, int32_t cols, const float2* phase,
+                           const double* row_norm, double ynormsq, double* out, hipStream_t st) {
+    const unsigned g = std::min<unsigned>(cdiv(plane_elems, 256), 256 * 16);
+    hipLaunchKernelGGL(k_sum_groups_qf2, dim3(g), dim3(256), 0, st, planes, ngroups, plane_elems, cols, phase, row_norm, ynormsq,
+                       out);
+}
+
 // Sub-sample refinement after the peak (fineFreqTimeSearch / GenXcorr, xcorrRoutines.py:583-719):
 //   k_mul_conj : out[i] = a[i] * conj(b[i])                       (x_fft * y_fft.conj(), y.conj() * x, masks)
 //   k_steer_dot: out[r] = scale * sum_k vec[k] * conj(steer[r][k]) (np.dot(rx_vec, steeringvec.conj().T), np.vdot)

@@ -247,6 +247,7 @@ class _GroupEngine:
         self._comp, self._rel, self._len = comp, rel_starts, lengths
         self._autoConj, self._bins, self._grid, self._fn = autoConj, bins, grid, freqs_norm
         self._plan, self._plan_len = None, -1
+        self._rows_state = None
 
     def _get_plan(self, rx_len):
         if self._plan is None or rx_len > self._plan_len:
@@ -260,10 +261,88 @@ class _GroupEngine:
 
     def _run(self, rx, shifts, **kw):
         d_rx = rx if isinstance(rx, DeviceArray) else asarray(_c64(np.asarray(rx)))  # device input stays where it is
+        if kw.get("surface") and not kw.get("rows", True) and not kw.get("peak", True) and self._rows_path_pays(shifts):
+            return self._run_rows(d_rx, np.asarray(shifts))
         plan = self._get_plan(d_rx.size)
         lo, cnt, rel = _engine_range(shifts)
         res = plan.run(d_rx, shift_start=lo, num_shifts=cnt, **kw)
         return res, rel
+
+    # -- the per-delay form for FEW delays over a LONG composite template ---------------------------------------
+    # The hypothesis engine transforms whole overlap-save blocks of at least twice the template span per frequency:
+    # the reference's benchmark_groupXcorrs.py (100 groups of 5000 samples spread over 10^6, 41 shifts, 201 CZT bins)
+    # is one 2^21-point block per bin -- 8 ms.  The reference's own algorithm (xcorrRoutines.py:996-1039,
+    # GroupXcorrCZT.cpp:106-329) is per delay and per group: product row, chirp-Z transform, phase of the group's
+    # start, coherent sum.  For equal-length groups on a CZT grid that is ONE indexed product launch for all
+    # (group, delay) rows, ONE batched CZT and one sum over the groups (caf_sum_groups_qf2).
+    _czt_grid = None      # (f1, f2, binWidth, fs) when the frequency list is such a grid
+    _force_rows = None    # tests: True / False pins the path
+
+    def _rows_path_pays(self, shifts):
+        if self._czt_grid is None or np.unique(self._len).size != 1:
+            return False
+        if self._force_rows is not None:
+            return bool(self._force_rows)
+        S, G, L = int(np.asarray(shifts).size), int(self._len.size), int(self._len[0])
+        k = int(np.asarray(self._fn).size)
+        nfft = 1 << int(np.ceil(np.log2(L + k - 1)))
+        rows_cost = 3.0 * S * G * nfft * np.log2(nfft)
+        lo, cnt, _ = _engine_range(shifts)
+        blk = 1 << int(np.ceil(np.log2(2 * self._span)))  # the engine's block for a template of this span (>= 2 N)
+        nblk = -(-cnt // max(1, blk - self._span + 1))
+        engine_cost = 1.0 * k * nblk * blk * np.log2(blk)
+        return self._span > 32768 and rows_cost * 2 < engine_cost  # (the in-LDS engines up to 32768 samples: always the engine)
+
+    def _run_rows(self, d_rx, shifts):
+        f1, f2, bw, fs = self._czt_grid
+        G, L, S = int(self._len.size), int(self._len[0]), int(shifts.size)
+        lib = _lib.load()
+        st = getattr(self, "_rows_state", None)
+        if st is None:
+            tm = np.stack([self._comp[r : r + L] for r in self._rel])
+            if self._autoConj:
+                tm = tm.conj()
+            czt = CZTCachedGPU(L, f1, f2, bw, fs)
+            ph = np.exp(-2j * np.pi * np.outer(self._rel.astype(np.float64), czt.getFreq()) / fs).astype(np.complex64)
+            st = self._rows_state = dict(d_tm=asarray(_c64(tm)), czt=czt, d_ph=asarray(ph),
+                                         ynormsq=float(np.sum(np.abs(tm.astype(np.complex128)) ** 2)))
+        czt, k = st["czt"], st["czt"].k
+        assert k == int(np.asarray(self._fn).size), "CZT grid and frequency list disagree"
+        starts = (shifts[None, :].astype(np.int64) + self._rel[:, None]).reshape(-1)  # [g][s]
+        assert starts.min() >= 0 and starts.max() + L <= d_rx.size
+        d_starts = asarray(starts.astype(np.int32))
+        d_len = asarray(np.full(G * S, L, np.int32))
+        d_row = asarray(np.repeat(np.arange(G, dtype=np.int32), S))
+        d_mul = empty((G * S, L), np.complex64)
+        _lib.check(lib.caf_multiply_slices_indexed_rows(ct.c_void_p(d_rx.ptr), d_rx.size, ct.c_void_p(st["d_tm"].ptr), G, L,
+                                                        ct.c_void_p(d_starts.ptr), ct.c_void_p(d_len.ptr), ct.c_void_p(d_row.ptr),
+                                                        L, G * S, ct.c_void_p(d_mul.ptr), None), "caf_multiply_slices_indexed_rows")
+        d_planes = czt.runMany(d_mul)  # (G S, k) complex64
+        # rx energy under the groups at every delay: one moving sum of |rx|^2, one gather, summed over the groups on the host
+        d_msum = cupyMovingAverage(cupyComplexMagnSq(d_rx, np.float32), L, sumInstead=True)
+        d_e = empty((G * S,), np.float32)
+        d_ei = asarray((starts + L - 1).astype(np.int32))
+        _lib.check(lib.caf_gather_b32(ct.c_void_p(d_msum.ptr), d_msum.size, ct.c_void_p(d_ei.ptr), G * S, ct.c_void_p(d_e.ptr), None),
+                   "caf_gather_b32")
+        d_norm = asarray(d_e.get().astype(np.float64).reshape(G, S).sum(axis=0))
+        d_out = empty((S, k), np.float64)
+        _lib.check(lib.caf_sum_groups_qf2(ct.c_void_p(d_planes.ptr), G, S, k, ct.c_void_p(st["d_ph"].ptr), ct.c_void_p(d_norm.ptr),
+                                          st["ynormsq"], ct.c_void_p(d_out.ptr), None), "caf_sum_groups_qf2")
+        return _RowsResult(d_out), np.arange(S)
+
+
+class _RowsResult:
+    """What _GroupEngine._run hands back from the per-delay form: ``surface.get()`` -> float32 (1, S, k) like a CAFResult's."""
+
+    class _Surface:
+        def __init__(self, d):
+            self._d = d
+
+        def get(self):
+            return self._d.get().astype(np.float32)[None]
+
+    def __init__(self, d_out):
+        self.surface = self._Surface(d_out)
 
 
 class GroupXcorr(_GroupEngine):
@@ -317,6 +396,7 @@ class GroupXcorrCZT(_GroupEngine):
         self._k = int((f2 - f1) / binWidth + 1)
         self._freq = np.arange(f1, f2 + binWidth / 2, binWidth)
         self._setup(groups, self.starts - self.starts[0], lengths, autoConj, freqs_norm=self._freq[: self._k] / fs)
+        self._czt_grid = (f1, f2, binWidth, fs)
         self._first = int(self.starts[0])
 
     def xcorr(self, rx, shifts=None):
@@ -633,6 +713,7 @@ class pbIppGroupXcorrCZT(_GroupEngine):
     def resetGroups(self):
         self._gstarts, self._groups = [], []
         self._plan, self._plan_len = None, -1
+        self._ready = False  # the composite template (and what either engine keeps for it) is built at the next xcorr
 
     def addGroup(self, start, group, autoConj=True):
         group = np.asarray(group)
@@ -650,6 +731,7 @@ class pbIppGroupXcorrCZT(_GroupEngine):
         self._gstarts.append(int(start))
         self._groups.append(group.conj() if autoConj else group.copy())
         self._plan = None
+        self._ready = False
 
     def addGroupsFromArray(self, starts, lengths, arr, autoConj=True):
         starts = np.asarray(starts)
@@ -672,7 +754,7 @@ class pbIppGroupXcorrCZT(_GroupEngine):
                 raise IndexError("Shifts accesses negative indices!")
             if xi + numShifts * shiftStep + g.size >= x.size:
                 raise IndexError("Input length is insufficient for search range!")
-        if self._plan is None:
+        if not self._ready:
             order = np.argsort(self._gstarts)
             gst = np.asarray(self._gstarts)[order]
             lens = np.asarray([self._groups[i].size for i in order])
@@ -680,6 +762,8 @@ class pbIppGroupXcorrCZT(_GroupEngine):
             # stored groups are already conjugated when autoConj was requested
             self._base = int(gst[0])
             self._setup([self._groups[i] for i in order], gst - gst[0], lens, False, freqs_norm=freqs)
+            self._czt_grid = (self._f1, self._f2, self._fstep, self._fs)
+            self._ready = True
         shifts = shiftStart + self._base + shiftStep * np.arange(numShifts)
         res, rel = self._run(x, shifts, surface=True, rows=False, peak=False)
         return res.surface.get()[0][rel]

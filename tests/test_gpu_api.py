@@ -319,6 +319,60 @@ def test_kat1_groupxcorrczt_and_pybind_twin(golden):
         pbIppGroupXcorrCZT(12, -0.1, 0.1, 0.1, 100.0, 0)
 
 
+def test_groupxcorrczt_per_delay_form_for_few_shifts(golden):
+    """GroupXcorrCZT / pbIppGroupXcorrCZT with few shifts over a long composite template take the reference's own per-delay
+    form (product rows of every (group, shift), one batched CZT, phases of the group starts and the coherent sum in
+    caf_sum_groups_qf2) instead of one overlap-save block of twice the template span per frequency.  KAT-1 through that form
+    against the reference's golden numbers; the reference's benchmark_groupXcorrs.py shape (reduced) through both forms."""
+    from pydsproutines_amd.signalCreationRoutines import randPSKsyms
+    from pydsproutines_amd.xcorrRoutines import GroupXcorrCZT, pbIppGroupXcorrCZT
+
+    g = golden("kat1_kat3_czt")
+    data, starts, lengths, sh = g["kat1_data"], g["kat1_starts"], g["kat1_lengths"], g["kat1_shifts"]
+    if np.unique(lengths).size == 1:  # (the per-delay form needs groups of one length)
+        obj = GroupXcorrCZT(data, starts, lengths, -0.1, 0.1, 0.1, 100)
+        obj._force_rows = True
+        xc, f = obj.xcorr(data, sh)
+        np.testing.assert_allclose(xc, g["kat1_qf2"], atol=TOL)
+    # benchmark_groupXcorrs.py:19-72 at a fifth of its size: 20 groups of 5000 samples, every second 5000 of 200000
+    np.random.seed(5)
+    x, _ = randPSKsyms(200_000, 4, dtype=np.complex64)
+    f1, f2, fstep, fs = -100.0, 100.0, 1.0, 10000
+    first, L = 100, 5000
+    gstarts = np.arange(first, x.size, 2 * L, dtype=np.int32)
+    shifts = np.arange(first - 20, first - 20 + 41)
+    out = {}
+    for force in (None, True, False):
+        gxc = GroupXcorrCZT(x, gstarts, np.zeros(gstarts.size, dtype=np.int32) + L, f1, f2, fstep, fs)
+        gxc._force_rows = force
+        if force is None:
+            assert gxc._rows_path_pays(shifts + int(gxc.starts[0]))  # the rule picks the per-delay form by itself here
+        res, freq = gxc.xcorr(x, shifts)
+        assert res.shape == (41, 201) and res.dtype == np.float64 and freq.size == 201
+        assert np.unravel_index(np.argmax(res), res.shape) == (20, 100) and abs(res[20, 100] - 1.0) < 1e-3
+        out[force] = res
+    np.testing.assert_array_equal(out[None], out[True])
+    np.testing.assert_allclose(out[True], out[False], atol=2e-5)
+    pb = pbIppGroupXcorrCZT(L, f1, f2, fstep, fs, 4)
+    for gs in gstarts:
+        pb.addGroup(gs - first, x[gs : gs + L])
+    pres = pb.xcorr(x, first - 20, 1, 41)
+    assert pres.dtype == np.float32 and pres.shape == (41, 201)
+    np.testing.assert_allclose(pres, out[True], atol=1e-6)
+    # the definition at a few cells (float64, product by product)
+    k = np.arange(L)
+    for (si, fi) in ((20, 100), (0, 0), (40, 200), (7, 133)):
+        acc, e_rx, e_t = 0.0 + 0.0j, 0.0, 0.0
+        fr = (f1 + fi * fstep) / fs
+        for gs in gstarts:
+            seg = x[shifts[si] - first + gs : shifts[si] - first + gs + L].astype(np.complex128)
+            tg = x[gs : gs + L].astype(np.complex128)
+            acc += np.sum(seg * np.conj(tg) * np.exp(-2j * np.pi * fr * (gs - first + k)))
+            e_rx += np.sum(np.abs(seg) ** 2)
+            e_t += np.sum(np.abs(tg) ** 2)
+        assert abs(out[True][si, fi] - abs(acc) ** 2 / e_rx / e_t) < 2e-5
+
+
 def test_permutations_and_groupxcorrgpu(golden):
     """GroupXcorrCZT_Permutations (CPU-flavour ``xcorr``/``getCAF`` and GPU-flavour ``xcorrGPU``/``getCAF_GPU``)
     and GroupXcorrGPU against the golden vectors made with the reference's GroupXcorrCZT / GroupXcorr."""
