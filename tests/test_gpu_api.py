@@ -334,6 +334,19 @@ def test_groupxcorrczt_per_delay_form_for_few_shifts(golden):
         obj._force_rows = True
         xc, f = obj.xcorr(data, sh)
         np.testing.assert_allclose(xc, g["kat1_qf2"], atol=TOL)
+    # the oracle's GroupXcorrCZT (pinned to the imported reference by KAT-1) on equal-length groups, through the per-delay form
+    rng = np.random.default_rng(77)
+    y = cn(rng, 4000)
+    st4, ln4 = np.array([50, 700, 1900, 3100]), np.array([300, 300, 300, 300])
+    rx4 = np.concatenate((cn(rng, 37), y * np.exp(2j * np.pi * 12.0 * np.arange(y.size) / 1000.0))).astype(np.complex64) + 0.3 * cn(rng, 4037)
+    sh4 = np.arange(80, 95)  # the first group starts at 37 + 50
+    ref4, rf4 = O.GroupXcorrCZT(y, st4, ln4, -20.0, 20.0, 0.5, 1000.0).xcorr(rx4, sh4)
+    obj4 = GroupXcorrCZT(y, st4, ln4, -20.0, 20.0, 0.5, 1000.0)
+    obj4._force_rows = True
+    got4, gf4 = obj4.xcorr(rx4, sh4)
+    np.testing.assert_allclose(gf4, rf4, atol=1e-12)
+    np.testing.assert_allclose(got4, ref4, atol=TOL)
+    assert np.unravel_index(np.argmax(got4), got4.shape) == (7, 64)  # shift 87, +12 Hz
     # benchmark_groupXcorrs.py:19-72 at a fifth of its size: 20 groups of 5000 samples, every second 5000 of 200000
     np.random.seed(5)
     x, _ = randPSKsyms(200_000, 4, dtype=np.complex64)
