@@ -202,6 +202,37 @@ def fastXcorr(cutout, rx, freqsearch=False, outputCAF=False, shifts=None, absRes
     return out
 
 
+_CZTXCORR_FORCE_ROWS = None  # tests: True / False pins cztXcorr's path
+
+
+_CZT_OBJECTS = {}  # the last few CZT objects of cztXcorr's per-delay form (chirps + transform plans: milliseconds to build)
+
+
+def _czt_object(n, f1, f2, step, fs):
+    key = (int(n), float(f1), float(f2), float(step), float(fs))
+    obj = _CZT_OBJECTS.pop(key, None)
+    if obj is None:
+        obj = CZTCachedGPU(n, f1, f2, step, fs)
+    _CZT_OBJECTS[key] = obj  # (most recently used last)
+    while len(_CZT_OBJECTS) > 4:
+        _CZT_OBJECTS.pop(next(iter(_CZT_OBJECTS)))
+    return obj
+
+
+def _czt_rows_pay(n, k, cnt):
+    """Per-delay CZT rows (3 transforms of nfft >= n + k - 1 per delay) against k hypotheses over overlap-save blocks of the
+    engine's size for an n-sample template (caf_plan.hip: 16 n clipped to 2^12 .. 2^18, at least 2 n)."""
+    nfft = 1 << int(np.ceil(np.log2(n + k - 1)))
+    rows_cost = 3.0 * cnt * nfft * np.log2(nfft)
+    lb = max(min(max(int(np.ceil(np.log2(16 * n))), 12), 18), int(np.ceil(np.log2(2 * n))))
+    nblk = -(-cnt // ((1 << lb) - n + 1))
+    engine_cost = float(k) * nblk * (1 << lb) * lb
+    # (rows of up to 32768 points: one rocFFT kernel per transform.  Longer rows -- measured with 65536- and 131072-point rows of
+    #  a 50000 / 100000-sample cutout, 201 delays -- run 1-4 ms for the first calls and then settle at exactly 100 ms per call,
+    #  a wait inside the runtime that the engine's launches do not meet: profiles/r04/timing_cztxcorr.log)
+    return nfft <= 32768 and rows_cost * 2 < engine_cost
+
+
 def cztXcorr(cutout, rx, f_searchMin, f_searchMax, fs, cztStep=0.1, outputCAF=False, shifts=None):
     """ref: xcorrRoutines.py:413-457.  The frequency grid is the reference's CZT grid, evaluated as explicit
     hypotheses: k = int((f2-f1)/cztStep + 1) bins, reported as f1 + i*cztStep (CZTCached.getFreq), computed
@@ -218,9 +249,25 @@ def cztXcorr(cutout, rx, f_searchMin, f_searchMax, fs, cztStep=0.1, outputCAF=Fa
         shifts = np.arange(len(rx) - n + 1)
     shifts = np.asarray(shifts)
     lo, cnt, rel = _engine_range(shifts)
+    d_rx = asarray(_c64(rx))
+    if _czt_rows_pay(n, k, cnt) if _CZTXCORR_FORCE_ROWS is None else _CZTXCORR_FORCE_ROWS:
+        # Few delays: the reference's own per-delay form (product row, CZT, norms: xcorrRoutines.py:436-452) as the kernel chain
+        # of cp_fastXcorr_v2 -- sliding normalised products, ONE batched CZT, argmax per row -- instead of k hypotheses over
+        # whole overlap-save blocks.  Same chirp as the engine's frequency list (CZTCached's W, see above).
+        czt = _czt_object(n, f_searchMin, f_searchMax, cztStep, fs)
+        assert czt.k == k
+        d_pdts = multiplySlidesNormalised(asarray(_c64(cutout).conj()), d_rx, lo, cnt)
+        d_spec = czt.runMany(d_pdts)  # (cnt, k) complex QF
+        if outputCAF:
+            out = empty((cnt, k), np.float32)
+            _lib.check(_lib.load().caf_complex_magnsq(ct.c_void_p(d_spec.ptr), d_spec.size, 0, ct.c_void_p(out.ptr), 0, None))
+            return out.get()[rel].astype(np.float64), f_search
+        spec = d_spec.get()[rel]
+        mi = np.argmax(np.abs(spec), axis=1)
+        result = spec[np.arange(rel.size), mi].astype(rx.dtype if np.iscomplexobj(rx) else np.complex64)
+        return result, f_search[mi].astype(np.float64)
     plan = CAFPlan(_c64(cutout), max_rx_len=len(rx), freqs_norm=f_eval / fs,
                    engine="auto" if outputCAF else "rocfft")
-    d_rx = asarray(_c64(rx))
     if outputCAF:
         res = plan.run(d_rx, shift_start=lo, num_shifts=cnt, surface=True, rows=False, peak=False)
         out = res.surface.get()[0][rel].astype(np.float64)
@@ -291,7 +338,8 @@ class _GroupEngine:
         blk = 1 << int(np.ceil(np.log2(2 * self._span)))  # the engine's block for a template of this span (>= 2 N)
         nblk = -(-cnt // max(1, blk - self._span + 1))
         engine_cost = 1.0 * k * nblk * blk * np.log2(blk)
-        return self._span > 32768 and rows_cost * 2 < engine_cost  # (the in-LDS engines up to 32768 samples: always the engine)
+        # (templates of up to 32768 samples: the in-LDS engines, always; rows longer than 32768 points: see _czt_rows_pay)
+        return self._span > 32768 and nfft <= 32768 and rows_cost * 2 < engine_cost
 
     def _run_rows(self, d_rx, shifts):
         f1, f2, bw, fs = self._czt_grid

@@ -161,9 +161,14 @@ def test_cp_fastxcorr_v2_and_kernel_chain():
 
 
 # ---- grouped templates ----------------------------------------------------------------------
-def test_cztxcorr(golden):
+@pytest.mark.parametrize("rows_path", [None, False, True])
+def test_cztxcorr(golden, rows_path, monkeypatch):
+    """cztXcorr against the reference's outputs through both of its forms: hypotheses over overlap-save blocks (False) and the
+    reference's own per-delay product / CZT rows (True: what few shifts over a long cutout take); None = the cost rule."""
+    import pydsproutines_amd.xcorrRoutines as X
     from pydsproutines_amd.xcorrRoutines import cztXcorr
 
+    monkeypatch.setattr(X, "_CZTXCORR_FORCE_ROWS", rows_path)
     g = golden("cztxcorr_small")
     fs = float(g["fs"][0])
     caf, f = cztXcorr(g["cutout"], g["rx"], -20.0, 20.0, fs, 0.5, True, g["shifts"])
@@ -187,6 +192,25 @@ def test_cztxcorr(golden):
     clear = top2[:, 1] - top2[:, 0] > 1e-4
     np.testing.assert_array_equal(fpk[clear], g["fpk"][clear])
     np.testing.assert_allclose(res[clear], g["res"][clear], atol=TOL)
+    if rows_path is None:
+        # the rule: a fine search over a handful of delays of a long cutout is the per-delay form, everything else the engine
+        assert X._czt_rows_pay(20_000, 401, 101) and X._czt_rows_pay(4096, 129, 8)
+        assert not X._czt_rows_pay(200, 201, 1800) and not X._czt_rows_pay(4096, 256, 1 << 20)
+        assert not X._czt_rows_pay(100_000, 2001, 200)  # (rows longer than 32768 points stay on the engine)
+        # ... and both forms agree on such a case: 20000-sample cutout, 21 delays around the truth, 401 bins
+        rng = np.random.default_rng(9)
+        cut = cn(rng, 20_000)
+        rx = (0.5 * cn(rng, 30_000)).astype(np.complex64)
+        rx[5_003 : 5_003 + cut.size] += (cut * np.exp(2j * np.pi * 3.7 * np.arange(cut.size) / 1e5)).astype(np.complex64)
+        sh = np.arange(4_993, 5_014)
+        out = {}
+        for force in (True, False):
+            monkeypatch.setattr(X, "_CZTXCORR_FORCE_ROWS", force)
+            out[force] = (cztXcorr(cut, rx, -20.0, 20.0, 1e5, 0.1, True, sh), cztXcorr(cut, rx, -20.0, 20.0, 1e5, 0.1, False, sh))
+        np.testing.assert_allclose(out[True][0][0], out[False][0][0], atol=TOL)
+        assert np.unravel_index(np.argmax(out[True][0][0]), out[True][0][0].shape) == (10, 237)
+        np.testing.assert_array_equal(out[True][1][1], out[False][1][1])
+        np.testing.assert_allclose(out[True][1][0], out[False][1][0], atol=TOL)
 
 
 def test_groupxcorr_family(golden):
