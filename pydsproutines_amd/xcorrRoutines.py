@@ -412,6 +412,14 @@ class GroupXcorr(_GroupEngine):
         self.yconcatNormSq = float(np.sum(np.abs(self.yconcat.astype(np.complex128)) ** 2))
         self._setup(groups, self.starts - self.starts[0], lengths, autoConj, freqs_norm=self.freqs / fs)
         self._first = int(self.starts[0])
+        # a uniformly spaced frequency list is a CZT grid: few shifts over a long composite template can then take the
+        # per-delay form of _GroupEngine (the maximum over the frequencies is taken from its (S, k) plane)
+        if self.freqs.size >= 2:
+            bw = float(self.freqs[1] - self.freqs[0])
+            if bw > 0 and np.allclose(np.diff(self.freqs), bw, rtol=0, atol=1e-9 * max(1.0, abs(bw))):
+                f1, f2 = float(self.freqs[0]), float(self.freqs[-1])
+                if int((f2 - f1) / bw + 1) == self.freqs.size:
+                    self._czt_grid = (f1, f2, bw, fs)
 
     def xcorr(self, rx, shifts=None):
         rx = np.asarray(rx)
@@ -420,6 +428,12 @@ class GroupXcorr(_GroupEngine):
         else:
             shifts = np.asarray(shifts)
             assert shifts[-1] + self.starts[-1] + self.lengths[-1] < rx.size
+        if self._rows_path_pays(shifts + self._first):
+            d_rx = asarray(_c64(rx))
+            res, _ = self._run_rows(d_rx, shifts + self._first)
+            plane = res.surface.get()[0]
+            mi = np.argmax(plane, axis=1)
+            return plane[np.arange(mi.size), mi].astype(np.float64), self.freqs[mi]
         res, rel = self._run(rx, shifts + self._first, rows=True, peak=False)
         xc = res.row_max.get()[0][rel].astype(np.float64)
         return xc, self.freqs[res.row_arg.get()[0][rel]]

@@ -371,6 +371,22 @@ def test_groupxcorrczt_per_delay_form_for_few_shifts(golden):
     np.testing.assert_allclose(gf4, rf4, atol=1e-12)
     np.testing.assert_allclose(got4, ref4, atol=TOL)
     assert np.unravel_index(np.argmax(got4), got4.shape) == (7, 64)  # shift 87, +12 Hz
+    # GroupXcorr with a uniformly spaced frequency list rides on the same form (maximum over the plane's frequencies)
+    from pydsproutines_amd.xcorrRoutines import GroupXcorr
+
+    fl = np.arange(-20.0, 20.25, 0.5)
+    gx = GroupXcorr(y, st4, ln4, fl, 1000.0)
+    assert gx._czt_grid is not None
+    gx._force_rows = True
+    xa, fa = gx.xcorr(rx4, sh4)
+    gx2 = GroupXcorr(y, st4, ln4, fl, 1000.0)
+    gx2._force_rows = False
+    xb, fb = gx2.xcorr(rx4, sh4)
+    xo, fo = O.GroupXcorr(y, st4, ln4, fl, 1000.0).xcorr(rx4, sh4)
+    np.testing.assert_allclose(xa, xb, atol=TOL)
+    np.testing.assert_allclose(xa, xo, atol=TOL)
+    assert xa.dtype == np.float64 and fa[7] == 12.0 and fb[7] == 12.0 and fo[7] == 12.0
+    assert GroupXcorr(y, st4, ln4, np.array([-3.0, 0.0, 1.0, 7.5]), 1000.0)._czt_grid is None  # (no grid: the engine)
     # benchmark_groupXcorrs.py:19-72 at a fifth of its size: 20 groups of 5000 samples, every second 5000 of 200000
     np.random.seed(5)
     x, _ = randPSKsyms(200_000, 4, dtype=np.complex64)
