@@ -36,6 +36,7 @@ F_BINS = 256
 D0 = 5_000_000
 K0 = 37
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_ACHIEVABLE_GBS = 6300.0  # ibid.: what streaming kernels reach
 
 
 def make_inputs(torch, device, rank):
@@ -465,18 +466,23 @@ def launch_ranks(n, argv):
               "on fewer GPUs over gloo)" % (n, have, n), file=sys.stderr)
         return 2
     # The rendezvous port is found by binding to port 0 and closing again, so another process can take it before rank 0
-    # binds it: a world that fails within its first 30 s is started again on a fresh port (twice at most).
+    # binds it.  ONLY that failure is retried (twice at most, on a fresh port): a child whose init_process_group raised exits
+    # with RC_RENDEZVOUS before it has run anything on the GPU.  Every other failure -- a rank that found a wrong peak, died
+    # from a GPU fault or a signal -- is reported at once with the rank codes and never run again.
     for attempt in range(3):
-        t_attempt = time.monotonic()
         rc = _launch_once(n, argv)
-        if rc == 0 or rc == 3 or time.monotonic() - t_attempt > 30.0 or attempt == 2:
-            return 1 if rc == 3 else rc
+        if rc != RC_RENDEZVOUS or attempt == 2:
+            return 1 if rc in (3, RC_RENDEZVOUS) else rc
         print("bench.py --gpus %d: the world did not form (attempt %d); trying another port" % (n, attempt + 1), file=sys.stderr)
     return 1
 
 
+RC_RENDEZVOUS = 4  # exit code of a rank whose torch.distributed rendezvous failed (nothing has run on the GPU yet)
+
+
 def _launch_once(n, argv):
-    """One attempt of launch_ranks: 0 = rank 0's line printed, 1 = a rank failed, 3 = the world formed with the wrong size."""
+    """One attempt of launch_ranks: 0 = rank 0's line printed, 1 = a rank failed, 3 = the world formed with the wrong size,
+    RC_RENDEZVOUS = the world did not form (some rank's init_process_group failed and no rank failed any other way)."""
     import socket
     import subprocess
 
@@ -520,7 +526,9 @@ def _launch_once(n, argv):
     line = [ln for ln in (out0 or "").splitlines() if ln.startswith("{")]
     if any(codes) or not line:
         print("bench.py --gpus %d: rank exit codes %r" % (n, codes), file=sys.stderr)
-        return 1
+        # (the ranks ended by terminate() after the first failure report -15: they did not fail by themselves)
+        own = [c for c in codes if c not in (0, -15)]
+        return RC_RENDEZVOUS if own and all(c == RC_RENDEZVOUS for c in own) else 1
     if json.loads(line[-1]).get("n_gpus") != n:
         print("bench.py --gpus %d: the world that formed reports n_gpus=%r" % (n, json.loads(line[-1]).get("n_gpus")), file=sys.stderr)
         return 3
@@ -584,10 +592,16 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearse:
-            dist.init_process_group(backend="gloo")
-        else:
-            dist.init_process_group(backend="nccl", device_id=device)
+        try:
+            if rehearse:
+                dist.init_process_group(backend="gloo")
+            else:
+                dist.init_process_group(backend="nccl", device_id=device)
+        except tuple(getattr(dist, n) for n in ("DistNetworkError", "DistStoreError") if hasattr(dist, n)) as e:
+            # the store could not bind / connect (port taken, peers never arrived): the one failure launch_ranks() starts
+            # again for.  A backend (RCCL) error is not caught here and fails the run.
+            print("rank %d: rendezvous failed: %r" % (rank, e), file=sys.stderr)
+            sys.exit(RC_RENDEZVOUS)
 
     from pydsproutines_amd import CAFPlan, _lib
     from pydsproutines_amd.caf import CAFResult
@@ -689,13 +703,54 @@ def main():
         extra = {"ms_per_step": dt * 1e3, "value": S / dt / 1e6, "unit": "Msamples/s",
                  "what": "same workload without the CAF surface (per-delay argmax + peak only)"}
 
+    # second side figure: the same surface written hypothesis-major ([F][S]: the FFT items write their own row segments, no
+    # |y|^2 tiles, no tile role) -- what the host-returning entry points run since round 5 (xcorrRoutines._host_surface)
+    extra_t = None
+    if world == 1 and surface_on and not args.no_side_figure and plan.engine_used == "persistent" and plan.block == 16384:
+        stream = torch.cuda.current_stream().cuda_stream
+        t_surface = None  # (the delay-major surface is checked and done with: its 17 GB go back to torch's allocator)
+        res.surface = None
+        t_surface_t = torch.empty((1, F_BINS, S), dtype=torch.float32, device=device)
+        res_t = CAFResult()
+        res_t.surface_t = DeviceArray((1, F_BINS, S), np.float32, ptr=t_surface_t.data_ptr())
+        res_t.row_max, res_t.row_arg = res.row_max, res.row_arg
+        res_t.peak_delay, res_t.peak_freq, res_t.peak_val = res.peak_delay, res.peak_freq, res.peak_val
+        for _ in range(2):
+            plan.run(rx, surface_t=True, rows=True, peak=True, stream=stream, out=res_t)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            plan.run(rx, surface_t=True, rows=True, peak=True, stream=stream, out=res_t)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t1) / 5
+        col = t_surface_t[0, :, D0].cpu().numpy()
+        if int(np.argmax(col)) != int(pk[1]) or col.max() != np.float32(got[2]):
+            raise SystemExit("rank %d: the hypothesis-major surface does not hold the reported peak" % rank)
+        extra_t = {"ms_per_step": dt * 1e3, "value": S / dt / 1e6, "unit": "Msamples/s",
+                   "what": "same workload with the surface written hypothesis-major f32[256][S] (caf_outputs2.d_surface_t) + "
+                           "per-delay argmax + peak; the form behind the host-returning API, which transposes during the download"}
+        del t_surface_t
+
+    rank_ms, gather_ms = None, None
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        # every rank's own time for the K steps (a straggler shows as max >> min) and what the collective alone costs
+        mine = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else device)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        rank_ms = [float(t.item()) / args.steps * 1e3 for t in allr]
+        elapsed = max(float(t.item()) for t in allr)
         tb = gathered["table"].cpu().numpy()
         if not all(int(r[0]) == D0 and int(bins[r[1]]) == K0 for r in tb):
             raise SystemExit("gathered peak table is wrong: %r" % (tb,))
+        rows = t_peak.view(1, 3).cpu() if rehearse else t_peak.view(1, 3)
+        fence()
+        tg = []
+        for _ in range(5):
+            t1 = time.perf_counter()
+            sharding.all_gather_peak_table(rows, world)
+            torch.cuda.synchronize()
+            tg.append((time.perf_counter() - t1) * 1e3)
+        gather_ms = {"first": tg[0], "median_of_5": float(np.median(tg))}
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
@@ -779,6 +834,8 @@ def main():
                 {
                     "kernel": st[dom].get("kernel", dom), "bound": "hbm", "achieved": st[dom]["achieved_GBs"],
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": st[dom]["achieved_GBs"] / HBM_PEAK_GBS,
+                    # against what a copy kernel reaches on this chip (MI355X_MICROARCH.md: ~6.3 TB/s achievable of the 8 spec)
+                    "frac_of_achievable": st[dom]["achieved_GBs"] / HBM_ACHIEVABLE_GBS, "achievable": HBM_ACHIEVABLE_GBS,
                     "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": st[dom]["avg_ms"],
                     "alg_bytes_per_launch": st[dom]["alg_bytes_per_launch"],
                     **({"also_TFLOPs": st[dom]["achieved_TFLOPs"], "also_frac_f32_peak": st[dom]["achieved_TFLOPs"] / 157.3,
@@ -805,6 +862,11 @@ def main():
         }
         if extra is not None:
             out["no_surface"] = extra
+        if extra_t is not None:
+            out["surface_t"] = extra_t
+        if rank_ms is not None:
+            out["per_rank_ms_per_step"] = {"min": min(rank_ms), "max": max(rank_ms), "ranks": rank_ms}
+            out["peak_table_allgather_ms"] = gather_ms
         if world == 1 and not args.no_cpu_baseline:
             rx_h, tm_h = rx[: min(M_RX, D0 + 560000)].cpu().numpy(), tmpl.cpu().numpy()
             out["cpu_baseline"] = cpu_baseline(rx_h, tm_h, bins)

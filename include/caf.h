@@ -62,6 +62,16 @@ CAF_EXPORT int32_t caf_memset(void* d_ptr, int32_t value, int64_t bytes, void* s
 CAF_EXPORT int32_t caf_h2d(void* d_dst, const void* h_src, int64_t bytes, void* stream);
 CAF_EXPORT int32_t caf_d2h(void* h_dst, const void* d_src, int64_t bytes, void* stream);
 CAF_EXPORT int32_t caf_d2d(void* d_dst, const void* d_src, int64_t bytes, void* stream);
+/* caf_h2d / caf_d2h / caf_d2h_transposed move pageable host memory through the library's own pinned staging buffers
+ * (several DMA lanes + host threads for large arrays) and return when the data has arrived: the caller's pages are
+ * never registered with the driver, so what the caller does with its arrays afterwards (NumPy returning them to the
+ * operating system) cannot stall the process's GPU queues (csrc/caf_host.cpp).
+ * caf_d2h_transposed: d_src is [rows][pitch] float32; columns col0 .. col0 + ncols - 1 arrive as the C-ordered host array
+ * [ncols][rows] of float32 (dst_f64 = 0) or float64 (1) -- a hypothesis-major surface (caf_outputs2.d_surface_t, rows = F,
+ * pitch = S) leaves the device as the (delays, frequencies) array the reference returns (xcorrRoutines.py:553-566,
+ * 1028-1039).  rows <= 65536.  (ABI 1.8) */
+CAF_EXPORT int32_t caf_d2h_transposed(void* h_dst, int32_t dst_f64, const float* d_src, int64_t rows, int64_t pitch,
+                                      int64_t col0, int64_t ncols, void* stream);
 CAF_EXPORT int32_t caf_stream_sync(void* stream);
 /* a non-blocking HIP stream of the current device for the `stream` arguments below (cupy.cuda.Stream(non_blocking=True)
  * of a cupy caller); NULL = the default stream everywhere */

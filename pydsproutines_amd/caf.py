@@ -22,7 +22,7 @@ class CAFResult:
 
     def __init__(self):
         self.surface = self.surface_t = self.row_max = self.row_arg = None
-        self._row_arg_zeroed = None  # (ptr, nbytes) of the F == 1 argument array this object has already filled with zeros
+        self._row_arg_zeroed = None  # the F == 1 argument array that run() allocated itself and has already filled with zeros
         self.peak_val = self.peak_delay = self.peak_freq = None
         self.cqf = None
 
@@ -142,20 +142,26 @@ class CAFPlan:
         want_arg = bool(rows) and rows != "max"  # rows="max": the per-delay maxima only (no argument array)
         if rows and res.row_max is None:
             res.row_max = empty((self.T, S), np.float32)
+        own_arg = False
         if want_arg and res.row_arg is None:
             res.row_arg = empty((self.T, S), np.int32)
+            own_arg = True
         skip_arg = False
         if want_arg and self.F == 1:
-            # one hypothesis per template: the argument of every per-delay maximum is 0.  The array is zeroed once per
-            # buffer -- on the stream of this run, keyed on the buffer itself, so a caller who swaps res.row_arg gets the
-            # new one filled -- and not handed to the library again (which would fill T x S x 4 bytes on every call:
-            # 0.65 ms of C3's 4.5)
-            key = (res.row_arg.ptr, res.row_arg.nbytes)
-            if res._row_arg_zeroed != key:
-                _lib.check(_lib.load().caf_memset(ct.c_void_p(res.row_arg.ptr), 0, res.row_arg.nbytes,
-                                                  ct.c_void_p(stream) if stream else None), "caf_memset")
-                res._row_arg_zeroed = key
-            skip_arg = True
+            # one hypothesis per template: the argument of every per-delay maximum is 0.  An array that THIS method allocated
+            # is zeroed once (the fill completed before the call returns, so that runs on any stream may follow) and not
+            # handed to the library again (which would fill T x S x 4 bytes on every call: 0.65 ms of C3's 4.5).  An array the
+            # caller put into the result object -- it may have been written since, or be a new tensor at an old address --
+            # always goes to the library.
+            if own_arg:
+                lib = _lib.load()
+                sp = ct.c_void_p(stream) if stream else None
+                _lib.check(lib.caf_memset(ct.c_void_p(res.row_arg.ptr), 0, res.row_arg.nbytes, sp), "caf_memset")
+                _lib.check(lib.caf_stream_sync(sp), "caf_stream_sync")
+                res._row_arg_zeroed = res.row_arg
+            skip_arg = res._row_arg_zeroed is res.row_arg
+        elif want_arg:
+            res._row_arg_zeroed = None  # (a plan with F > 1 writes real arguments into the shared result object)
         if peak and res.peak_val is None:
             res.peak_val = empty((self.T,), np.float32)
             res.peak_delay = empty((self.T,), np.int32)

@@ -17,20 +17,18 @@ constexpr int MAG_THREADS = 256;  // |.|^2/normalise/argmax: 4 waves
 constexpr int MAG_S = 64;         // delays per tile (one wave-row of 8-byte loads = 512 B)
 constexpr int MAG_F = 128;        // frequency hypotheses per LDS chunk (512 B store rows)
 
-// Window energies below this fraction of the float64 prefix they are differences of are reported as zero-energy windows
-// (NaN results): k_inv_energy, k_block_spectra.  The prefix differences carry a few units in the 2^-53 place of the prefix
-// times log2(samples) (tree scans): 2^-44 is ~30 x that.  What "the prefix" is differs by engine, and with it the quietest
-// window that still passes:
-//   * 16384-point in-LDS engines (k_block_spectra): the prefix restarts in every overlap-save block, so the floor is
-//     2^-44 of the energy of the <= 16384 samples around the window -- a 4096-sample window passes down to ~-126 dB below
-//     its own block (2^-44 * 4 = -126 dB);
-//   * rocFFT engine, 32768-point blocks, per-delay path (k_inv_energy / the product kernels): ONE prefix over the whole
-//     record, so the floor is 2^-44 of everything BEFORE the window's end: behind 2^24 unit-power samples a 4096-sample
-//     window passes down to -96 dB (2^-44 * 2^24 / 4096 = 2.3e-10), behind 10^7 samples down to -98 dB.
-// A window between the two thresholds is finite on the first group and NaN on the second (tests/test_gpu_engine.py:
-// test_quiet_windows_late_in_a_long_record pins both sides: -90 dB finite everywhere, exact zeros NaN everywhere).  A common
-// threshold would need block-local energies in k_inv_energy too; the float64 global prefix cannot resolve less.
-constexpr double CAF_ENERGY_FLOOR = 5.6843418860808015e-14;  // 2^-44
+// Window energies.  The engines take the energy of a window as a difference of two entries of a float64 prefix of |rx|^2;
+// a difference resolves nothing below ~2^-50 of the prefix it is taken from.  Where it comes out below 2^-30 of the upper
+// entry (a window more than ~50 dB under everything in front of it) the energy is summed again directly, in float64, with
+// no subtraction: the <= 63 samples before the first and after the last 64-sample boundary inside the window, and the
+// whole 64-sample chunks between them from an array of chunk energies that the prefix pass leaves behind the prefix (each a
+// plain sum of 64 squares) -- <= 126 + N / 64 additions, so a record FULL of such windows costs a bounded amount.  NaN
+// therefore means an energy of exactly zero on every engine, as in the reference's 0 / 0 (xcorrRoutines.py:527-528,
+// IppXcorrFFT.cpp:174); rounds 1-4 reported anything below 2^-44 of the prefix as zero energy, with the floor in different
+// places on different engines.  (caf_energy.h; tests/test_gpu_engine.py::test_quiet_windows_*)
+constexpr double CAF_ENERGY_RESOLVED = 9.313225746154785e-10;  // 2^-30
+// a prefix buffer for m samples: m + 1 prefix entries (padded to an even count), then the chunk energies
+inline int64_t energy_prefix_doubles(int64_t m) { return ((m + 2) & ~(int64_t)1) + (m + 63) / 64 + 1; }
 
 struct PeakRec {
     float v;
@@ -64,6 +62,18 @@ inline int allow_dynamic_lds(const void* kernel, size_t bytes) {
     return CAF_OK;
 }
 
+// pageable host memory <-> device through the library's own pinned staging lanes (caf_host.cpp); complete on return
+int host_h2d(void* d_dst, const void* h_src, int64_t bytes, hipStream_t st);
+int host_d2h(void* h_dst, const void* d_src, int64_t bytes, hipStream_t st);
+int host_d2h_transposed(void* h_dst, bool dst_f64, const float* d_src, int64_t rows, int64_t pitch, int64_t col0, int64_t ncols,
+                        hipStream_t st);
+// blocking upload of host memory of any size (a caller's array, a std::vector about to be freed) on the null stream
+#define CAF_H2D(dst, src, bytes)                                                        \
+    do {                                                                                \
+        const int _rc = caf::host_h2d((dst), (src), (int64_t)(bytes), nullptr);         \
+        if (_rc) return _rc;                                                            \
+    } while (0)
+
 // caching device allocator (caf_pool.hip)
 int pool_alloc(void** out, int64_t bytes);
 int pool_free(void* p);
@@ -71,9 +81,10 @@ void pool_trim();
 void pool_stats(int64_t* cached, int64_t* in_use, int64_t* hits, int64_t* misses);
 
 int64_t prefix_num_tiles(int64_t m);
+// prefix: energy_prefix_doubles(m) entries (the prefix itself, then the 64-sample chunk energies: caf_energy.h)
 void launch_energy_prefix(const float2* rx, int64_t m, double* tile_sums, double* prefix, hipStream_t st);
-void launch_inv_energy(const double* prefix, int64_t shift_start, int64_t num_shifts, const int32_t* gstart,
-                       const int32_t* glen, int32_t ngroups, float* inv_e, hipStream_t st);
+void launch_inv_energy(const float2* rx, int64_t rx_len, const double* prefix, int64_t shift_start, int64_t num_shifts,
+                       const int32_t* gstart, const int32_t* glen, int32_t ngroups, float* inv_e, hipStream_t st);
 // peak records from finished (T, S) rows: rows_peak_chunks(S) records per template
 int64_t rows_peak_chunks(int64_t num_shifts);
 void launch_rows_peak(const float* rows, int32_t ntmpl, int64_t num_shifts, int64_t shift_start, PeakRec* partial,

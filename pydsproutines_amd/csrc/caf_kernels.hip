@@ -8,6 +8,7 @@
 //   custom_kernels/filter.cu:291-347           sliding energy (moving sum, double accumulate)
 // These kernels are HBM-bound elementwise / transpose / reduction work: no MFMA.
 #include "caf_internal.h"
+#include "caf_energy.h"
 
 namespace caf {
 
@@ -151,6 +152,20 @@ __global__ __launch_bounds__(PF_NT) void k_prefix_tiles(const float2* __restrict
         if (!WRITE && lane == 0) tile_sums[blockIdx.x] = run;
     }
     if (!WRITE) return;
+    // the energies of the 64-sample chunks (8 lanes x 8 samples), plain sums: what window_energy_direct adds up (caf_energy.h)
+    {
+        double* chunks = prefix + ((m + 2) & ~(int64_t)1);
+        const int64_t nchunks = (m + 63) / 64;
+#pragma unroll
+        for (int k = 0; k < SUB; ++k) {
+            double c = tot[k];
+            c += __shfl_xor(c, 1, 64);
+            c += __shfl_xor(c, 2, 64);
+            c += __shfl_xor(c, 4, 64);
+            const int64_t ci = (tbase + (int64_t)k * PF_NT * PF_PER) >> 6;
+            if ((lane & 7) == 0 && ci < nchunks) chunks[ci] = c;
+        }
+    }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < SUB; ++k) {
@@ -174,26 +189,21 @@ __global__ __launch_bounds__(PF_NT) void k_prefix_tiles(const float2* __restrict
     }
 }
 
-// inv_e[i] = 1 / sum_g (P[s+st_g+len_g] - P[s+st_g]),  s = shift_start + i.
-__global__ __launch_bounds__(256) void k_inv_energy(const double* __restrict__ prefix, int64_t shift_start,
-                                                    int64_t num_shifts, const int32_t* __restrict__ gstart,
+// inv_e[i] = 1 / sum_g E(s + st_g, len_g),  s = shift_start + i; E from the prefix (window_energy, caf_energy.h).
+// A window of zeros (a gap in a recording) is the reference's 0 / 0 = NaN, and only that is.
+__global__ __launch_bounds__(256) void k_inv_energy(const float2* __restrict__ rx, int64_t rx_len, const double* __restrict__ prefix,
+                                                    int64_t shift_start, int64_t num_shifts, const int32_t* __restrict__ gstart,
                                                     const int32_t* __restrict__ glen, int32_t ngroups,
                                                     float* __restrict__ inv_e) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= num_shifts) return;
     const int64_t s = shift_start + i;
-    double e = 0.0, ptop = 0.0;
+    double e = 0.0;
     for (int g = 0; g < ngroups; ++g) {
         const int64_t a = s + gstart[g];
-        const double pb = prefix[a + glen[g]];
-        e += pb - prefix[a];
-        ptop = pb > ptop ? pb : ptop;
+        e += window_energy(prefix, rx, rx_len, a, a + glen[g]);
     }
-    // A window of zeros (a gap in a recording) is the reference's 0 / 0 = NaN.  Here the energy is a difference of float64
-    // prefix values from a parallel scan -- 0 up to a few units in the last place of the prefix, not exactly 0 -- and the
-    // in-LDS engines multiply |y|^2, which is FFT rounding noise there, by this factor: 1 / (almost 0) would make that noise the
-    // row's maximum.  Anything below the resolution of the prefix it was taken from (2^-44 of it) is reported as NaN.
-    inv_e[i] = e > CAF_ENERGY_FLOOR * ptop ? (float)(1.0 / e) : __builtin_nanf("");
+    inv_e[i] = e > 0.0 ? (float)(1.0 / e) : __builtin_nanf("");
 }
 
 // ----------------------------------------------------------------------------------------
@@ -575,11 +585,11 @@ void scan_tiles(double* tile_sums, int64_t ntiles, hipStream_t st) {
     hipLaunchKernelGGL(k_scan_tile_sums, dim3(1), dim3(1024), 0, st, tile_sums, ntiles);
 }
 
-void launch_inv_energy(const double* prefix, int64_t shift_start, int64_t num_shifts, const int32_t* gstart,
-                       const int32_t* glen, int32_t ngroups, float* inv_e, hipStream_t st) {
+void launch_inv_energy(const float2* rx, int64_t rx_len, const double* prefix, int64_t shift_start, int64_t num_shifts,
+                       const int32_t* gstart, const int32_t* glen, int32_t ngroups, float* inv_e, hipStream_t st) {
     const unsigned g = (unsigned)((num_shifts + 255) / 256);
-    hipLaunchKernelGGL(k_inv_energy, dim3(g), dim3(256), 0, st, prefix, shift_start, num_shifts, gstart, glen, ngroups,
-                       inv_e);
+    hipLaunchKernelGGL(k_inv_energy, dim3(g), dim3(256), 0, st, rx, rx_len, prefix, shift_start, num_shifts, gstart, glen,
+                       ngroups, inv_e);
 }
 
 void launch_gather_blocks(const float2* rx, int64_t rx_len, int64_t src0, int32_t step, int32_t bsz, int32_t nblk,

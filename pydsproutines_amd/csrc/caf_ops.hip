@@ -92,7 +92,7 @@ int energy_prefix(const float2* x, int64_t n, Scratch& sc, double** prefix, hipS
     double* tiles = nullptr;
     int rc = sc.get(&tiles, prefix_num_tiles(n) + 1024);
     if (rc) return rc;
-    if ((rc = sc.get(prefix, n + 1))) return rc;
+    if ((rc = sc.get(prefix, energy_prefix_doubles(n)))) return rc;
     launch_energy_prefix(x, n, tiles, *prefix, st);
     return CAF_OK;
 }
@@ -241,9 +241,9 @@ int zoom_constants(int dev, int m, double span, double step, ZoomCzt* out) {
     CAF_HIP_TRY(hipMalloc((void**)&z.aa, (size_t)m * 8));
     CAF_HIP_TRY(hipMalloc((void**)&z.fv, (size_t)nfft * 8));
     CAF_HIP_TRY(hipMalloc((void**)&z.wws, (size_t)k * 8));
-    CAF_HIP_TRY(hipMemcpy(z.aa, aa.data(), (size_t)m * 8, hipMemcpyHostToDevice));
-    CAF_HIP_TRY(hipMemcpy(z.fv, fvf.data(), (size_t)nfft * 8, hipMemcpyHostToDevice));
-    CAF_HIP_TRY(hipMemcpy(z.wws, wws.data(), (size_t)k * 8, hipMemcpyHostToDevice));
+    CAF_H2D(z.aa, aa.data(), (size_t)m * 8);
+    CAF_H2D(z.fv, fvf.data(), (size_t)nfft * 8);
+    CAF_H2D(z.wws, wws.data(), (size_t)k * 8);
     if (g_zoom_czt.size() > 64) g_zoom_czt.clear();  // (leaks a few hundred KB at worst; bounded)
     g_zoom_czt[key] = z;
     *out = z;

@@ -20,6 +20,7 @@
 #include <complex>
 
 #include "caf_internal.h"
+#include "caf_energy.h"
 #include "caf_ldsfft.h"
 
 namespace caf {
@@ -255,6 +256,7 @@ __global__ __launch_bounds__(1024) void k_block_spectra(const float2* __restrict
     extern __shared__ __attribute__((aligned(16))) float2 s_bs[];
     __shared__ double s_wtot[16];
     __shared__ double s_total;
+    __shared__ double s_chunk[N / 64];
     const int l = threadIdx.x;
     // conj(x) of the block's 16 points of this thread (zeros past the end of rx)
     auto load = [&](int64_t b, float2 (&d)[16], int lo) {
@@ -298,6 +300,12 @@ __global__ __launch_bounds__(1024) void k_block_spectra(const float2* __restrict
 #pragma unroll
             for (int j = 0; j < 16; ++j) tot += s_p[17 * lo + j];
             const int lane = lo & 63, wave = lo >> 6;
+            {   // energies of the block's 64-sample chunks (4 lanes x 16 samples), plain sums: for windows the prefix cannot resolve
+                double c4 = tot;
+                c4 += __shfl_xor(c4, 1, 64);
+                c4 += __shfl_xor(c4, 2, 64);
+                if ((lane & 3) == 0) s_chunk[lo >> 2] = c4;
+            }
             double incl = tot;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
@@ -320,18 +328,37 @@ __global__ __launch_bounds__(1024) void k_block_spectra(const float2* __restrict
             __syncthreads();
             auto P = [&](int m) { return m >= N ? s_total : s_p[m + (m >> 4)]; };
             const int64_t i0 = b * step;
+            const int64_t s0 = src0 + b * step;  // the block's first sample in rx
+            // a window the block's prefix does not resolve (caf_internal.h, CAF_ENERGY_RESOLVED): summed again without any
+            // subtraction -- edge samples re-read from rx (they are in the L2: this block has just loaded them), whole chunks
+            // from s_chunk
+            auto direct = [&](int a, int e_) {
+                auto smp = [&](int m) {
+                    const int64_t j = s0 + m;
+                    return j < rx_len ? sample_energy(rx[j]) : 0.0;
+                };
+                double e = 0.0;
+                const int h = (a + 63) & ~63, t = e_ & ~63;
+                if (h >= t) {
+                    for (int m = a; m < e_; ++m) e += smp(m);
+                    return e;
+                }
+                for (int m = a; m < h; ++m) e += smp(m);
+                for (int c = h >> 6; c < (t >> 6); ++c) e += s_chunk[c];
+                for (int m = t; m < e_; ++m) e += smp(m);
+                return e;
+            };
             for (int k = lo; k < step; k += 1024) {
                 const int64_t i = i0 + k;
                 if (i < num_shifts) {
-                    double e = 0.0, ptop = 0.0;
+                    double e = 0.0;
                     for (int g = 0; g < ngroups; ++g) {
                         const int a = k + gstart[g];
-                        const double pb = P(a + glen[g]);
-                        e += pb - P(a);
-                        ptop = pb > ptop ? pb : ptop;
+                        const double pb = P(a + glen[g]), d = pb - P(a);
+                        e += d > CAF_ENERGY_RESOLVED * pb ? d : direct(a, a + glen[g]);
                     }
-                    // (a window of zeros, or one below the resolution of the block's prefix: NaN -- see k_inv_energy)
-                    inv_e[i] = e > CAF_ENERGY_FLOOR * ptop ? (float)(1.0 / e) : __builtin_nanf("");
+                    // (a window of zeros -- a gap in a recording -- is the reference's 0 / 0 = NaN, and only that is)
+                    inv_e[i] = e > 0.0 ? (float)(1.0 / e) : __builtin_nanf("");
                 }
             }
             __syncthreads();  // the image is overwritten by the transform's first pass
@@ -606,7 +633,7 @@ __global__ __launch_bounds__(R10<P>::WG, 4) void k_perdelay_r10(  // (4 waves pe
             // 1 / (sqrt(E) ||x||) as rsq(E ||x||^2) + one Newton step (2^-45 or better before the rounding to float32), as in
             // k_perdelay_fused: a float64 square root and a float64 division per row and thread are ~40 half-rate
             // instructions.  E = 0: rsq = inf, 0 * inf = NaN -> NaN row, as before.
-            const double en = (prefix[b] - prefix[a]) * (xn * xn);
+            const double en = window_energy(prefix, y, ylen, a, b) * (xn * xn);  // (exact where the difference is not: caf_energy.h)
             const double y0 = __builtin_amdgcn_rsq(en);
             inv = (float)__builtin_fma(__builtin_fma(-(en * y0), 0.5 * y0, 0.5), y0, y0);
         }

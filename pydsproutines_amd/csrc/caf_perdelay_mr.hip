@@ -29,6 +29,7 @@
 #include <vector>
 
 #include "caf_internal.h"
+#include "caf_energy.h"
 #include "caf_fft_dev.h"
 
 namespace caf {
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(WGMAX, 4) void k_perdelay_mr(MrPlan pl, const float
             // 1 / (sqrt(E) ||x||) as rsq(E ||x||^2) + one Newton step (2^-45 or better before the rounding to float32), as in
             // k_perdelay_fused: a float64 square root and a float64 division per row and thread are ~40 half-rate
             // instructions.  E = 0: rsq = inf, 0 * inf = NaN -> NaN row, as before.
-            const double en = (prefix[b] - prefix[a]) * (xn * xn);
+            const double en = window_energy(prefix, y, ylen, a, b) * (xn * xn);  // (exact where the difference is not: caf_energy.h)
             const double y0 = __builtin_amdgcn_rsq(en);
             inv = (float)__builtin_fma(__builtin_fma(-(en * y0), 0.5 * y0, 0.5), y0, y0);
         }

@@ -247,7 +247,7 @@ int32_t caf_last_error(char* buf, int32_t len) {
     return CAF_OK;
 }
 
-int32_t caf_abi_version(void) { return (1 << 16) | 7; }  // minor: +1 per batch of added entry points
+int32_t caf_abi_version(void) { return (1 << 16) | 8; }  // minor: +1 per batch of added entry points
 
 int32_t caf_device_count(int32_t* count) {
     CAF_REQUIRE(count, "count is NULL");
@@ -296,14 +296,18 @@ int32_t caf_memset(void* d_ptr, int32_t value, int64_t bytes, void* stream) {
     return CAF_OK;
 }
 int32_t caf_h2d(void* d_dst, const void* h_src, int64_t bytes, void* stream) {
-    CAF_HIP_TRY(hipMemcpyAsync(d_dst, h_src, (size_t)bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
-    CAF_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-    return CAF_OK;
+    CAF_REQUIRE(bytes >= 0 && (bytes == 0 || (d_dst && h_src)), "caf_h2d: bad arguments");
+    return host_h2d(d_dst, h_src, bytes, (hipStream_t)stream);
 }
 int32_t caf_d2h(void* h_dst, const void* d_src, int64_t bytes, void* stream) {
-    CAF_HIP_TRY(hipMemcpyAsync(h_dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
-    CAF_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-    return CAF_OK;
+    CAF_REQUIRE(bytes >= 0 && (bytes == 0 || (h_dst && d_src)), "caf_d2h: bad arguments");
+    return host_d2h(h_dst, d_src, bytes, (hipStream_t)stream);
+}
+int32_t caf_d2h_transposed(void* h_dst, int32_t dst_f64, const float* d_src, int64_t rows, int64_t pitch, int64_t col0,
+                           int64_t ncols, void* stream) {
+    CAF_REQUIRE(h_dst && d_src, "caf_d2h_transposed: NULL");
+    CAF_REQUIRE(rows >= 1 && rows <= 65536 && ncols >= 0 && col0 >= 0 && col0 + ncols <= pitch, "caf_d2h_transposed: bad shape");
+    return host_d2h_transposed(h_dst, dst_f64 != 0, d_src, rows, pitch, col0, ncols, (hipStream_t)stream);
 }
 int32_t caf_d2d(void* d_dst, const void* d_src, int64_t bytes, void* stream) {
     CAF_HIP_TRY(hipMemcpyAsync(d_dst, d_src, (size_t)bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
@@ -382,13 +386,13 @@ static int32_t plan_build_direct(caf_plan p, const caf_plan_desc* d, const std::
         return rc;
     std::vector<std::complex<float>> uc((size_t)T * N);
     for (size_t i = 0; i < uc.size(); ++i) uc[i] = d->auto_conj ? std::conj(tm[i]) : tm[i];
-    CAF_HIP_TRY(hipMemcpy(p->d_dir_pos, nz.data(), (size_t)K * 4, hipMemcpyHostToDevice));
-    CAF_HIP_TRY(hipMemcpy(p->d_dir_w, w.data(), w.size() * 8, hipMemcpyHostToDevice));
-    CAF_HIP_TRY(hipMemcpy(p->d_tscale, tscale.data(), (size_t)T * 4, hipMemcpyHostToDevice));
-    CAF_HIP_TRY(hipMemcpy(p->d_gstart, gs.data(), gs.size() * 4, hipMemcpyHostToDevice));
-    CAF_HIP_TRY(hipMemcpy(p->d_glen, gl.data(), gl.size() * 4, hipMemcpyHostToDevice));
-    CAF_HIP_TRY(hipMemcpy(p->d_uconj, uc.data(), uc.size() * 8, hipMemcpyHostToDevice));
-    CAF_HIP_TRY(hipMemcpy(p->d_nu, nu.data(), nu.size() * 8, hipMemcpyHostToDevice));
+    CAF_H2D(p->d_dir_pos, nz.data(), (size_t)K * 4);
+    CAF_H2D(p->d_dir_w, w.data(), w.size() * 8);
+    CAF_H2D(p->d_tscale, tscale.data(), (size_t)T * 4);
+    CAF_H2D(p->d_gstart, gs.data(), gs.size() * 4);
+    CAF_H2D(p->d_glen, gl.data(), gl.size() * 4);
+    CAF_H2D(p->d_uconj, uc.data(), uc.size() * 8);
+    CAF_H2D(p->d_nu, nu.data(), nu.size() * 8);
     return CAF_OK;
 }
 
@@ -595,7 +599,7 @@ static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
     if ((rc = p->alloc(&p->d_gstart, p->G))) return rc;
     if ((rc = p->alloc(&p->d_glen, p->G))) return rc;
     if ((rc = p->alloc(&p->d_tile_sums, prefix_num_tiles(d->max_rx_len) + 1024))) return rc;
-    if ((rc = p->alloc(&p->d_prefix, d->max_rx_len + 1))) return rc;
+    if ((rc = p->alloc(&p->d_prefix, energy_prefix_doubles(d->max_rx_len)))) return rc;
     if ((rc = p->alloc(&p->d_inv_e, d->max_rx_len))) return rc;
     // all rx block spectra are produced up front, fwd_chunk blocks per rocFFT launch
     // (~32 MiB of spectra per forward launch: 256 blocks of 16384, 64 blocks of 65536, ...)
@@ -643,11 +647,9 @@ static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
             free_tmp();
             return rc;
         }
-        hipError_t e1 = hipMemcpy(tmp_tm, tm, (size_t)T * N * 8, hipMemcpyHostToDevice);
-        if (e1 == hipSuccess) e1 = hipMemcpy(tmp_nu, d->h_freqs_norm, (size_t)F * 8, hipMemcpyHostToDevice);
-        if (e1 != hipSuccess) {
+        if ((rc = host_h2d(tmp_tm, tm, (int64_t)T * N * 8, nullptr)) || (rc = host_h2d(tmp_nu, d->h_freqs_norm, (int64_t)F * 8, nullptr))) {
             free_tmp();
-            CAF_HIP_TRY(e1);
+            return rc;
         }
         launch_build_hyp_time((const float2*)tmp_tm, (const double*)tmp_nu, N, B, F, T, d->auto_conj ? 0 : 1, p->d_hc,
                               nullptr);
@@ -676,7 +678,7 @@ static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
                 }
             }
         }
-        CAF_HIP_TRY(hipMemcpy(p->d_hc, host.data(), host.size() * sizeof(std::complex<float>), hipMemcpyHostToDevice));
+        CAF_H2D(p->d_hc, host.data(), host.size() * sizeof(std::complex<float>));
     }
     {
         FftPlan tmp;
@@ -724,8 +726,8 @@ static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
         CAF_HIP_TRY(e);
     }
     if (!shifts.empty())
-        CAF_HIP_TRY(hipMemcpy(p->d_shifts, shifts.data(), shifts.size() * 4, hipMemcpyHostToDevice));
-    CAF_HIP_TRY(hipMemcpy(p->d_tscale, tscale.data(), (size_t)T * 4, hipMemcpyHostToDevice));
+        CAF_H2D(p->d_shifts, shifts.data(), shifts.size() * 4);
+    CAF_H2D(p->d_tscale, tscale.data(), (size_t)T * 4);
     {   // what the zoom needs beside the coarse result: the time-domain multiplier of a product row,
         // rx[d + n] * conj(u[n]), and the frequency each hypothesis index stands for
         std::vector<std::complex<float>> uc((size_t)T * N);
@@ -734,11 +736,11 @@ static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
         for (int f = 0; f < F; ++f)
             nu[f] = d->freq_mode == CAF_FREQ_BINS ? (double)d->h_bins[f] / (double)d->grid : d->h_freqs_norm[f];
         if ((rc = p->alloc(&p->d_uconj, (int64_t)T * N)) || (rc = p->alloc(&p->d_nu, F))) return rc;
-        CAF_HIP_TRY(hipMemcpy(p->d_uconj, uc.data(), uc.size() * 8, hipMemcpyHostToDevice));
-        CAF_HIP_TRY(hipMemcpy(p->d_nu, nu.data(), nu.size() * 8, hipMemcpyHostToDevice));
+        CAF_H2D(p->d_uconj, uc.data(), uc.size() * 8);
+        CAF_H2D(p->d_nu, nu.data(), nu.size() * 8);
     }
-    CAF_HIP_TRY(hipMemcpy(p->d_gstart, gs.data(), gs.size() * 4, hipMemcpyHostToDevice));
-    CAF_HIP_TRY(hipMemcpy(p->d_glen, gl.data(), gl.size() * 4, hipMemcpyHostToDevice));
+    CAF_H2D(p->d_gstart, gs.data(), gs.size() * 4);
+    CAF_H2D(p->d_glen, gl.data(), gl.size() * 4);
 
     if ((rc = fft_plan_acquire(&p->fwd, false, (size_t)B, (size_t)p->fwd_chunk, (size_t)B))) return rc;
     if (!p->fused && (rc = fft_plan_acquire(&p->inv, true, (size_t)B, (size_t)nb * T * F, (size_t)p->pitch))) return rc;
@@ -913,7 +915,7 @@ int32_t caf_plan_execute2(caf_plan p, const float* d_rx, int64_t rx_len, int64_t
         }
         p->stage_begin(0, se);
         launch_energy_prefix(rx, rx_len, p->d_tile_sums, p->d_prefix, se);
-        launch_inv_energy(p->d_prefix, shift_start, num_shifts, p->d_gstart, p->d_glen, p->G, p->d_inv_e, se);
+        launch_inv_energy(rx, rx_len, p->d_prefix, shift_start, num_shifts, p->d_gstart, p->d_glen, p->G, p->d_inv_e, se);
         p->stage_end(se);
         if (aux) CAF_HIP_TRY(hipEventRecord(p->ev_join, p->s_aux));
     }
@@ -1228,17 +1230,16 @@ int32_t caf_plan_execute_host(caf_plan p, const float* h_rx, int64_t rx_len, int
         cleanup();
         return rc;
     }
-    hipError_t e = hipMemcpy(d_rx, h_rx, (size_t)rx_len * 8, hipMemcpyHostToDevice);
-    if (e == hipSuccess) {
-        rc = caf_plan_execute(p, reinterpret_cast<const float*>(d_rx), rx_len, shift_start, num_shifts, &o, nullptr);
-        if (rc) {
-            cleanup();
-            return rc;
-        }
-        e = hipStreamSynchronize(nullptr);
+    // (host arrays travel through the library's pinned staging lanes, never as pinned user pages: caf_host.cpp)
+    rc = host_h2d(d_rx, h_rx, rx_len * 8, nullptr);
+    if (!rc) rc = caf_plan_execute(p, reinterpret_cast<const float*>(d_rx), rx_len, shift_start, num_shifts, &o, nullptr);
+    if (rc) {
+        cleanup();
+        return rc;
     }
+    hipError_t e = hipSuccess;
     auto back = [&](void* h, const void* dptr, int64_t bytes) {
-        if (e == hipSuccess && h) e = hipMemcpy(h, dptr, (size_t)bytes, hipMemcpyDeviceToHost);
+        if (!rc && h) rc = host_d2h(h, dptr, bytes, nullptr);
     };
     back(h_surface, o.d_surface, (int64_t)T * num_shifts * F * 4);
     back(h_row_max, o.d_row_max, (int64_t)T * num_shifts * 4);
@@ -1248,7 +1249,7 @@ int32_t caf_plan_execute_host(caf_plan p, const float* h_rx, int64_t rx_len, int
     back(h_peak_freq, o.d_peak_freq, T * 4);
     cleanup();
     CAF_HIP_TRY(e);
-    return CAF_OK;
+    return rc;
 }
 
 }  // extern "C"

@@ -12,6 +12,7 @@
 //   custom_kernels/copying.cu:8-138, cupyExtensions.py:17-38   slice/group copies
 // All are HBM-bound (or, for long FIRs, VALU-bound) elementwise / sliding-window work.
 #include "caf_internal.h"
+#include "caf_energy.h"
 
 namespace caf {
 
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(256) void k_sliding_multiply(const float2* __restri
             int64_t a = s < 0 ? 0 : (s > ylen ? ylen : s);
             int64_t b = s + xlen;
             b = b < 0 ? 0 : (b > ylen ? ylen : b);
-            const double e = prefix[b] - prefix[a];
+            const double e = window_energy(prefix, y, ylen, a, b);  // (exact where the difference is not: caf_energy.h)
             inv = (float)(1.0 / (sqrt(e) * (d_coef ? coef * *d_coef : coef)));
         }
         s_inv[threadIdx.x] = inv;

@@ -124,6 +124,31 @@ def _take_u32(d_i32, rel, out=None):
     return out
 
 
+def _host_surface(plan, d_rx, lo, cnt, rel, dtype):
+    """Rows ``rel`` of the (cnt, F) QF^2 surface of a one-template plan over the delays lo .. lo + cnt - 1, as a host array
+    of ``dtype`` (float32 / float64) -- what the reference's CPU signatures return (xcorrRoutines.py:553-566, 1028-1039).
+
+    Where the engine can write the hypothesis-major surface itself (persistent engine, 16384-point blocks: no |y|^2 tiles,
+    no tile role -- 10.7 instead of 13.4 ms at config C2) that launch is used, and the transposition to the reference's
+    (delays, frequencies) layout happens on the host side of the download (``caf_d2h_transposed``: DMA lanes into pinned
+    staging, 8 x 8 register transposes straight into the result array, float64 widening included).  Same numbers as the
+    delay-major launch (tests/test_gpu_fullsize.py::test_c2_hypothesis_major_surface)."""
+    rel = np.asarray(rel)
+    F = plan.F
+    lib = _lib.load()
+    if plan.T == 1 and F > 1 and plan.engine_used == "persistent" and plan.block == 16384:
+        res = plan.run(d_rx, shift_start=lo, num_shifts=cnt, surface_t=True, rows=False, peak=False)
+        contiguous = rel.size > 0 and rel[-1] - rel[0] + 1 == rel.size and (rel.size == 1 or np.all(np.diff(rel) == 1))
+        c0, nc = (int(rel[0]), int(rel.size)) if contiguous else (0, cnt)
+        out = np.empty((nc, F), dtype)
+        if nc:
+            _lib.check(lib.caf_d2h_transposed(out.ctypes.data, 1 if out.dtype == np.float64 else 0, ct.c_void_p(res.surface_t.ptr),
+                                              F, cnt, c0, nc, None), "caf_d2h_transposed")
+        return out if contiguous else out[rel]
+    res = plan.run(d_rx, shift_start=lo, num_shifts=cnt, surface=True, rows=False, peak=False)
+    return res.surface.get()[0][rel].astype(dtype, copy=False)
+
+
 # ------------------------------------------------------------------------------------------
 # fastXcorr and relatives (host-array signatures)
 # ------------------------------------------------------------------------------------------
@@ -220,17 +245,16 @@ def _czt_object(n, f1, f2, step, fs):
 
 
 def _czt_rows_pay(n, k, cnt):
-    """Per-delay CZT rows (3 transforms of nfft >= n + k - 1 per delay) against k hypotheses over overlap-save blocks of the
-    engine's size for an n-sample template (caf_plan.hip: 16 n clipped to 2^12 .. 2^18, at least 2 n)."""
-    nfft = 1 << int(np.ceil(np.log2(n + k - 1)))
+    """Per-delay CZT rows (3 transforms of CZTCachedGPU's nfft = next_fast_len(n + k + 1) per delay) against k hypotheses over
+    overlap-save blocks of the engine's size for an n-sample template (caf_plan.hip: 16 n clipped to 2^12 .. 2^18, at least 2 n).
+    (Round 4 kept rows of more than 32768 points on the engine because such calls "settled at 100 ms": that was the runtime
+    pinning the 3.2 MB result array of those calls, not the rows -- csrc/caf_host.cpp; the rule is cost alone again.)"""
+    nfft = next_fast_len(n + k + 1)
     rows_cost = 3.0 * cnt * nfft * np.log2(nfft)
     lb = max(min(max(int(np.ceil(np.log2(16 * n))), 12), 18), int(np.ceil(np.log2(2 * n))))
     nblk = -(-cnt // ((1 << lb) - n + 1))
     engine_cost = float(k) * nblk * (1 << lb) * lb
-    # (rows of up to 32768 points: one rocFFT kernel per transform.  Longer rows -- measured with 65536- and 131072-point rows of
-    #  a 50000 / 100000-sample cutout, 201 delays -- run 1-4 ms for the first calls and then settle at exactly 100 ms per call,
-    #  a wait inside the runtime that the engine's launches do not meet: profiles/r04/timing_cztxcorr.log)
-    return nfft <= 32768 and rows_cost * 2 < engine_cost
+    return rows_cost * 2 < engine_cost
 
 
 def cztXcorr(cutout, rx, f_searchMin, f_searchMax, fs, cztStep=0.1, outputCAF=False, shifts=None):
@@ -269,8 +293,7 @@ def cztXcorr(cutout, rx, f_searchMin, f_searchMax, fs, cztStep=0.1, outputCAF=Fa
     plan = CAFPlan(_c64(cutout), max_rx_len=len(rx), freqs_norm=f_eval / fs,
                    engine="auto" if outputCAF else "rocfft")
     if outputCAF:
-        res = plan.run(d_rx, shift_start=lo, num_shifts=cnt, surface=True, rows=False, peak=False)
-        out = res.surface.get()[0][rel].astype(np.float64)
+        out = _host_surface(plan, d_rx, lo, cnt, rel, np.float64)
         plan.close()
         return out, f_search
     res = plan.run(d_rx, shift_start=lo, num_shifts=cnt, rows=True, peak=False, cqf=True)
@@ -315,6 +338,16 @@ class _GroupEngine:
         res = plan.run(d_rx, shift_start=lo, num_shifts=cnt, **kw)
         return res, rel
 
+    def _surface_host(self, rx, shifts, dtype):
+        """(len(shifts), F) host array of ``dtype``: the surface of ``_run(surface=True)`` brought home (see _host_surface)."""
+        d_rx = rx if isinstance(rx, DeviceArray) else asarray(_c64(np.asarray(rx)))
+        if self._rows_path_pays(shifts):
+            res, rel = self._run_rows(d_rx, np.asarray(shifts))
+            return res.surface.get()[0][rel].astype(dtype, copy=False)
+        plan = self._get_plan(d_rx.size)
+        lo, cnt, rel = _engine_range(shifts)
+        return _host_surface(plan, d_rx, lo, cnt, rel, dtype)
+
     # -- the per-delay form for FEW delays over a LONG composite template ---------------------------------------
     # The hypothesis engine transforms whole overlap-save blocks of at least twice the template span per frequency:
     # the reference's benchmark_groupXcorrs.py (100 groups of 5000 samples spread over 10^6, 41 shifts, 201 CZT bins)
@@ -328,18 +361,25 @@ class _GroupEngine:
     def _rows_path_pays(self, shifts):
         if self._czt_grid is None or np.unique(self._len).size != 1:
             return False
+        # (a grid whose span is not a whole number of bins: CZTCached evaluates at f1 + i (f2 - f1 + bw) / k but labels -- and
+        #  phases the groups -- at f1 + i bw (spectralRoutines.py:239-311, xcorrRoutines.py:996-1039); the engine evaluates
+        #  one frequency list for both.  The two forms agree only on whole-bin grids, so only those may take either.)
+        f1, f2, bw, _ = self._czt_grid
+        r = (f2 - f1) / bw
+        if abs(r - round(r)) > 1e-9 * max(1.0, abs(r)):
+            return False
         if self._force_rows is not None:
             return bool(self._force_rows)
         S, G, L = int(np.asarray(shifts).size), int(self._len.size), int(self._len[0])
         k = int(np.asarray(self._fn).size)
-        nfft = 1 << int(np.ceil(np.log2(L + k - 1)))
+        nfft = next_fast_len(L + k + 1)
         rows_cost = 3.0 * S * G * nfft * np.log2(nfft)
         lo, cnt, _ = _engine_range(shifts)
         blk = 1 << int(np.ceil(np.log2(2 * self._span)))  # the engine's block for a template of this span (>= 2 N)
         nblk = -(-cnt // max(1, blk - self._span + 1))
         engine_cost = 1.0 * k * nblk * blk * np.log2(blk)
-        # (templates of up to 32768 samples: the in-LDS engines, always; rows longer than 32768 points: see _czt_rows_pay)
-        return self._span > 32768 and nfft <= 32768 and rows_cost * 2 < engine_cost
+        # (templates of up to 32768 samples: the in-LDS engines, always)
+        return self._span > 32768 and rows_cost * 2 < engine_cost
 
     def _run_rows(self, d_rx, shifts):
         f1, f2, bw, fs = self._czt_grid
@@ -356,26 +396,31 @@ class _GroupEngine:
                                          ynormsq=float(np.sum(np.abs(tm.astype(np.complex128)) ** 2)))
         czt, k = st["czt"], st["czt"].k
         assert k == int(np.asarray(self._fn).size), "CZT grid and frequency list disagree"
-        starts = (shifts[None, :].astype(np.int64) + self._rel[:, None]).reshape(-1)  # [g][s]
-        assert starts.min() >= 0 and starts.max() + L <= d_rx.size
-        d_starts = asarray(starts.astype(np.int32))
-        d_len = asarray(np.full(G * S, L, np.int32))
-        d_row = asarray(np.repeat(np.arange(G, dtype=np.int32), S))
-        d_mul = empty((G * S, L), np.complex64)
-        _lib.check(lib.caf_multiply_slices_indexed_rows(ct.c_void_p(d_rx.ptr), d_rx.size, ct.c_void_p(st["d_tm"].ptr), G, L,
-                                                        ct.c_void_p(d_starts.ptr), ct.c_void_p(d_len.ptr), ct.c_void_p(d_row.ptr),
-                                                        L, G * S, ct.c_void_p(d_mul.ptr), None), "caf_multiply_slices_indexed_rows")
-        d_planes = czt.runMany(d_mul)  # (G S, k) complex64
-        # rx energy under the groups at every delay: one moving sum of |rx|^2, one gather, summed over the groups on the host
-        d_msum = cupyMovingAverage(cupyComplexMagnSq(d_rx, np.float32), L, sumInstead=True)
-        d_e = empty((G * S,), np.float32)
-        d_ei = asarray((starts + L - 1).astype(np.int32))
-        _lib.check(lib.caf_gather_b32(ct.c_void_p(d_msum.ptr), d_msum.size, ct.c_void_p(d_ei.ptr), G * S, ct.c_void_p(d_e.ptr), None),
-                   "caf_gather_b32")
-        d_norm = asarray(d_e.get().astype(np.float64).reshape(G, S).sum(axis=0))
         d_out = empty((S, k), np.float64)
-        _lib.check(lib.caf_sum_groups_qf2(ct.c_void_p(d_planes.ptr), G, S, k, ct.c_void_p(st["d_ph"].ptr), ct.c_void_p(d_norm.ptr),
-                                          st["ynormsq"], ct.c_void_p(d_out.ptr), None), "caf_sum_groups_qf2")
+        # rx energy under the groups at every delay: one moving sum of |rx|^2 (then a gather per chunk, summed over the groups on the host)
+        d_msum = cupyMovingAverage(cupyComplexMagnSq(d_rx, np.float32), L, sumInstead=True)
+        # the (G S, L) product matrix and the (G S, k) planes are bounded: delays in chunks of at most 2^27 matrix elements
+        per = max(1, _MAX_PLANE_ELEMS // (G * max(L, k)))
+        for s0 in range(0, S, per):
+            sh = shifts[s0 : s0 + per]
+            Sc = int(sh.size)
+            starts = (sh[None, :].astype(np.int64) + self._rel[:, None]).reshape(-1)  # [g][s]
+            assert starts.min() >= 0 and starts.max() + L <= d_rx.size
+            d_starts = asarray(starts.astype(np.int32))
+            d_len = asarray(np.full(G * Sc, L, np.int32))
+            d_row = asarray(np.repeat(np.arange(G, dtype=np.int32), Sc))
+            d_mul = empty((G * Sc, L), np.complex64)
+            _lib.check(lib.caf_multiply_slices_indexed_rows(ct.c_void_p(d_rx.ptr), d_rx.size, ct.c_void_p(st["d_tm"].ptr), G, L,
+                                                            ct.c_void_p(d_starts.ptr), ct.c_void_p(d_len.ptr), ct.c_void_p(d_row.ptr),
+                                                            L, G * Sc, ct.c_void_p(d_mul.ptr), None), "caf_multiply_slices_indexed_rows")
+            d_planes = czt.runMany(d_mul)  # (G Sc, k) complex64
+            d_e = empty((G * Sc,), np.float32)
+            d_ei = asarray((starts + L - 1).astype(np.int32))
+            _lib.check(lib.caf_gather_b32(ct.c_void_p(d_msum.ptr), d_msum.size, ct.c_void_p(d_ei.ptr), G * Sc, ct.c_void_p(d_e.ptr), None),
+                       "caf_gather_b32")
+            d_norm = asarray(d_e.get().astype(np.float64).reshape(G, Sc).sum(axis=0))
+            _lib.check(lib.caf_sum_groups_qf2(ct.c_void_p(d_planes.ptr), G, Sc, k, ct.c_void_p(st["d_ph"].ptr), ct.c_void_p(d_norm.ptr),
+                                              st["ynormsq"], ct.c_void_p(d_out[s0 : s0 + Sc].ptr), None), "caf_sum_groups_qf2")
         return _RowsResult(d_out), np.arange(S)
 
 
@@ -457,7 +502,10 @@ class GroupXcorrCZT(_GroupEngine):
         self.ystackNormSq = float(sum(np.sum(np.abs(g.astype(np.complex128)) ** 2) for g in groups))
         self._k = int((f2 - f1) / binWidth + 1)
         self._freq = np.arange(f1, f2 + binWidth / 2, binWidth)
-        self._setup(groups, self.starts - self.starts[0], lengths, autoConj, freqs_norm=self._freq[: self._k] / fs)
+        # (evaluated where CZTCached evaluates -- f1 + i (f2 - f1 + binWidth) / k, the labels whenever the span is a whole
+        #  number of bins --, like cztXcorr above; reported at the labels)
+        f_eval = f1 + np.arange(self._k) * ((f2 - f1 + binWidth) / self._k)
+        self._setup(groups, self.starts - self.starts[0], lengths, autoConj, freqs_norm=f_eval / fs)
         self._czt_grid = (f1, f2, binWidth, fs)
         self._first = int(self.starts[0])
 
@@ -468,8 +516,7 @@ class GroupXcorrCZT(_GroupEngine):
         else:
             shifts = np.asarray(shifts)
             assert shifts[-1] + self.starts[-1] + self.lengths[-1] < rx.size
-        res, rel = self._run(rx, shifts + self._first, surface=True, rows=False, peak=False)
-        return res.surface.get()[0][rel].astype(np.float64), self._freq
+        return self._surface_host(rx, shifts + self._first, np.float64), self._freq
 
 
 class GroupXcorrFFT(_GroupEngine):
@@ -515,8 +562,7 @@ class GroupXcorrFFT(_GroupEngine):
         if flattenToTime:
             res, rel = self._run(rx, shifts + self._first, rows=True, peak=False)
             return res.row_max.get()[0][rel].astype(np.float64), res.row_arg.get()[0][rel].astype(np.uint32)
-        res, rel = self._run(rx, shifts + self._first, surface=True, rows=False, peak=False)
-        return res.surface.get()[0][rel].astype(np.float64)
+        return self._surface_host(rx, shifts + self._first, np.float64)
 
     def xcorrThreads(self, rx, shifts=None, NUM_THREADS=4):
         return self.xcorr(rx, shifts, flattenToTime=False)
@@ -751,8 +797,7 @@ class CyGroupXcorrFFT(_GroupEngine):
         shifts = np.asarray(shifts)
         if rx.dtype != np.complex64 or shifts.dtype != np.int32:
             raise ValueError("rx must be complex64 and shifts int32")
-        res, rel = self._run(rx, shifts, surface=True, rows=False, peak=False)
-        return res.surface.get()[0][rel]
+        return self._surface_host(rx, shifts, np.float32)
 
 
 class pbIppGroupXcorrCZT(_GroupEngine):
@@ -827,8 +872,7 @@ class pbIppGroupXcorrCZT(_GroupEngine):
             self._czt_grid = (self._f1, self._f2, self._fstep, self._fs)
             self._ready = True
         shifts = shiftStart + self._base + shiftStep * np.arange(numShifts)
-        res, rel = self._run(x, shifts, surface=True, rows=False, peak=False)
-        return res.surface.get()[0][rel]
+        return self._surface_host(x, shifts, np.float32)
 
 
 # ------------------------------------------------------------------------------------------

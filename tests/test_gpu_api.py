@@ -196,7 +196,7 @@ def test_cztxcorr(golden, rows_path, monkeypatch):
         # the rule: a fine search over a handful of delays of a long cutout is the per-delay form, everything else the engine
         assert X._czt_rows_pay(20_000, 401, 101) and X._czt_rows_pay(4096, 129, 8)
         assert not X._czt_rows_pay(200, 201, 1800) and not X._czt_rows_pay(4096, 256, 1 << 20)
-        assert not X._czt_rows_pay(100_000, 2001, 200)  # (rows longer than 32768 points stay on the engine)
+        assert X._czt_rows_pay(100_000, 2001, 200)  # (rows of any length: round 4's "stay on the engine" rule was a transfer stall)
         # ... and both forms agree on such a case: 20000-sample cutout, 21 delays around the truth, 401 bins
         rng = np.random.default_rng(9)
         cut = cn(rng, 20_000)

@@ -805,9 +805,9 @@ def test_hypothesis_major_surface_rules():
 
 @pytest.mark.parametrize("engine", ["persistent", "fused", "rocfft"])
 def test_quiet_windows_late_in_a_long_record(engine):
-    """The zero-energy rule is a threshold on float64 prefix differences (CAF_ENERGY_FLOOR, caf_internal.h): 10^7 loud
-    samples, then a stretch 90 dB below them that holds a (scaled) copy of the template, then a gap of exact zeros.  On every
-    engine the quiet windows are FINITE -- and right: QF^2 does not depend on the scale -- and the gap is NaN."""
+    """10^7 loud samples, then a stretch 90 dB below them that holds a (scaled) copy of the template, then a gap of exact
+    zeros.  On every engine the quiet windows are FINITE -- and right: QF^2 does not depend on the scale -- and the gap is NaN
+    (only an energy of exactly zero is: csrc/caf_energy.h; the deeper levels: test_quiet_windows_down_to_minus_160_db)."""
     from pydsproutines_amd import CAFPlan, asarray
 
     rng = np.random.default_rng(9)
@@ -838,3 +838,80 @@ def test_quiet_windows_late_in_a_long_record(engine):
     #  about one part in a thousand; the 16384-point engines take it from a block-local prefix and hold 1e-4 here)
     assert np.max(np.abs(res.surface.get()[0][sel - lo] - ref)) <= (5e-3 if engine == "rocfft" else 1e-4) * ref.max()
     plan.close()
+
+
+_QUIET_RX = {}
+
+
+def _quiet_record(db):
+    """2^24 unit-power samples, then -- `db` below them -- 3 x 65536 samples with a scaled copy of the template, exact zeros and
+    20000 more quiet samples: from the start of the quiet stretch on, every engine's overlap-save blocks (and their float32
+    transforms) see nothing but quiet samples."""
+    if db not in _QUIET_RX:
+        _QUIET_RX.clear()  # (one 134 MB record at a time)
+        rng = np.random.default_rng(1000 - db)
+        n, loud, quiet_len = 4096, 1 << 24, 3 * 65536
+        t = qpsk(rng, n)
+        a = np.float32(10.0 ** (db / 20))
+        rx = np.concatenate((cn(rng, loud), a * cn(rng, quiet_len), np.zeros(3 * n, np.complex64), a * cn(rng, 20000)))
+        d0 = loud + 30000
+        rx[d0 : d0 + n] += a * t
+        _QUIET_RX[db] = (t, rx, loud, quiet_len, d0)
+    return _QUIET_RX[db]
+
+
+@pytest.mark.parametrize("engine", ["persistent", "fused", "rocfft"])
+@pytest.mark.parametrize("db", [-100, -120, -160])
+def test_quiet_windows_down_to_minus_160_db(engine, db):
+    """The reference divides by the window's own norm (xcorrRoutines.py:527-528; ippsNorm_L2 per window, IppXcorrFFT.cpp:133-175)
+    and is finite for every window that is not exactly zero.  Windows 100 / 120 / 160 dB below the 2^24 unit-power samples in
+    front of them: a float64 prefix over the record resolves 2^-53 x 2^24 x (a few) -- the -100 dB windows to two digits, the
+    others not at all -- so their energies are summed again directly (caf_energy.h).  Finite, within 1e-4 of the oracle, and
+    the same NaN pattern -- exactly the windows of zeros -- on every engine."""
+    from pydsproutines_amd import CAFPlan, asarray
+
+    t, rx, loud, quiet_len, d0 = _quiet_record(db)
+    n, m = t.size, rx.size
+    bins = np.arange(-2, 2)
+    plan = CAFPlan(t, max_rx_len=m, bins=bins, grid=n, engine=engine)
+    lo = loud  # block 0 starts with the quiet stretch
+    S = m - n + 1 - lo
+    res = plan.run(asarray(rx), shift_start=lo, num_shifts=S, surface=True)
+    rm, surf = res.row_max.get()[0], res.surface.get()[0]
+    # NaN <=> the window holds nothing but zeros
+    zeros_lo, zeros_hi = quiet_len, quiet_len + 3 * n  # (relative to lo) the zeros are samples [zeros_lo, zeros_hi)
+    expect_nan = np.zeros(S, bool)
+    expect_nan[zeros_lo : zeros_hi - n + 1] = True
+    assert np.array_equal(np.isnan(rm), expect_nan)
+    assert np.array_equal(np.isnan(surf).all(axis=1), expect_nan) and np.array_equal(np.isnan(surf).any(axis=1), expect_nan)
+    assert np.all(res.row_arg.get()[0][expect_nan] == 0)
+    # right to 1e-4 (QF^2 does not depend on the scale): around the planted copy, anywhere in the quiet stretch, and across
+    # the edges of the zeros (windows that hold a few quiet samples and zeros otherwise)
+    rng = np.random.default_rng(3)
+    sel = np.unique(np.concatenate((np.arange(d0 - lo - 40, d0 - lo + 40), rng.integers(0, quiet_len - n, 60),
+                                    np.arange(zeros_lo - n + 1, zeros_lo - n + 9), np.arange(zeros_hi - 8, zeros_hi))))
+    ref = O.caf_bins(t, rx, bins, sel + lo)
+    assert 0.3 < ref.max() < 0.7
+    assert np.max(np.abs(surf[sel] - ref)) <= 1e-4 * ref.max()
+    assert int(res.peak_delay.get()[0]) == d0 and int(bins[res.peak_freq.get()[0]]) == 0
+    plan.close()
+
+
+@pytest.mark.parametrize("n", [1000, 1200, 1430, 4096])
+def test_quiet_windows_on_the_per_delay_path(n):
+    """The same record through fastXcorr's frequency-search branch: the radix-10 kernel (1000), the mixed-radix kernel (1200), the
+    three-kernel form (1430: k_sliding_multiply) -- all three normalise from the float64 prefix -- and the power-of-two kernel,
+    which sums its own windows: -120 dB windows finite and within 1e-4 of the oracle, windows of zeros (NaN, 0)."""
+    from pydsproutines_amd.xcorrRoutines import fastXcorr
+
+    t, rx, loud, quiet_len, d0 = _quiet_record(-120)
+    cut = rx[d0 : d0 + n].copy()
+    sh = np.concatenate((np.arange(d0 - 20, d0 + 20), np.arange(loud + 100, loud + 140),
+                         np.arange(loud + quiet_len, loud + quiet_len + 8)))  # ... and 8 windows of zeros (n <= 3 x 4096 - 8)
+    q, fi = fastXcorr(cut, rx, freqsearch=True, shifts=sh)
+    rq, rfi = O.fastXcorr(cut, rx, freqsearch=True, shifts=sh[:-8])
+    assert np.all(np.isnan(q[-8:])) and np.all(fi[-8:] == 0)
+    assert not np.any(np.isnan(q[:-8]))
+    np.testing.assert_allclose(q[:-8], rq, atol=1e-4)
+    assert abs(q[20] - 1.0) < 1e-4 and fi[20] == 0
+    np.testing.assert_array_equal(fi[:40], rfi[:40])
