@@ -277,10 +277,17 @@ def run_c4(args, torch, dist, device, world, rank, rehearse):
     stages = plan.profile_get()
     plan.profile(False)
     tb = check_table()
+    rank_ms, gather_ms = None, None
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        elapsed, rank_ms = rank_times(torch, dist, elapsed, args.steps, world, rehearse, device)
+        fence()
+        tg = []
+        for _ in range(5):  # the collective alone (the engine's three output arrays, read in place)
+            t1 = time.perf_counter()
+            sharding.all_gather_peak_columns(cols.cpu() if rehearse else cols, T)
+            torch.cuda.synchronize()
+            tg.append((time.perf_counter() - t1) * 1e3)
+        gather_ms = {"first": tg[0], "median_of_5": float(np.median(tg))}
     if rank != 0:
         return
     dt = elapsed / args.steps
@@ -331,6 +338,9 @@ def run_c4(args, torch, dist, device, world, rank, rehearse):
                              "min_peak_qf2": float(pv.min()), "max_peak_qf2": float(pv.max())},
         "stages_ms_per_step": {k: v[0] / args.steps for k, v in stages.items()},
     }
+    if rank_ms is not None:
+        out["per_rank_ms_per_step"] = {"min": min(rank_ms), "max": max(rank_ms), "ranks": rank_ms}
+        out["peak_table_allgather_ms"] = gather_ms
     print(json.dumps(out))
 
 
@@ -398,10 +408,9 @@ def run_c2_freq_shard(args, torch, dist, device, world, rank, rehearse):
     stages = plan.profile_get()
     plan.profile(False)
     pv = check()
+    rank_ms = None
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        elapsed, rank_ms = rank_times(torch, dist, elapsed, args.steps, world, rehearse, device)
     if rank != 0:
         return
     dt = elapsed / args.steps
@@ -449,7 +458,19 @@ def run_c2_freq_shard(args, torch, dist, device, world, rank, rehearse):
         "peak_check": {"delay": D0, "bin": K0, "qf2": pv, "exact_on_every_rank": True},
         "stages_ms_per_step": {k: v[0] / args.steps for k, v in stages.items()},
     }
+    if rank_ms is not None:
+        out["per_rank_ms_per_step"] = {"min": min(rank_ms), "max": max(rank_ms), "ranks": rank_ms}
     print(json.dumps(out))
+
+
+def rank_times(torch, dist, elapsed, steps, world, rehearse, device):
+    """Every rank's own time for the timed steps: (max over ranks in s, per-rank ms per step) -- a straggler or a slow first
+    collective shows as max >> min in the one line the driver keeps."""
+    mine = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else device)
+    allr = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allr, mine)
+    vals = [float(t.item()) for t in allr]
+    return max(vals), [v / steps * 1e3 for v in vals]
 
 
 def launch_ranks(n, argv):
@@ -734,11 +755,7 @@ def main():
     rank_ms, gather_ms = None, None
     if world > 1:
         # every rank's own time for the K steps (a straggler shows as max >> min) and what the collective alone costs
-        mine = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else device)
-        allr = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allr, mine)
-        rank_ms = [float(t.item()) / args.steps * 1e3 for t in allr]
-        elapsed = max(float(t.item()) for t in allr)
+        elapsed, rank_ms = rank_times(torch, dist, elapsed, args.steps, world, rehearse, device)
         tb = gathered["table"].cpu().numpy()
         if not all(int(r[0]) == D0 and int(bins[r[1]]) == K0 for r in tb):
             raise SystemExit("gathered peak table is wrong: %r" % (tb,))

@@ -112,6 +112,7 @@ _SIGNATURES = {
     "caf_last_error": [ct.c_char_p, _I32],
     "caf_abi_version": [],
     "caf_xcorr_perdelay_one_kernel": [_I32],
+    "caf_perdelay_jit_describe": [_I32, ct.c_char_p, ct.c_char_p, ct.c_char_p, _I32],
     "caf_device_count": [ct.POINTER(_I32)],
     "caf_set_device": [_I32],
     "caf_device_info": [_I32, ct.c_char_p, _I32, ct.POINTER(_I64), ct.POINTER(_I32)],

@@ -1,9 +1,15 @@
 // Window energies from a float64 prefix of |x|^2, exact where a difference of prefix entries is not (caf_internal.h,
 // CAF_ENERGY_RESOLVED): device helpers shared by every kernel that normalises by a window energy.
 #pragma once
-#include "caf_internal.h"
+#ifndef __HIPCC_RTC__
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#endif
 
 namespace caf {
+
+// (what the threshold is and why: caf_internal.h, "Window energies")
+constexpr double CAF_ENERGY_RESOLVED = 9.313225746154785e-10;  // 2^-30
 
 // where the chunk energies of a prefix over m samples start (launch_energy_prefix writes them there)
 __device__ __forceinline__ const double* energy_chunks(const double* prefix, int64_t m) { return prefix + ((m + 2) & ~(int64_t)1); }

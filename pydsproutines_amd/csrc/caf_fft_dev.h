@@ -1,7 +1,9 @@
 // Device-side complex helpers and the in-register inverse DFT butterflies shared by the LDS-resident FFT kernels
 // (caf_fused.hip: 16384-point hypothesis transform; caf_perdelay.hip: per-delay row transforms).
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
+#endif
 
 namespace caf {
 

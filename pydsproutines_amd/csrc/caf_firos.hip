@@ -54,10 +54,13 @@ template <int LOGN, typename TIn>
 __global__ __launch_bounds__((1 << LOGN) / 16 > 256 ? (1 << LOGN) / 16 : 256, 4) void k_fir_os(
     const TIn* __restrict__ x, int64_t n, const TIn* __restrict__ delay, int32_t dlen, float scale,
     const float2* __restrict__ ht, const float2* __restrict__ tw, int32_t ntaps, int32_t dsr, int32_t phase,
-    float2* __restrict__ out, int64_t nout, int64_t nblk) {
+    float2* __restrict__ out, int64_t nout, int64_t nblk, int64_t x_row_stride, int64_t out_row_stride) {
     constexpr int N = 1 << LOGN, NTR = N / 16, WG = NTR > 256 ? NTR : 256, RPW = WG / NTR;
     extern __shared__ __attribute__((aligned(16))) float2 s_buf[];
     const int tid = threadIdx.x;
+    // (blockIdx.y: independent signals of n samples each, x_row_stride / out_row_stride apart -- the rows of upfirdn)
+    x += (int64_t)blockIdx.y * x_row_stride;
+    out += (int64_t)blockIdx.y * out_row_stride;
     const int rl = tid / NTR, l = tid - rl * NTR;
     float2* buf = s_buf + rl * (N + N / 16);
     const int64_t b = (int64_t)blockIdx.x * RPW + rl;
@@ -169,7 +172,8 @@ int fos_taps_launch(const float* taps, int32_t ntaps, const float2* tw, float2* 
 
 template <int LOGN, typename TIn>
 int fos_launch(const TIn* x, int64_t n, const TIn* delay, int32_t dlen, float scale, const float2* ht, const float2* tw,
-               int32_t ntaps, int32_t dsr, int32_t phase, float2* out, int64_t nout, hipStream_t st) {
+               int32_t ntaps, int32_t dsr, int32_t phase, float2* out, int64_t nout, hipStream_t st, int64_t rows = 1,
+               int64_t x_row_stride = 0, int64_t out_row_stride = 0) {
     constexpr int N = 1 << LOGN, NTR = N / 16, WG = NTR > 256 ? NTR : 256, RPW = WG / NTR;
     const size_t lds = (size_t)RPW * (N + N / 16) * sizeof(float2);
     {
@@ -181,8 +185,9 @@ int fos_launch(const TIn* x, int64_t n, const TIn* delay, int32_t dlen, float sc
     const int64_t nblk = last / L + 1;
     const int64_t nwg = (nblk + RPW - 1) / RPW;
     CAF_REQUIRE(nwg <= 0x7fffffff, "overlap-save FIR: too many blocks for one launch");
-    hipLaunchKernelGGL((k_fir_os<LOGN, TIn>), dim3((unsigned)nwg), dim3(WG), lds, st, x, n, delay, dlen, scale, ht, tw, ntaps,
-                       dsr, phase, out, nout, nblk);
+    CAF_REQUIRE(rows >= 1 && rows <= 65535, "overlap-save FIR: too many rows for one launch");
+    hipLaunchKernelGGL((k_fir_os<LOGN, TIn>), dim3((unsigned)nwg, (unsigned)rows), dim3(WG), lds, st, x, n, delay, dlen, scale, ht, tw,
+                       ntaps, dsr, phase, out, nout, nblk, x_row_stride, out_row_stride);
     return CAF_OK;
 }
 
@@ -199,7 +204,8 @@ int fir_os_fused_block(int32_t ntaps) {
 // ht: scratch of fir_os_fused_block(ntaps) complex values
 template <typename TIn>
 static int fir_os_fused_t(const TIn* x, int64_t n, const float* taps, int32_t ntaps, const TIn* delay, int32_t dlen, float scale,
-                          int32_t dsr, int32_t phase, float2* out, int64_t nout, float2* ht, hipStream_t st) {
+                          int32_t dsr, int32_t phase, float2* out, int64_t nout, float2* ht, hipStream_t st, int64_t rows = 1,
+                          int64_t xs = 0, int64_t os = 0) {
     if (nout <= 0) return CAF_OK;
     int dev = 0;
     CAF_HIP_TRY(hipGetDevice(&dev));
@@ -209,20 +215,21 @@ static int fir_os_fused_t(const TIn* x, int64_t n, const float* taps, int32_t nt
     switch (fir_os_fused_block(ntaps)) {
         case 1024:
             if ((rc = fos_taps_launch<10>(taps, ntaps, tw, ht, st))) return rc;
-            return fos_launch<10, TIn>(x, n, delay, dlen, scale, ht, tw, ntaps, dsr, phase, out, nout, st);
+            return fos_launch<10, TIn>(x, n, delay, dlen, scale, ht, tw, ntaps, dsr, phase, out, nout, st, rows, xs, os);
         case 4096:
             if ((rc = fos_taps_launch<12>(taps, ntaps, tw, ht, st))) return rc;
-            return fos_launch<12, TIn>(x, n, delay, dlen, scale, ht, tw, ntaps, dsr, phase, out, nout, st);
+            return fos_launch<12, TIn>(x, n, delay, dlen, scale, ht, tw, ntaps, dsr, phase, out, nout, st, rows, xs, os);
         case 16384:
             if ((rc = fos_taps_launch<14>(taps, ntaps, tw, ht, st))) return rc;
-            return fos_launch<14, TIn>(x, n, delay, dlen, scale, ht, tw, ntaps, dsr, phase, out, nout, st);
+            return fos_launch<14, TIn>(x, n, delay, dlen, scale, ht, tw, ntaps, dsr, phase, out, nout, st, rows, xs, os);
     }
     set_error("overlap-save FIR: tap set too long for the fused form");
     return CAF_ERR_INVALID;
 }
 int launch_fir_os_fused(const float2* x, int64_t n, const float* taps, int32_t ntaps, const float2* delay, int32_t dlen,
-                        int32_t dsr, int32_t phase, float2* out, int64_t nout, float2* ht, hipStream_t st) {
-    return fir_os_fused_t<float2>(x, n, taps, ntaps, delay, dlen, 1.0f, dsr, phase, out, nout, ht, st);
+                        int32_t dsr, int32_t phase, float2* out, int64_t nout, float2* ht, hipStream_t st, int64_t rows,
+                        int64_t x_row_stride, int64_t out_row_stride) {
+    return fir_os_fused_t<float2>(x, n, taps, ntaps, delay, dlen, 1.0f, dsr, phase, out, nout, ht, st, rows, x_row_stride, out_row_stride);
 }
 int launch_iq16_fir_os_fused(const int16_t* iq, int64_t n, float scale, const float* taps, int32_t ntaps, const int16_t* delay,
                              int32_t dlen, int32_t dsr, int32_t phase, float2* out, int64_t nout, float2* ht, hipStream_t st) {

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include "caf.h"
+#include "caf_energy.h"
 
 #include <map>
 #include <mutex>
@@ -26,7 +27,6 @@ constexpr int MAG_F = 128;        // frequency hypotheses per LDS chunk (512 B s
 // therefore means an energy of exactly zero on every engine, as in the reference's 0 / 0 (xcorrRoutines.py:527-528,
 // IppXcorrFFT.cpp:174); rounds 1-4 reported anything below 2^-44 of the prefix as zero energy, with the floor in different
 // places on different engines.  (caf_energy.h; tests/test_gpu_engine.py::test_quiet_windows_*)
-constexpr double CAF_ENERGY_RESOLVED = 9.313225746154785e-10;  // 2^-30
 // a prefix buffer for m samples: m + 1 prefix entries (padded to an even count), then the chunk energies
 inline int64_t energy_prefix_doubles(int64_t m) { return ((m + 2) & ~(int64_t)1) + (m + 63) / 64 + 1; }
 
@@ -174,6 +174,14 @@ bool perdelay_mixed_ok(int32_t n);
 int launch_perdelay_mixed(const float2* x, int32_t n, const float2* y, int64_t ylen, const double* prefix, const double* xnorm,
                           int64_t start, int64_t step, int64_t num, int32_t zero_oor, float* qf2, uint32_t* fidx, float* plane,
                           float2* cplane, hipStream_t st);
+// the same lengths (and the powers of two and of ten) with a kernel compiled at run time for the length (caf_jit.hip, caf_perdelay_jit.h):
+// false when CAF_JIT=0, hiprtc is missing or the length has no plan -- the callers then use the kernels above
+bool perdelay_jit_ok(int32_t n);
+void perdelay_jit_failed(int32_t n);  // (a length whose compilation failed: not tried again in this process)
+int launch_perdelay_jit(const float2* x, int32_t n, const float2* y, int64_t ylen, const double* prefix, const double* xnorm,
+                        int64_t start, int64_t step, int64_t num, int32_t zero_oor, float* qf2, uint32_t* fidx, float* plane,
+                        float2* cplane, hipStream_t st);
+int perdelay_jit_describe(int32_t n, const char* arch, const char* dump_path, std::string* text);  // plan + layout as text (no GPU needed)
 int cutout_norm_scratch_doubles();
 const double* launch_cutout_norm(const float2* x, int64_t n, double* parts, hipStream_t st);  // -> device address of ||x||
 // e^{+j 2 pi q / 16384}, q < 16384: the twiddle table of the in-LDS transforms (caf_ldsfft.h), built once per device
@@ -208,8 +216,10 @@ void launch_zoom_finish(const float* trace, const int32_t* row_arg, const double
 
 // caf_firos.hip: overlap-save FIR (fused in-LDS form for <= 8192 taps; gather / scatter kernels for the rocFFT rows)
 int fir_os_fused_block(int32_t ntaps);
+// rows > 1: independent signals x + r x_row_stride -> out + r out_row_stride in one launch (no carried-in history)
 int launch_fir_os_fused(const float2* x, int64_t n, const float* taps, int32_t ntaps, const float2* delay, int32_t dlen,
-                        int32_t dsr, int32_t phase, float2* out, int64_t nout, float2* ht, hipStream_t st);
+                        int32_t dsr, int32_t phase, float2* out, int64_t nout, float2* ht, hipStream_t st, int64_t rows = 1,
+                        int64_t x_row_stride = 0, int64_t out_row_stride = 0);
 int launch_iq16_fir_os_fused(const int16_t* iq, int64_t n, float scale, const float* taps, int32_t ntaps, const int16_t* delay,
                              int32_t dlen, int32_t dsr, int32_t phase, float2* out, int64_t nout, float2* ht, hipStream_t st);
 void launch_fos_gather(const float2* x, int64_t n, const float2* delay, int32_t dlen, int64_t b0, int64_t nb, int64_t L,

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <complex>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -268,6 +269,14 @@ int32_t caf_xcorr_perdelay_one_kernel(int32_t n) {
     return (perdelay_fused_ok(n) || perdelay_decimal_ok(n) || perdelay_mixed_ok(n)) ? 1 : 0;
 }
 
+int32_t caf_perdelay_jit_describe(int32_t n, const char* arch, const char* dump_path, char* buf, int32_t len) {
+    CAF_REQUIRE(buf && len > 0, "caf_perdelay_jit_describe: no buffer");
+    std::string text;
+    const int rc = perdelay_jit_describe(n, arch, dump_path, &text);
+    std::snprintf(buf, (size_t)len, "%s", text.c_str());
+    return rc;
+}
+
 int32_t caf_xcorr_perdelay(const float* d_cutout, int32_t n, const float* d_rx, int64_t rx_len, int64_t start,
                            int64_t step, int64_t num, int32_t zero_oor, float* d_qf2, int32_t* d_fidx, float* d_caf,
                            float* d_ccaf, int64_t batch_rows, void* stream) {
@@ -279,6 +288,11 @@ int32_t caf_xcorr_perdelay(const float* d_cutout, int32_t n, const float* d_rx, 
     }
     if (num == 0) return CAF_OK;
     hipStream_t st = (hipStream_t)stream;
+    // CAF_JIT_ALL=1 (measurements): the powers of two and of ten through the run-time-compiled kernel as well
+    const bool jit_all = [] {
+        const char* e = getenv("CAF_JIT_ALL");
+        return e && atoi(e) != 0;
+    }();
     // Power-of-two cutouts up to 16384 samples: one fused kernel (product -> LDS FFT -> |.|^2 -> argmax; window energies
     // and the cutout norm summed in the kernel): no product matrix, no prefix pass, no scratch, no synchronisation.
     // CAF_PERDELAY_UNFUSED=1 keeps the three-kernel form below (A/B switch; it also serves every other length).
@@ -287,7 +301,7 @@ int32_t caf_xcorr_perdelay(const float* d_cutout, int32_t n, const float* d_rx, 
             const char* e = getenv("CAF_PERDELAY_UNFUSED");
             return e && atoi(e) != 0;
         }();
-        if (!unfused && perdelay_fused_ok(n)) {
+        if (!unfused && perdelay_fused_ok(n) && !(jit_all && perdelay_jit_ok(n))) {
             const int rc1 = launch_perdelay_fused((const float2*)d_cutout, n, (const float2*)d_rx, rx_len, start, step, num,
                                                   zero_oor ? 1 : 0, d_qf2, (uint32_t*)d_fidx, d_caf, (float2*)d_ccaf, st);
             if (rc1) return rc1;
@@ -320,8 +334,27 @@ int32_t caf_xcorr_perdelay(const float* d_cutout, int32_t n, const float* d_rx, 
             const char* e = getenv("CAF_PERDELAY_UNFUSED");
             return e && atoi(e) != 0;
         }();
+        // 2^a 3^b 5^c 7^d lengths that are neither a power of two nor of ten: a kernel compiled for the length at run time
+        // (caf_jit.hip); a length / box without one, or a compilation that fails (reported once), keeps the plan-driven kernel
+        if (!unfused10 && ((!perdelay_decimal_ok(n) && perdelay_mixed_ok(n)) || jit_all) && perdelay_jit_ok(n)) {
+            rc = launch_perdelay_jit((const float2*)d_cutout, n, yv, ylen_v, prefix, d_norm, start_v, step, num, zero_oor ? 1 : 0, d_qf2,
+                                     (uint32_t*)d_fidx, d_caf, (float2*)d_ccaf, st);
+            if (rc == CAF_OK) {
+                CAF_HIP_TRY(hipStreamSynchronize(st));  // scratch (prefix, norm) is freed on return
+                CAF_HIP_TRY(hipGetLastError());
+                return CAF_OK;
+            }
+            perdelay_jit_failed(n);
+            static bool said = false;
+            if (!said) {
+                said = true;
+                char msg[2048];
+                caf_last_error(msg, sizeof(msg));
+                std::fprintf(stderr, "[caf] run-time compilation unavailable, using the prebuilt per-delay kernels: %s\n", msg);
+            }
+        }
         if (!unfused10 && (perdelay_decimal_ok(n) || perdelay_mixed_ok(n))) {
-            // (2^a 3^b 5^c 7^d lengths that are neither a power of two nor of ten: the mixed-radix kernel, caf_perdelay_mr.hip)
+            // (the radix-10 kernel of caf_perdelay.hip / the plan-driven mixed-radix kernel of caf_perdelay_mr.hip)
             rc = perdelay_decimal_ok(n)
                      ? launch_perdelay_decimal((const float2*)d_cutout, n, yv, ylen_v, prefix, d_norm, start_v, step, num,
                                                zero_oor ? 1 : 0, d_qf2, (uint32_t*)d_fidx, d_caf, (float2*)d_ccaf, st)
@@ -555,6 +588,22 @@ int32_t caf_upfirdn(const float* d_x, int64_t rows, int64_t n, const float* d_ta
     CAF_REQUIRE(num_taps >= 1 && num_taps <= 16384 && up >= 1 && down >= 1, "caf_upfirdn: bad taps/up/down");
     const int64_t full = ((n - 1) * up + num_taps + down - 1) / down;
     CAF_REQUIRE(out_len >= 1 && out_len <= full, "caf_upfirdn: out_len larger than the full upfirdn length");
+    // up == 1 is a FIR with decimation: full-convolution outputs [0 :: down] (zeros beyond the input).  From 96 taps per unit of
+    // decimation on, the overlap-save form (caf_firos.hip: the rows are blockIdx.y of ONE launch) -- 64 x 262144 samples, 128
+    // taps, up = down = 1: 0.38 ms through the polyphase kernel (0.09 of the HBM bound), the same job as caf_fir_lfilter otherwise
+    if (up == 1 && d_out && !d_out_abs && fir_os_fused_block(num_taps) && fir_use_overlap_save(num_taps, down, 1 << 30)) {
+        hipStream_t st = (hipStream_t)stream;
+        Scratch sc;
+        float2* ht = nullptr;
+        int rc = sc.get(&ht, fir_os_fused_block(num_taps));
+        if (rc) return rc;
+        rc = launch_fir_os_fused((const float2*)d_x, n, d_taps, num_taps, nullptr, 0, down, 0, (float2*)d_out, out_len, ht, st, rows, n,
+                                 out_len);
+        if (rc) return rc;
+        if (st != nullptr) CAF_HIP_TRY(hipStreamSynchronize(st));  // (scratch: stream-ordered on the default stream, see fir_overlap_save)
+        CAF_HIP_TRY(hipGetLastError());
+        return CAF_OK;
+    }
     launch_upfirdn((const float2*)d_x, rows, n, d_taps, num_taps, up, down, out_len, (float2*)d_out, d_out_abs,
                    (hipStream_t)stream);
     CAF_HIP_TRY(hipGetLastError());

@@ -16,6 +16,7 @@ signatures are widened copies of those results.
 """
 
 import ctypes as ct
+import os
 
 import numpy as np
 
@@ -136,7 +137,10 @@ def _host_surface(plan, d_rx, lo, cnt, rel, dtype):
     rel = np.asarray(rel)
     F = plan.F
     lib = _lib.load()
-    if plan.T == 1 and F > 1 and plan.engine_used == "persistent" and plan.block == 16384:
+    # (CAF_HOST_SURFACE_DELAY_MAJOR=1: the delay-major launch + plain download + NumPy selection / widening of rounds 1-4 --
+    #  an A/B switch for scripts/time_host_surface.py)
+    if plan.T == 1 and F > 1 and plan.engine_used == "persistent" and plan.block == 16384 \
+            and os.environ.get("CAF_HOST_SURFACE_DELAY_MAJOR") != "1":
         res = plan.run(d_rx, shift_start=lo, num_shifts=cnt, surface_t=True, rows=False, peak=False)
         contiguous = rel.size > 0 and rel[-1] - rel[0] + 1 == rel.size and (rel.size == 1 or np.all(np.diff(rel) == 1))
         c0, nc = (int(rel[0]), int(rel.size)) if contiguous else (0, cnt)

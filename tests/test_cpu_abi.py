@@ -118,3 +118,34 @@ def test_header_is_plain_c_and_the_library_links_from_c():
     assert r.returncode == 0, r.stdout + r.stderr
     assert "warning" not in (r.stdout + r.stderr).lower()
     assert os.path.exists(os.path.join(d, "caf_client"))
+
+
+def test_perdelay_jit_planner_and_compile_without_a_gpu():
+    """The planner of the run-time-compiled per-delay kernel (caf_jit.hip) runs on the host: every 7-smooth length has a plan whose
+    row images fit the LDS and whose simulated bank-conflict cycles stay a small fraction; one length is also compiled for gfx950
+    through hiprtc (no GPU needed for that) when hiprtc is installed."""
+    import ctypes as ct
+
+    from pydsproutines_amd import _lib
+
+    lib = _lib.load()
+
+    def describe(n, arch=None):
+        buf = ct.create_string_buffer(2048)
+        rc = lib.caf_perdelay_jit_describe(n, arch, None, buf, 2048)
+        return rc, dict(kv.split("=", 1) for kv in buf.value.decode().split(" ") if "=" in kv)
+
+    for n in (96, 360, 1200, 1400, 2401, 5000, 12000, 16200, 4096):
+        rc, d = describe(n)
+        assert rc == 0 and int(d["n"]) == n, (n, d)
+        rad = [int(r) for r in d["radices"].split(",")]
+        assert int(np.prod(rad)) == n and 2 <= len(rad) <= 5
+        assert int(d["lds_bytes"]) <= 160 * 1024 - 64
+        assert int(d["conflict_cycles"]) <= 0.4 * int(d["base_cycles"]), d
+    rc, d = describe(97)  # (a prime: no plan)
+    assert rc == 0 and not d
+    rc, d = describe(1200, b"gfx950")
+    if rc == 0:
+        assert int(d["code_bytes"]) > 4000
+    else:  # no hiprtc on this box: the library says so and the prebuilt kernels stay in charge
+        assert "hiprtc" in _lib.last_error()

@@ -5,13 +5,15 @@ filterRoutines.py:1245-1365 (moving averages), benchmark_upfirdnkernels.py:58-67
 benchmark_filterkernels.py:72-74, benchmark_xcorrs.py:55-59, pybinds/*/test.py.
 Float tolerance: GPU complex64 vs the oracle -> 2e-5 absolute on QF / QF^2 values in [0, 1]."""
 
+import os
+
 import numpy as np
 import pytest
 import scipy.signal as sps
 
 import oracle as O
 from oracle import kernels as K
-from conftest import cn, qpsk
+from conftest import REPO, cn, qpsk
 
 pytestmark = pytest.mark.gpu
 TOL = 2e-5
@@ -959,6 +961,58 @@ def test_c_abi_peak_table_allgather_world_of_one():
     _lib.check(lib.caf_stream_sync(None))
     np.testing.assert_array_equal(d_tab.get()[0], rows)
     _lib.check(lib.caf_comm_destroy(comm))
+
+
+_TWO_RANK_CODE = r"""
+import ctypes as ct, sys, numpy as np
+sys.path.insert(0, %r)
+from pydsproutines_amd import _lib, asarray
+from pydsproutines_amd.devarray import empty
+rank, world, uid_path = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+lib = _lib.load()
+_lib.check(lib.caf_set_device(rank), "caf_set_device")
+uid = (ct.c_ubyte * 128).from_buffer_copy(open(uid_path, "rb").read())
+comm = ct.c_void_p()
+_lib.check(lib.caf_comm_create(ct.byref(comm), world, rank, uid), "caf_comm_create")
+rows = np.stack((np.arange(5) * 1000 + rank, np.arange(5) - 2 * rank, np.full(5, 0.25 + rank, np.float32).view(np.int32))).astype(np.int32)
+d_loc, d_tab = asarray(rows), empty((world, 3, 5), np.int32)
+_lib.check(lib.caf_peak_table_allgather(comm, ct.c_void_p(d_loc.ptr), 5, ct.c_void_p(d_tab.ptr), None))
+_lib.check(lib.caf_stream_sync(None))
+tab = d_tab.get()
+for r in range(world):
+    want = np.stack((np.arange(5) * 1000 + r, np.arange(5) - 2 * r, np.full(5, 0.25 + r, np.float32).view(np.int32))).astype(np.int32)
+    assert np.array_equal(tab[r], want), (rank, r, tab[r])
+_lib.check(lib.caf_comm_destroy(comm))
+print("rank %%d ok" %% rank)
+"""
+
+
+def test_c_abi_peak_table_allgather_two_ranks():
+    """The same exchange with TWO ranks, one process per GPU, the unique id handed over through a file as a launcher would:
+    runs wherever two GPUs are visible (the driver's 8-GPU node), skips on the one-GPU boxes of this pool."""
+    import subprocess
+    import sys
+    import tempfile
+
+    import ctypes as ct
+
+    from pydsproutines_amd import _lib
+
+    if _lib.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL over xGMI): %d visible" % _lib.device_count())
+    lib = _lib.load()
+    uid = (ct.c_ubyte * 128)()
+    _lib.check(lib.caf_comm_unique_id(uid), "caf_comm_unique_id")
+    with tempfile.NamedTemporaryFile(suffix=".uid", delete=False) as f:
+        f.write(bytes(uid))
+        path = f.name
+    code = _TWO_RANK_CODE % REPO
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r), "2", path], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    os.unlink(path)
+    for r, (p, (out, err)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and "rank %d ok" % r in out, err[-2000:]
 
 
 def test_plain_c_client_of_the_abi():

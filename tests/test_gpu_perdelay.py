@@ -174,6 +174,7 @@ def test_mixed_radix_every_butterfly(n, plan, monkeypatch, capfd):
     """Radices 2 ... 10, 12, 14, 15, 16, 18, 20 (the composite ones as Cooley-Tukey butterflies in registers, radix 7 for
     7-smooth lengths such as 1400 = 2^3 5^2 7), first and later passes, against the oracle as above."""
     monkeypatch.setenv("CAF_MR_DEBUG", "1")
+    monkeypatch.setenv("CAF_JIT", "0")  # the prebuilt, plan-driven kernel (what a box without hiprtc runs)
     if plan:
         monkeypatch.setenv("CAF_MR_PLAN", plan)
     _composite_cutout_checks(n)
@@ -181,6 +182,41 @@ def test_mixed_radix_every_butterfly(n, plan, monkeypatch, capfd):
     assert "[caf mr] n=%d plan=" % n in err
     if plan:
         assert "[caf mr] n=%d plan=%s " % (n, plan) in err  # (the forced plan was valid and is the one that ran)
+
+
+# the same lengths and butterflies through the kernel compiled for the length at run time (caf_jit.hip, caf_perdelay_jit.h: in-place
+# decimation in frequency, layout by bank simulation); forced plans put every radix first, in the middle and last
+@pytest.mark.parametrize("n,plan", [(1200, None), (1400, None), (5000, None), (1536, None), (3000, None), (96, None), (12000, None),
+                                    (16200, None), (14336, None), (360, None), (15000, None), (48, None), (2401, None),
+                                    (125, "5,5,5/8"), (343, "7,7,7/25"), (72, "3,3,8/5"), (81, "9,9/6"), (50, "5,10/4"), (36, "3,12/3"),
+                                    (98, "7,14/7"), (225, "15,15/15"), (1280, "5,16,16/80"), (324, "2,9,18/21"), (400, "20,20/25"),
+                                    (8000, "20,20,20/500"), (96, "6,16/6"), (1200, "8,10,15/80"), (1200, "3,5,5,16/75"),
+                                    (1250, "25,25,2/64"), (2500, "4,25,25/125"), (7000, "7,10,10,10/500"), (7776, "6,6,6,6,6/432")])
+def test_jit_kernel_lengths_and_butterflies(n, plan, monkeypatch, capfd):
+    monkeypatch.setenv("CAF_JIT_DEBUG", "1")
+    monkeypatch.delenv("CAF_JIT", raising=False)
+    if plan:
+        monkeypatch.setenv("CAF_PDJ_PLAN", plan)
+    _composite_cutout_checks(n)
+    err = capfd.readouterr().err
+    assert "[caf jit] n=%d plan=" % n in err, err
+    if plan:
+        assert "[caf jit] n=%d plan=%s " % (n, plan) in err  # (the forced plan was valid and is the one that ran)
+
+
+def test_jit_and_prebuilt_kernels_agree(monkeypatch):
+    """The two mixed-radix kernels (run-time compiled / plan-driven) on the same rows: same maxima to float32 rounding, same bins."""
+    rng = np.random.default_rng(12)
+    n, m = 1200, 30_000
+    rx, cut = cn(rng, m), cn(rng, n)
+    out = {}
+    for jit in ("1", "0"):
+        monkeypatch.setenv("CAF_JIT", jit)
+        out[jit] = _perdelay(cut, rx, 3, 5, 4000, caf=True)
+    assert np.max(np.abs(out["1"][0] - out["0"][0])) <= 2e-6
+    np.testing.assert_allclose(out["1"][2], out["0"][2], atol=2e-6)
+    same = out["1"][1] == out["0"][1]
+    assert same.mean() > 0.999  # (float32 ties between two bins may fall either way)
 
 
 def _composite_cutout_checks(n):
