@@ -288,10 +288,14 @@ int32_t caf_xcorr_perdelay(const float* d_cutout, int32_t n, const float* d_rx, 
     }
     if (num == 0) return CAF_OK;
     hipStream_t st = (hipStream_t)stream;
-    // CAF_JIT_ALL=1 (measurements): the powers of two and of ten through the run-time-compiled kernel as well
-    const bool jit_all = [] {
+    // CAF_JIT_ALL=1 (measurements): every power of two and of ten through the run-time-compiled kernel as well.  By default those
+    // where it measured faster than the prebuilt kernels, from the row count at which its per-call work (energy prefix, cutout
+    // norm: ~25 us) is paid back (profiles/r05/timing_pow2_pow10_through_jit.log, ms per 1e5 delays): 10000 (2.0 against the
+    // radix-10 kernel's 4.0), 16384 (3.1 / 3.8), 8192 (1.50 / 1.82), 2048 (0.29 / 0.32).
+    const bool jit_all = [n, num] {
         const char* e = getenv("CAF_JIT_ALL");
-        return e && atoi(e) != 0;
+        if (e) return atoi(e) != 0;
+        return n == 10000 || ((n == 8192 || n == 16384) && num >= 8192) || (n == 2048 && num >= (1 << 17));
     }();
     // Power-of-two cutouts up to 16384 samples: one fused kernel (product -> LDS FFT -> |.|^2 -> argmax; window energies
     // and the cutout norm summed in the kernel): no product matrix, no prefix pass, no scratch, no synchronisation.

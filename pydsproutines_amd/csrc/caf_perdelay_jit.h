@@ -97,6 +97,28 @@ __device__ __forceinline__ void row_sync() {
         __syncthreads();
 }
 
+// (value, first index) maximum over the aligned group of G = gcd(TPR, 64) lanes a thread sits in (G a power of two <= 16 uses
+// DPP only: quad permutes, row_half_mirror, row_mirror; such a group never straddles two rows or two waves).  One lane per
+// group then offers the result to the row's slot -- with one LDS atomic per THREAD the 64 same-address operations of a wave
+// were served one after the other and showed as two thirds of the kernel's bank-conflict cycles.
+constexpr int cGCD(int a, int b) { return b == 0 ? a : cGCD(b, a % b); }
+constexpr int GRP = cGCD(TPR, 64) > 16 ? 16 : cGCD(TPR, 64);
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
+}
+__device__ __forceinline__ void group_max(uint32_t& vbits, uint32_t& nidx) {  // nidx = ~index: the larger, the earlier
+    auto step = [&](uint32_t ov, uint32_t oi) {
+        const bool take = ov > vbits || (ov == vbits && oi > nidx);
+        vbits = take ? ov : vbits;
+        nidx = take ? oi : nidx;
+    };
+    if constexpr (GRP >= 2) step(dpp<0xB1>(vbits), dpp<0xB1>(nidx));    // quad_perm [1,0,3,2]
+    if constexpr (GRP >= 4) step(dpp<0x4E>(vbits), dpp<0x4E>(nidx));    // quad_perm [2,3,0,1]
+    if constexpr (GRP >= 8) step(dpp<0x141>(vbits), dpp<0x141>(nidx));  // row_half_mirror
+    if constexpr (GRP >= 16) step(dpp<0x140>(vbits), dpp<0x140>(nidx));  // row_mirror
+}
+
 // butterfly b of pass p -> its base position in the row image and m_p (index within the dimensions after p)
 template <int p>
 __device__ __forceinline__ void decode(int b, int& base, int& m) {
@@ -335,8 +357,11 @@ extern "C" __global__ __launch_bounds__(PDJ_WG, 4) void k_pdj(const float2* __re
             // one 64-bit maximum of (value bits, ~index) per row: values are >= +0, whose bit patterns order like the numbers; a
             // thread that saw only NaNs offers nothing, so an all-NaN row -- a zero-energy window -- keeps key 0 -> (NaN, 0)
             unsigned long long* slot = &s_key[(it & 1) * RPW + rl];
-            const unsigned long long key = bv < 0.f ? 0ull : (((unsigned long long)__float_as_uint(bv) << 32) | (uint32_t)~bi);
-            if (live && key) atomicMax(slot, key);
+            // (a thread that saw nothing -- inactive, or only NaNs -- offers (0, 0): below every real candidate)
+            uint32_t vb = (live && !(bv < 0.f)) ? __float_as_uint(bv) : 0u, ni = (live && !(bv < 0.f)) ? ~bi : 0u;
+            group_max(vb, ni);
+            const unsigned long long key = ((unsigned long long)vb << 32) | ni;
+            if (live && key && (tid & (GRP - 1)) == 0) atomicMax(slot, key);
             row_sync();
             if (live && l_fixed == 0) {
                 const unsigned long long kk = *(volatile unsigned long long*)slot;

@@ -1,9 +1,9 @@
 #!/bin/bash
 # plan sweep of the run-time-compiled per-delay kernel: six processes, timing sections serialised by a lock
 set -o pipefail
-O=gpurun_out/r05_call6
+O=gpurun_out/r05_call8
 mkdir -p $O
-export CAF_JIT_CACHE=off SWEEP_LIMIT=48
+export CAF_JIT_CACHE=off SWEEP_LIMIT=40
 python scripts/sweep_pdj_plans.py $O/sweep_a.csv 1200 5000 96 2400 > $O/a.log 2>&1 &
 python scripts/sweep_pdj_plans.py $O/sweep_b.csv 1400 8000 360 1000 > $O/b.log 2>&1 &
 python scripts/sweep_pdj_plans.py $O/sweep_c.csv 1536 12000 4096 100 > $O/c.log 2>&1 &

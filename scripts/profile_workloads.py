@@ -286,19 +286,25 @@ def w_perdelay_decimal_1000():
              _perdelay_bytes(n, num), num * 5.0 * n * np.log2(n), 2)]
 
 
+def _w_perdelay_jit(n):
+    num = 100_000
+    perdelay(n, num, "mixed")
+    return [("k_pdj", "per-delay correlator compiled for N=%d at run time (caf_perdelay_jit.h), %d rows (f32-bound; 5 N log2 N flop per row)" % (n, num),
+             _perdelay_bytes(n, num), num * 5.0 * n * np.log2(n), 2)]
+
+
 def w_perdelay_mixed_1200():
-    """2^a 3^b 5^c 7^d cutouts: the mixed-radix in-LDS kernel (caf_perdelay_mr.hip), here 1200 = 16.15.5, 5000 = 10.10.10.5 and
-    1400 = 14.10.10."""
-    man = []
-    for n, num in ((1200, 100_000), (5000, 100_000), (1400, 100_000)):
-        perdelay(n, num, "mixed")
-    man.append(("k_perdelay_mr<14", "mixed-radix per-delay correlator, N=1400 x 1e5 rows (f32-bound)", _perdelay_bytes(1400, 100_000),
-                100_000 * 5.0 * 1400 * np.log2(1400), 2))
-    man.append(("k_perdelay_mr<16", "mixed-radix per-delay correlator, N=1200 x 1e5 rows (f32-bound)", _perdelay_bytes(1200, 100_000),
-                100_000 * 5.0 * 1200 * np.log2(1200), 2))
-    man.append(("k_perdelay_mr<10", "mixed-radix per-delay correlator, N=5000 x 1e5 rows (f32-bound)", _perdelay_bytes(5000, 100_000),
-                100_000 * 5.0 * 5000 * np.log2(5000), 2))
-    return man
+    """2^a 3^b 5^c 7^d cutouts: the kernel compiled for the length at run time (caf_jit.hip); one workload per length (every length's
+    kernel is called k_pdj)."""
+    return _w_perdelay_jit(1200)
+
+
+def w_perdelay_mixed_1400():
+    return _w_perdelay_jit(1400)
+
+
+def w_perdelay_mixed_5000():
+    return _w_perdelay_jit(5000)
 
 
 def w_cp_fastxcorr_1e7():
