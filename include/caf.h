@@ -231,7 +231,7 @@ CAF_EXPORT int32_t caf_plan_execute_host(caf_plan plan, const float* h_rx, int64
 CAF_EXPORT int32_t caf_xcorr_perdelay(const float* d_cutout, int32_t n, const float* d_rx, int64_t rx_len,
                                       int64_t start, int64_t step, int64_t num, int32_t zero_oor, float* d_qf2,
                                       int32_t* d_fidx, float* d_caf, float* d_ccaf, int64_t batch_rows, void* stream);
-/* Cutouts of 2^a 3^b 5^c 7^d samples (32 .. 16384) get a kernel compiled for the length at run time (hiprtc, as the reference
+/* Cutouts of 32 .. 16384 samples whose prime factors are at most 23 get a kernel compiled for the length at run time (hiprtc, as the reference
  * compiles its own through NVRTC; cached in memory and under CAF_JIT_CACHE / ~/.cache/pydsproutines_amd/jit; CAF_JIT=0 keeps the
  * prebuilt kernels).  This call describes what would run for n -- radices, threads per row, LDS strides, the bank-conflict
  * cycles its layout was chosen by -- as one line of text in buf ("" when the length has no such kernel), without a GPU.

@@ -269,7 +269,7 @@ struct PdjPlan {
     double cost = 0.0;
 };
 
-constexpr int PDJ_RADICES[] = {25, 20, 18, 16, 15, 14, 12, 10, 9, 8, 7, 6, 5, 4, 3, 2};
+constexpr int PDJ_RADICES[] = {25, 23, 20, 19, 18, 17, 16, 15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2};
 
 bool pdj_valid(int n, const std::vector<int>& rad, int tpr) {
     if (rad.size() < 2 || (int)rad.size() > PDJ_MAXP || tpr < 1 || tpr > 1024) return false;
@@ -287,12 +287,12 @@ bool pdj_valid(int n, const std::vector<int>& rad, int tpr) {
 // Modelled cost of a row (arbitrary units): threads the row occupies x ( sum over passes of points per thread x w(position, radix)
 // + a charge per butterfly of the thread + a charge per pass ) + a charge per row.  w = a + b log2(radix) + c [radix not a power
 // of two], separately for the first pass (global loads, products), the middle passes (image in and out, twiddles) and the last
-// one (image in, |.|^2 and maxima): a least-squares fit to 783 timed plans of 24 lengths with a first radix of at most 16
-// (scripts/sweep_pdj_plans.py -> profiles/r05/pdj_plan_sweep*.csv, scripts/fit_pdj_model.py); median error 10 %, the model's pick within 10 % of the fastest measured plan for most lengths (28 % at worst).  What the fit
+// one (image in, |.|^2 and maxima): a least-squares fit to 1227 timed plans of 48 lengths with a first radix of at most 16
+// (scripts/sweep_pdj_plans.py -> profiles/r05/pdj_plan_sweep*.csv, scripts/fit_pdj_model.py); median error 8.5 %, the model's pick within 10 % of the fastest measured plan for three lengths in four (profiles/r05/pdj_plan_fit.log).  What the fit
 // cannot see is kept out by rule (pdj_valid): a first radix above 16 spills (x and y of 20 / 25 points in flight).
 double pdj_cost(int n, const std::vector<int>& rad, int tpr) {
-    static const double A[3] = {-79.7, 24.8, -35.3}, B[3] = {42.0, 17.1, 19.2}, C[3] = {3.9, 0.2, 9.6};
-    static const double PASS[3] = {-402.5, 332.4, -402.5}, BFLY[3] = {127.5, 3.9, 10.9};
+    static const double A[3] = {0.8, 18.6, 51.9}, B[3] = {24.3, 6.0, -0.2}, C[3] = {2.5, 4.1, 7.6};
+    static const double PASS[3] = {-338.3, 190.2, -338.3}, BFLY[3] = {115.6, 27.3, -20.8};
     const int rpw = std::max(1, 256 / tpr);
     const double threads = (double)((rpw * tpr + 63) / 64 * 64) / rpw;
     double per_thread = 0.0;
@@ -302,7 +302,7 @@ double pdj_cost(int n, const std::vector<int>& rad, int tpr) {
         const bool pow2 = (r & (r - 1)) == 0;
         per_thread += (double)cnt * r * (A[pos] + B[pos] * std::log2((double)r) + (pow2 ? 0.0 : C[pos])) + BFLY[pos] * cnt + PASS[pos];
     }
-    return threads * per_thread + 64.0 * 189.4;
+    return threads * per_thread + 64.0 * 98.1;
 }
 
 // Plans measured fastest on an MI355X for the lengths of the sweep (the same file): consulted before the model.
@@ -555,8 +555,10 @@ bool pdj_plan(int n, PdjPlan& out) {
                 int cap = PDJ_PT;
                 for (int r : cur) cap = std::min(cap, std::max(PDJ_PT, r) / r * r);
                 const int t0 = (n + cap - 1) / cap;
-                for (int t : {t0, (t0 + 15) / 16 * 16, (t0 + 31) / 32 * 32, (t0 + 63) / 64 * 64})
-                    if (pdj_valid(n, cur, t)) cands.push_back({cur, t, pdj_cost(n, cur, t)});
+                // (rows of 32 threads and more in whole quarter / half / full waves: 250 or 500 threads per row measured 15-20 %
+                //  slower than 256 / 512 with the same radices)
+                for (int t : {t0 < 32 ? t0 : 0, (t0 + 15) / 16 * 16, (t0 + 31) / 32 * 32, (t0 + 63) / 64 * 64})
+                    if (t && pdj_valid(n, cur, t)) cands.push_back({cur, t, pdj_cost(n, cur, t)});
                 return;
             }
             if ((int)cur.size() >= PDJ_MAXP) return;
@@ -611,21 +613,8 @@ bool pdj_plan(int n, PdjPlan& out) {
     return pl.tpr > 0;
 }
 
-// e^{+j 2 pi q / n}, q < n (built once per device and length; at most 64 tables are kept)
-int pdj_twiddles(int device, int32_t n, const float2** out) {
-    static std::mutex mu;
-    static std::vector<std::pair<std::pair<int, int32_t>, float2*>> tabs;
-    std::lock_guard<std::mutex> lk(mu);
-    for (auto& e : tabs)
-        if (e.first.first == device && e.first.second == n) {
-            *out = e.second;
-            return CAF_OK;
-        }
-    if (tabs.size() >= 64) {  // a caller sweeping lengths: drop the oldest table once nothing can be reading it any more
-        CAF_HIP_TRY(hipDeviceSynchronize());
-        (void)pool_free(tabs.front().second);
-        tabs.erase(tabs.begin());
-    }
+// e^{+j 2 pi q / n}, q < n: one table per loaded kernel (owned by its entry in launch_perdelay_jit's cache)
+int pdj_twiddles(int32_t n, float2** out) {
     std::vector<std::complex<float>> t(n);
     for (int q = 0; q < n; ++q) {
         const double ph = 2.0 * M_PI * (double)q / (double)n;
@@ -639,7 +628,6 @@ int pdj_twiddles(int device, int32_t n, const float2** out) {
         (void)pool_free(d);
         return rc;
     }
-    tabs.push_back({{device, n}, d});
     *out = d;
     return CAF_OK;
 }
@@ -676,7 +664,7 @@ void perdelay_jit_failed(int32_t n) {
 bool perdelay_jit_ok(int32_t n) {
     if (!jit_enabled() || n < 32 || n > 16384) return false;
     int32_t r = n;
-    for (int p : {2, 3, 5, 7})
+    for (int p : {2, 3, 5, 7, 11, 13, 17, 19, 23})
         while (r % p == 0) r /= p;
     if (r != 1) return false;
     if (!rtc()->lib) return false;
@@ -696,10 +684,13 @@ int launch_perdelay_jit(const float2* x, int32_t n, const float2* y, int64_t yle
     struct Ready {
         PdjPlan pl;
         hipFunction_t fn = nullptr;
-        const float2* tw = nullptr;
+        float2* tw = nullptr;  // owned: freed when the entry is evicted
+        uint64_t used = 0;     // last call (for the eviction of the least recently used entry)
     };
     static std::mutex mu;
     static std::map<std::tuple<int, int, std::string>, Ready> ready;
+    static uint64_t tick = 0;
+    constexpr size_t READY_MAX = 256;  // lengths x forced plans kept per process (a table of n x 8 B each)
     int dev = 0;
     CAF_HIP_TRY(hipGetDevice(&dev));
     const char* forced_env = std::getenv("CAF_PDJ_PLAN");
@@ -709,7 +700,10 @@ int launch_perdelay_jit(const float2* x, int32_t n, const float2* y, int64_t yle
     {
         std::lock_guard<std::mutex> lk(mu);
         auto it = ready.find(key);
-        if (it != ready.end()) r = it->second, have = true;
+        if (it != ready.end()) {
+            it->second.used = ++tick;
+            r = it->second, have = true;
+        }
     }
     if (!have) {
         if (!pdj_plan(n, r.pl)) {
@@ -731,9 +725,20 @@ int launch_perdelay_jit(const float2* x, int32_t n, const float2* y, int64_t yle
             rc = jit_function(dev, "#include \"caf_perdelay_jit.h\"\n", pdj_options(r.pl), "k_pdj", what.c_str(), &r.fn);
             if (rc) return rc;
         }
-        if ((rc = pdj_twiddles(dev, n, &r.tw))) return rc;
+        if ((rc = pdj_twiddles(n, &r.tw))) return rc;
         std::lock_guard<std::mutex> lk(mu);
-        if (ready.size() > 512) ready.clear();
+        if (ready.size() >= READY_MAX) {
+            // the least recently used entry goes, with its twiddle table -- once nothing on the device can still be reading it
+            // (the first version kept the tables in a cache of their own that dropped the oldest of 64 while the entries here
+            // kept pointing at them: garbage twiddles after 64 lengths in one process)
+            auto old = ready.begin();
+            for (auto it = ready.begin(); it != ready.end(); ++it)
+                if (it->second.used < old->second.used) old = it;
+            CAF_HIP_TRY(hipDeviceSynchronize());
+            (void)pool_free(old->second.tw);
+            ready.erase(old);
+        }
+        r.used = ++tick;
         ready[key] = r;
     }
     const PdjPlan& pl = r.pl;

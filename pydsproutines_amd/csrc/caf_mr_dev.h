@@ -1,4 +1,4 @@
-// Mixed-radix inverse DFT butterflies in registers, radices 2 .. 10, 12, 14, 15, 16, 18, 20, 25 (kernel e^{+j 2 pi n k / R}): shared
+// Mixed-radix inverse DFT butterflies in registers, radices 2 .. 20 and 23, 25 (composite ones as Cooley-Tukey butterflies, primes from 7 up in the direct form) (kernel e^{+j 2 pi n k / R}): shared
 // by the plan-driven kernel of caf_perdelay_mr.hip and the run-time-specialised kernel of caf_perdelay_jit.h (this header
 // is also compiled by hiprtc: no standard-library includes).
 #pragma once
@@ -44,27 +44,37 @@ struct MrW {
 template <int R>
 __device__ __forceinline__ void mr_idft(float2* v);
 
-// inverse 7-point DFT (kernel e^{+j 2 pi n k / 7}): X[k], X[7 - k] = a_k +- j b_k from the sums and differences of the pairs
-__device__ __forceinline__ void idft7(float2* v) {
-    constexpr MrW<7> W = MrW<7>();
+// inverse DFT of a prime number of points R (kernel e^{+j 2 pi n k / R}) in the direct form on pair sums and differences:
+// X[k], X[R - k] = a_k +- j b_k with a_k = x0 + sum_m cos(2 pi m k / R) (x_m + x_{R-m}), b_k = sum_m sin(2 pi m k / R) (x_m - x_{R-m}):
+// (R - 1)^2 real multiply-adds, constants folded at compile time.  7 in the mixed-radix plans; 11, 13, 17, 19, 23 make cutouts
+// with those prime factors one-kernel lengths too (24 .. 44 flop per point where a 16-point butterfly costs 11: still far
+// below the three trips through HBM of product rows -> rocFFT rows -> argmax).
+template <int R>
+__device__ __forceinline__ void idft_prime(float2* v) {
+    constexpr MrW<R> W = MrW<R>();
+    constexpr int H = (R - 1) / 2;
     const float2 x0 = v[0];
-    float2 t[3], d[3];
+    float2 t[H], d[H];
 #pragma unroll
-    for (int m = 1; m <= 3; ++m) t[m - 1] = cadd(v[m], v[7 - m]), d[m - 1] = csub(v[m], v[7 - m]);
-    v[0] = make_float2(x0.x + t[0].x + t[1].x + t[2].x, x0.y + t[0].y + t[1].y + t[2].y);
+    for (int m = 1; m <= H; ++m) t[m - 1] = cadd(v[m], v[R - m]), d[m - 1] = csub(v[m], v[R - m]);
+    float2 s0 = x0;
 #pragma unroll
-    for (int k = 1; k <= 3; ++k) {
+    for (int m = 0; m < H; ++m) s0 = cadd(s0, t[m]);
+    v[0] = s0;
+#pragma unroll
+    for (int k = 1; k <= H; ++k) {
         float2 a = x0, b = make_float2(0.f, 0.f);
 #pragma unroll
-        for (int m = 1; m <= 3; ++m) {
-            const float c = W.c[(m * k) % 7], sn = W.s[(m * k) % 7];
+        for (int m = 1; m <= H; ++m) {
+            const float c = W.c[(m * k) % R], sn = W.s[(m * k) % R];
             a.x = __builtin_fmaf(c, t[m - 1].x, a.x), a.y = __builtin_fmaf(c, t[m - 1].y, a.y);
             b.x = __builtin_fmaf(sn, d[m - 1].x, b.x), b.y = __builtin_fmaf(sn, d[m - 1].y, b.y);
         }
         v[k] = make_float2(a.x - b.y, a.y + b.x);      // a + j b
-        v[7 - k] = make_float2(a.x + b.y, a.y - b.x);  // a - j b
+        v[R - k] = make_float2(a.x + b.y, a.y - b.x);  // a - j b
     }
 }
+__device__ __forceinline__ void idft7(float2* v) { idft_prime<7>(v); }
 
 // Cooley-Tukey butterfly of R = A B points in registers: n = B a + b, k = k1 + A k2;
 //   X[k1 + A k2] = sum_b W_B^{b k2} ( W_R^{b k1} sum_a W_A^{a k1} x[B a + b] )
@@ -112,6 +122,7 @@ __device__ __forceinline__ void mr_idft(float2* v) {
     if constexpr (R == 18) idft_ct<3, 6>(v);
     if constexpr (R == 20) idft_ct<5, 4>(v);
     if constexpr (R == 25) idft_ct<5, 5>(v);
+    if constexpr (R == 11 || R == 13 || R == 17 || R == 19 || R == 23) idft_prime<R>(v);
 }
 
 }  // namespace caf

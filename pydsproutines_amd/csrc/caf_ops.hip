@@ -266,7 +266,7 @@ int32_t caf_fft_rows(const float* d_in, float* d_out, int64_t rows, int64_t len,
 }
 
 int32_t caf_xcorr_perdelay_one_kernel(int32_t n) {
-    return (perdelay_fused_ok(n) || perdelay_decimal_ok(n) || perdelay_mixed_ok(n)) ? 1 : 0;
+    return (perdelay_fused_ok(n) || perdelay_decimal_ok(n) || perdelay_mixed_ok(n) || perdelay_jit_ok(n)) ? 1 : 0;
 }
 
 int32_t caf_perdelay_jit_describe(int32_t n, const char* arch, const char* dump_path, char* buf, int32_t len) {
@@ -338,9 +338,10 @@ int32_t caf_xcorr_perdelay(const float* d_cutout, int32_t n, const float* d_rx, 
             const char* e = getenv("CAF_PERDELAY_UNFUSED");
             return e && atoi(e) != 0;
         }();
-        // 2^a 3^b 5^c 7^d lengths that are neither a power of two nor of ten: a kernel compiled for the length at run time
-        // (caf_jit.hip); a length / box without one, or a compilation that fails (reported once), keeps the plan-driven kernel
-        if (!unfused10 && ((!perdelay_decimal_ok(n) && perdelay_mixed_ok(n)) || jit_all) && perdelay_jit_ok(n)) {
+        // lengths with prime factors up to 23 that are neither a power of two nor of ten: a kernel compiled for the length at run
+        // time (caf_jit.hip); a length / box without one, or a compilation that fails (reported once), keeps the plan-driven
+        // kernel (7-smooth lengths) or the three-kernel form below
+        if (!unfused10 && (jit_all || !(perdelay_fused_ok(n) || perdelay_decimal_ok(n))) && perdelay_jit_ok(n)) {
             rc = launch_perdelay_jit((const float2*)d_cutout, n, yv, ylen_v, prefix, d_norm, start_v, step, num, zero_oor ? 1 : 0, d_qf2,
                                      (uint32_t*)d_fidx, d_caf, (float2*)d_ccaf, st);
             if (rc == CAF_OK) {

@@ -24,7 +24,12 @@ struct Live {
 };
 
 std::mutex g_mu;
-std::multimap<std::pair<int, int64_t>, void*> g_free;  // (device, rounded bytes) -> block
+struct Cached {
+    void* p;
+    uint64_t seq;  // when it was freed (larger = more recent)
+};
+std::multimap<std::pair<int, int64_t>, Cached> g_free;  // (device, rounded bytes) -> block
+uint64_t g_seq = 0;
 std::unordered_map<void*, Live> g_live;                // blocks handed out
 int64_t g_cached = 0, g_in_use = 0, g_hits = 0, g_misses = 0;
 
@@ -52,7 +57,7 @@ int64_t round_size(int64_t bytes) {
 void trim_locked(int dev) {
     for (auto it = g_free.begin(); it != g_free.end();) {
         if (dev < 0 || it->first.first == dev) {
-            (void)hipFree(it->second);
+            (void)hipFree(it->second.p);
             g_cached -= it->first.second;
             it = g_free.erase(it);
         } else {
@@ -71,7 +76,7 @@ int pool_alloc(void** out, int64_t bytes) {
     auto it = g_free.find({dev, r});
     void* p = nullptr;
     if (it != g_free.end()) {
-        p = it->second;
+        p = it->second.p;
         g_free.erase(it);
         g_cached -= r;
         ++g_hits;
@@ -106,12 +111,23 @@ int pool_free(void* p) {
     const Live l = it->second;
     g_live.erase(it);
     g_in_use -= l.bytes;
-    if (g_cached + l.bytes <= pool_limit()) {
-        g_free.emplace(std::make_pair(l.dev, l.bytes), p);
-        g_cached += l.bytes;
-    } else {
+    if (l.bytes > pool_limit()) {  // (larger than the whole cache: straight back to the driver)
         CAF_HIP_TRY(hipFree(p));
+        return CAF_OK;
     }
+    // A full cache gives up its OLDEST blocks for the one that has just been in use -- kept the other way round (the new block
+    // dropped), a process whose cache had filled with sizes it no longer asks for paid a hipMalloc + hipFree pair (10-20 ms
+    // each at 160 MB, and a device synchronisation) for every scratch buffer of every later call.
+    while (g_cached + l.bytes > pool_limit() && !g_free.empty()) {
+        auto old = g_free.begin();
+        for (auto it = g_free.begin(); it != g_free.end(); ++it)
+            if (it->second.seq < old->second.seq) old = it;
+        (void)hipFree(old->second.p);
+        g_cached -= old->first.second;
+        g_free.erase(old);
+    }
+    g_free.emplace(std::make_pair(l.dev, l.bytes), Cached{p, ++g_seq});
+    g_cached += l.bytes;
     return CAF_OK;
 }
 

@@ -1059,22 +1059,22 @@ constexpr int FIRP_R = 4;
 constexpr int FIRP_TILE = 256 * FIRP_R;
 constexpr int FIRP_MAXSPAN = 7400;  // samples of the tile window (+ the tap table: < 64 KB of LDS)
 
-template <typename TIn>
-__global__ __launch_bounds__(256) void k_fir_poly(const TIn* __restrict__ x, int64_t n, float scale,
+template <typename TIn, int NT>
+__global__ __launch_bounds__(NT) void k_fir_poly(const TIn* __restrict__ x, int64_t n, float scale,
                                                   const float* __restrict__ taps, int32_t ntaps,
                                                   const TIn* __restrict__ delay, int32_t dlen, int32_t dsr, int32_t phase,
                                                   float2* __restrict__ out, int64_t nout) {
     extern __shared__ float s_firp[];
     const int qmax = (ntaps + dsr - 1) / dsr;                      // sub-filter length of branch 0 (the longest)
     const int qpad = (qmax + FIRP_R - 1) / FIRP_R * FIRP_R;        // padded with zero taps
-    const int ncols = FIRP_TILE + qpad;                            // columns per branch row
+    const int ncols = NT * FIRP_R + qpad;                            // columns per branch row
     const int pitch2 = ncols / FIRP_R + 1;
     const int rowpitch = FIRP_R * pitch2;
     float* s_g = s_firp;                                           // dsr * qpad sub-filter taps
     float2* s_x = reinterpret_cast<float2*>(s_firp + ((dsr * qpad + 1) & ~1));  // dsr rows of rowpitch
-    const int64_t o0 = (int64_t)blockIdx.x * FIRP_TILE;
+    const int64_t o0 = (int64_t)blockIdx.x * (NT * FIRP_R);
     const int64_t i0 = o0 * dsr + phase - (ntaps - 1);             // input index of window element 0
-    for (int t = threadIdx.x; t < dsr * qpad; t += 256) {
+    for (int t = threadIdx.x; t < dsr * qpad; t += NT) {
         const int rho = t / qpad, q = t - rho * qpad;
         const int m = q * dsr + rho;
         s_g[t] = m < ntaps ? taps[ntaps - 1 - m] : 0.f;
@@ -1085,15 +1085,15 @@ __global__ __launch_bounds__(256) void k_fir_poly(const TIn* __restrict__ x, int
         // with the running (rho, c) instead of a division per element).
         const int total = ncols * dsr;
         int c = threadIdx.x / dsr, rho = threadIdx.x - c * dsr;
-        const int dc = 256 / dsr, dr = 256 - dc * dsr;
+        const int dc = NT / dsr, dr = NT - dc * dsr;
         constexpr int STG = sizeof(TIn) == 8 ? 8 : 1;  // (raw int16 IQ: one at a time measured 5-15 % faster, ab_iq16_staging.log)
-        for (int e0 = threadIdx.x; e0 < total; e0 += 256 * STG) {
+        for (int e0 = threadIdx.x; e0 < total; e0 += NT * STG) {
             float2 v[STG];
 #pragma unroll
             for (int u = 0; u < STG; ++u) {
-                const int64_t j = i0 + e0 + 256 * u;
+                const int64_t j = i0 + e0 + NT * u;
                 v[u] = make_float2(0.f, 0.f);
-                if (e0 + 256 * u < total) {
+                if (e0 + NT * u < total) {
                     if (j >= 0) {
                         if (j < n) v[u] = fird_load(x, j, scale);
                     } else if (delay && -j <= dlen) {
@@ -1103,7 +1103,7 @@ __global__ __launch_bounds__(256) void k_fir_poly(const TIn* __restrict__ x, int
             }
 #pragma unroll
             for (int u = 0; u < STG; ++u) {
-                if (e0 + 256 * u < total) s_x[rho * rowpitch + (c % FIRP_R) * pitch2 + c / FIRP_R] = v[u];
+                if (e0 + NT * u < total) s_x[rho * rowpitch + (c % FIRP_R) * pitch2 + c / FIRP_R] = v[u];
                 c += dc;
                 rho += dr;
                 if (rho >= dsr) {
@@ -1723,7 +1723,23 @@ static void launch_fir_decim(const TIn* x, int64_t n, float scale, const float* 
         const size_t smp = (size_t)((dsr * qpad + 1) & ~1) * sizeof(float) +
                            (size_t)dsr * FIRP_R * (ncols / FIRP_R + 1) * sizeof(float2);
         if (smp <= 64 * 1024 && (size_t)ncols * dsr <= FIRP_MAXSPAN + 4 * FIRP_R * dsr) {
-            hipLaunchKernelGGL(k_fir_poly<TIn>, dim3(cdiv(nout, FIRP_TILE)), dim3(256), smp, st, x, n, scale, taps, ntaps,
+            // A workgroup stages its window, meets at a barrier and only then computes: the more INDEPENDENT workgroups a CU
+            // holds, the better their phases cover for one another -- tiles of 512 outputs on 128 threads (half the LDS: twice
+            // the workgroups per CU, the same waves) where the launch has tiles to spare.  CAF_FIR_POLY_NT=256: the A/B switch.
+            static const int nt_env = [] {
+                const char* e = getenv("CAF_FIR_POLY_NT");
+                return e ? atoi(e) : 0;
+            }();
+            const bool small = nt_env ? nt_env == 128 : nout >= (int64_t)128 * FIRP_R * 2048;
+            if (small) {
+                const int ncols2 = 128 * FIRP_R + qpad;
+                const size_t smp2 = (size_t)((dsr * qpad + 1) & ~1) * sizeof(float) +
+                                    (size_t)dsr * FIRP_R * (ncols2 / FIRP_R + 1) * sizeof(float2);
+                hipLaunchKernelGGL((k_fir_poly<TIn, 128>), dim3(cdiv(nout, 128 * FIRP_R)), dim3(128), smp2, st, x, n, scale, taps, ntaps,
+                                   delay, dlen, dsr, phase, out, nout);
+                return;
+            }
+            hipLaunchKernelGGL((k_fir_poly<TIn, 256>), dim3(cdiv(nout, FIRP_TILE)), dim3(256), smp, st, x, n, scale, taps, ntaps,
                                delay, dlen, dsr, phase, out, nout);
             return;
         }

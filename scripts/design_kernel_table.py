@@ -24,10 +24,10 @@ ROWS = [  # (workload, kernel prefix of the manifest entry, label)
     ("direct_small_support", "k_direct_caf", "`k_direct_caf` (16 samples of support, 64 frequencies, 2²² delays, surface)"),
     ("cp_fastxcorr_1e7", "k_sliding_multiply", "`k_sliding_multiply` (128 rows × 10⁷)"),
     ("perdelay_decimal_1000", "k_perdelay_r10", "`k_perdelay_r10<3>` (1000 × 10⁶, radix 10)"),
-    ("perdelay_mixed_1200", "k_perdelay_mr<16", "`k_perdelay_mr<16>` (1200 × 10⁵, radices 16·15·5)"),
-    ("perdelay_mixed_1200", "k_perdelay_mr<10", "`k_perdelay_mr<10>` (5000 × 10⁵, radices 10·10·10·5)"),
-    ("perdelay_mixed_1200", "k_perdelay_mr<14", "`k_perdelay_mr<14>` (1400 × 10⁵, radices 14·10·10)"),
-    ("perdelay_rows_1430", "k_sliding_multiply", "`k_sliding_multiply` (10⁵ rows × 1430)"),
+    ("perdelay_mixed_1200", "k_pdj", "`k_pdj` (1200 × 10⁵, compiled for the length: radices 5·16·15)"),
+    ("perdelay_mixed_5000", "k_pdj", "`k_pdj` (5000 × 10⁵: radices 5·10·5·20)"),
+    ("perdelay_mixed_1400", "k_pdj", "`k_pdj` (1400 × 10⁵: radices 5·14·20)"),
+    ("perdelay_rows_1450", "k_sliding_multiply", "`k_sliding_multiply` (10⁵ rows × 1450)"),
     ("cp_fastxcorr_1e7", "k_rows_argmax", "`k_rows_argmax` (chunked, 128 rows × 10⁷)"),
     ("kernels_misc", "k_magnsq", "`k_magnsq`"),
     ("kernels_misc", "k_iq16_to_c64", "`k_iq16_to_c64`"),

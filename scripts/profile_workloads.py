@@ -272,10 +272,10 @@ def w_perdelay_fused_256():
     return [("k_perdelay_fused", "N=256 x 1e6 delays (same accounting)", _perdelay_bytes(n, num), num * 5.0 * n * np.log2(n), 2)]
 
 
-def w_perdelay_rows_1430():
-    """A cutout length with factors 11 and 13 (no in-LDS kernel): product rows -> rocFFT rows -> argmax."""
-    n, num = perdelay(1430, 100_000, "rows")
-    return [("k_sliding_multiply", "normalised product rows, N=1430 x 1e5 (8 B written per element)", num * n * 8.0, 0.0, 2),
+def w_perdelay_rows_1450():
+    """A cutout length with a prime factor above 23 (1450 = 2 5^2 29: no in-LDS kernel): product rows -> rocFFT rows -> argmax."""
+    n, num = perdelay(1450, 100_000, "rows")
+    return [("k_sliding_multiply", "normalised product rows, N=1450 x 1e5 (8 B written per element)", num * n * 8.0, 0.0, 2),
             ("k_rows_argmax", "|.|^2 + first argmax per row (8 B read per element)", num * n * 8.0, 0.0, 2)]
 
 

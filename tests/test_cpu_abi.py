@@ -141,7 +141,7 @@ def test_perdelay_jit_planner_and_compile_without_a_gpu():
         rad = [int(r) for r in d["radices"].split(",")]
         assert int(np.prod(rad)) == n and 2 <= len(rad) <= 5
         assert int(d["lds_bytes"]) <= 160 * 1024 - 64
-        assert int(d["conflict_cycles"]) <= 0.4 * int(d["base_cycles"]), d
+        assert int(d["conflict_cycles"]) <= 0.6 * int(d["base_cycles"]), d
     rc, d = describe(97)  # (a prime: no plan)
     assert rc == 0 and not d
     rc, d = describe(1200, b"gfx950")

@@ -897,10 +897,11 @@ def test_quiet_windows_down_to_minus_160_db(engine, db):
     plan.close()
 
 
-@pytest.mark.parametrize("n", [1000, 1200, 1430, 4096])
+@pytest.mark.parametrize("n", [1000, 1200, 1430, 1450, 4096])
 def test_quiet_windows_on_the_per_delay_path(n):
     """The same record through fastXcorr's frequency-search branch: the radix-10 kernel (1000), the mixed-radix kernel (1200), the
-    three-kernel form (1430: k_sliding_multiply) -- all three normalise from the float64 prefix -- and the power-of-two kernel,
+    three-kernel form (1450 = 2 5^2 29: k_sliding_multiply), a length with factors 11 and 13 (1430) -- all of them normalise from the
+    float64 prefix -- and the power-of-two kernel,
     which sums its own windows: -120 dB windows finite and within 1e-4 of the oracle, windows of zeros (NaN, 0)."""
     from pydsproutines_amd.xcorrRoutines import fastXcorr
 

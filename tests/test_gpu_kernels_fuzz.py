@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 import scipy.signal as sps
 
+import oracle as O
 from oracle import kernels as K
 from conftest import cn
 
@@ -175,3 +176,67 @@ def test_elementwise_and_resampling_random_shapes(seed):
     f0, fstep = float(rng.uniform(-0.4, 0.4)), float(rng.uniform(1e-5, 1e-2))
     got = cupyDotTonesScaling(f0, fstep, nf, asarray(src)).get()
     np.testing.assert_allclose(got, K.dotTonesScaling(f0, fstep, nf, src), atol=3e-5 * np.sqrt(src.size) * 4)
+
+
+def _smooth_lengths(limit, max_prime=23):
+    out = []
+    for n in range(32, limit + 1):
+        r = n
+        for p in (2, 3, 5, 7, 11, 13, 17, 19, 23):
+            if p > max_prime:
+                break
+            while r % p == 0:
+                r //= p
+        if r == 1:
+            out.append(n)
+    return out
+
+
+_LENGTHS = _smooth_lengths(16384)
+
+
+@pytest.mark.parametrize("seed", CASES)
+def test_perdelay_random_cutout_lengths(seed):
+    """caf_xcorr_perdelay at random cutout lengths whose prime factors are at most 23 -- whatever kernel the library routes them to
+    (powers of two / ten, or the kernel it compiles for the length at run time with the plan its model picks) -- against the
+    oracle's fastXcorr(freqsearch=True): maxima to 2e-5, bins exact where the oracle's top-2 margin is clear, planes, strides in
+    both directions, the (0, 0) rule for windows that leave rx."""
+    import ctypes as ct
+
+    from pydsproutines_amd import _lib, asarray
+    from pydsproutines_amd.devarray import empty
+
+    rng = np.random.default_rng(9100 + seed)
+    lib = _lib.load()
+    # two lengths per seed: one anywhere, one short (many rows per workgroup)
+    for n in (int(rng.choice(_LENGTHS)), int(rng.choice([v for v in _LENGTHS if v <= 600]))):
+        num = int(rng.integers(3, 40 if n > 4000 else 120))
+        step = int(rng.choice([1, 1, 2, -1, 5]))
+        m = n + abs(step) * num + int(rng.integers(0, 50))
+        rx = cn(rng, m)
+        start = 0 if step > 0 else m - n
+        start += int(rng.integers(0, 3)) * (1 if step > 0 else -1)
+        sh = start + step * np.arange(num)
+        sh = sh[(sh >= 0) & (sh + n <= m)]
+        num = sh.size
+        k0 = int(rng.integers(0, n))
+        cut = (rx[sh[num // 2] : sh[num // 2] + n] * np.exp(-2j * np.pi * k0 * np.arange(n) / n)).astype(np.complex64)
+        rx = (rx + 0.1 * cn(rng, m)).astype(np.complex64)
+        d_rx, d_cut = asarray(rx), asarray(cut.conj().copy())
+        q, fi, pl = empty(num, np.float32), empty(num, np.int32), empty((num, n), np.float32)
+        p = lambda a: ct.c_void_p(a.ptr)  # noqa: E731
+        want_plane = bool(rng.integers(0, 2))
+        _lib.check(lib.caf_xcorr_perdelay(p(d_cut), n, p(d_rx), m, int(sh[0]), step, num, 0, p(q), p(fi), p(pl) if want_plane else None,
+                                          None, 0, None))
+        rq, rf = O.fastXcorr(cut, rx, freqsearch=True, shifts=sh)
+        gq, gf = q.get(), fi.get()
+        assert np.max(np.abs(gq - rq)) <= 2e-5, (n, step)
+        assert (int(np.argmax(gq)), int(gf[np.argmax(gq)])) == (num // 2, k0), (n, step)
+        diff = np.nonzero(gf != rf)[0]
+        if diff.size:  # float32 ties only
+            rows = O.fastXcorr(cut, rx, freqsearch=True, outputCAF=True, shifts=sh[diff])
+            assert np.all(rows[np.arange(diff.size), gf[diff]] >= rows.max(axis=1) - 4e-5), (n, step)
+        if want_plane:
+            gp = pl.get()
+            np.testing.assert_array_equal(gq, gp.max(axis=1))
+            np.testing.assert_array_equal(gf, np.argmax(gp, axis=1))

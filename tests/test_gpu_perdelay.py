@@ -191,7 +191,10 @@ def test_mixed_radix_every_butterfly(n, plan, monkeypatch, capfd):
                                     (125, "5,5,5/8"), (343, "7,7,7/25"), (72, "3,3,8/5"), (81, "9,9/6"), (50, "5,10/4"), (36, "3,12/3"),
                                     (98, "7,14/7"), (225, "15,15/15"), (1280, "5,16,16/80"), (324, "2,9,18/21"), (400, "20,20/25"),
                                     (8000, "20,20,20/500"), (96, "6,16/6"), (1200, "8,10,15/80"), (1200, "3,5,5,16/75"),
-                                    (1250, "25,25,2/64"), (2500, "4,25,25/125"), (7000, "7,10,10,10/500"), (7776, "6,6,6,6,6/432")])
+                                    (1250, "25,25,2/64"), (2500, "4,25,25/125"), (7000, "7,10,10,10/500"), (7776, "6,6,6,6,6/432"),
+                                    # prime factors 11 .. 23 (direct-form butterflies): lengths rounds 1-4 sent through rocFFT rows
+                                    (1430, None), (1001, None), (2431, None), (46, None), (33, None), (4199, None), (253, "11,23/23"),
+                                    (2873, "13,17,13/221"), (361, "19,19/19")])
 def test_jit_kernel_lengths_and_butterflies(n, plan, monkeypatch, capfd):
     monkeypatch.setenv("CAF_JIT_DEBUG", "1")
     monkeypatch.delenv("CAF_JIT", raising=False)
