@@ -317,7 +317,7 @@ const PdjTuned PDJ_TUNED[] = {
 // Bank model (MI355X_MICROARCH.md, LDS): ds_write_b64 is served in four groups of 16 consecutive lanes, bank = 8-byte element
 // index mod 16; ds_read_b64 in two groups of 32 lanes, bank = element index mod 32; each extra distinct address on a bank
 // costs one cycle.  Returns the extra cycles of all LDS accesses of one row group (every wave of the workgroup).
-long pdj_conflicts(const PdjPlan& pl, long* base_cycles) {
+long pdj_conflicts(const PdjPlan& pl, long* base_cycles, int max_waves = 1 << 20) {
     const int P = pl.np, N = pl.n;
     int M[PDJ_MAXP];
     for (int d = 0; d < P; ++d) {
@@ -336,12 +336,13 @@ long pdj_conflicts(const PdjPlan& pl, long* base_cycles) {
     };
     long extra = 0, basec = 0;
     const int nwaves = pl.wg / 64;
+    const int wstep = std::max(1, (nwaves + max_waves - 1) / max_waves);  // (the search looks at a sample of the waves: they repeat)
     std::vector<int> pos(64);
     for (int p = 0; p < P; ++p) {
         const int R = pl.rad[p], NB = N / R, cnt = (NB + pl.tpr - 1) / pl.tpr;
         const bool reads = p > 0, writes = p < P - 1;
         for (int c = 0; c < cnt; ++c)
-            for (int w = 0; w < nwaves; ++w) {
+            for (int w = 0; w < nwaves; w += wstep) {
                 // positions of t = 0 for the wave's lanes (-1: lane inactive); the other t shift every lane by t STR_p
                 for (int lane = 0; lane < 64; ++lane) {
                     const int tid = w * 64 + lane;
@@ -415,7 +416,7 @@ void pdj_layout(PdjPlan& pl) {
     auto eval = [&]() {
         apply();
         if ((size_t)pl.rpw * pl.img * 8 + 16 * pl.rpw + 64 > 160 * 1024) return TOO_BIG;
-        return pdj_conflicts(pl, nullptr);
+        return pdj_conflicts(pl, nullptr, 4);
     };
     long best = eval();
     // stage 1: the first dimension's pad x the lane orders of the middle passes, jointly (what one pass wants of STR_0 depends
@@ -495,6 +496,70 @@ void pdj_layout(PdjPlan& pl) {
         if (pads[d + 1]) pl.p0_linear = 0;  // (pads of the dimensions after the first break position == butterfly index)
 }
 
+// "pdjplan <version> n np tpr rpw wg img p0_linear conflict base | rad.. | str.. | ord.." in <cache>/plan_v<V>_<n>.txt; the version
+// changes with the planner (model constants, layout search), so that a new library does not pick up an old library's choice
+constexpr int PDJ_PLAN_FILE_VERSION = 4;
+std::string plan_file_path(int n) {
+    const std::string dir = cache_dir();
+    return dir.empty() ? std::string() : dir + "/plan_v" + std::to_string(PDJ_PLAN_FILE_VERSION) + "_" + std::to_string(n) + ".txt";
+}
+void plan_file_store(const PdjPlan& pl) {
+    const std::string path = plan_file_path(pl.n);
+    if (path.empty()) return;
+    const std::string tmp = path + "." + std::to_string((long)getpid());
+    FILE* f = std::fopen(tmp.c_str(), "w");
+    if (!f) return;
+    std::fprintf(f, "pdjplan %d %d %d %d %d %d %d %d %ld %ld\n", PDJ_PLAN_FILE_VERSION, pl.n, pl.np, pl.tpr, pl.rpw, pl.wg, pl.img, pl.p0_linear,
+                 pl.conflict_cycles, pl.lds_ops);
+    for (int p = 0; p < PDJ_MAXP; ++p) std::fprintf(f, "%d %d %d %d %d %d\n", pl.rad[p], pl.str[p], pl.ord[p][0], pl.ord[p][1], pl.ord[p][2], pl.ord[p][3]);
+    const bool ok = std::fclose(f) == 0;
+    if (!ok || std::rename(tmp.c_str(), path.c_str()) != 0) (void)std::remove(tmp.c_str());
+}
+bool plan_file_load(int n, PdjPlan& pl) {
+    const std::string path = plan_file_path(n);
+    if (path.empty()) return false;
+    FILE* f = std::fopen(path.c_str(), "r");
+    if (!f) return false;
+    int ver = 0;
+    PdjPlan q;
+    bool ok = std::fscanf(f, "pdjplan %d %d %d %d %d %d %d %d %ld %ld", &ver, &q.n, &q.np, &q.tpr, &q.rpw, &q.wg, &q.img, &q.p0_linear, &q.conflict_cycles,
+                          &q.lds_ops) == 10;
+    for (int p = 0; ok && p < PDJ_MAXP; ++p)
+        ok = std::fscanf(f, "%d %d %d %d %d %d", &q.rad[p], &q.str[p], &q.ord[p][0], &q.ord[p][1], &q.ord[p][2], &q.ord[p][3]) == 6;
+    std::fclose(f);
+    // (a file is only trusted as far as it can be checked: the radices multiply to n, the images fit the LDS)
+    if (!ok || ver != PDJ_PLAN_FILE_VERSION || q.n != n || q.np < 2 || q.np > PDJ_MAXP || q.tpr < 1 || q.tpr > 1024 || q.rpw < 1) return false;
+    int64_t prod = 1;
+    std::vector<int> rad;
+    for (int p = 0; p < q.np; ++p) prod *= q.rad[p], rad.push_back(q.rad[p]);
+    if (prod != n || q.wg != (q.rpw * q.tpr + 63) / 64 * 64 || q.wg > 1024 || (size_t)q.rpw * q.img * 8 + 16 * q.rpw + 64 > 160 * 1024) return false;
+    for (int p = 0; p < q.np; ++p)
+        if (std::find(std::begin(PDJ_RADICES), std::end(PDJ_RADICES), q.rad[p]) == std::end(PDJ_RADICES) ||
+            ((n / q.rad[p] + q.tpr - 1) / q.tpr) * q.rad[p] > std::max(PDJ_PT, q.rad[p]))
+            return false;
+    // strides must address disjoint positions inside the image: recompute the natural nesting and compare
+    if (q.str[q.np - 1] != 1) return false;
+    for (int d = q.np - 2; d >= 0; --d)
+        if (q.str[d] < q.rad[d + 1] * q.str[d + 1]) return false;
+    if (q.img < q.rad[0] * q.str[0]) return false;
+    for (int p = 0; p < q.np; ++p) {  // every lane order a permutation of the other dimensions
+        int seen = 0;
+        for (int i = 0; i < q.np - 1; ++i) {
+            const int d = q.ord[p][i];
+            if (d < 0 || d >= q.np || d == p || (seen >> d & 1)) return false;
+            seen |= 1 << d;
+        }
+    }
+    if (q.np >= 2) {  // pass 0 must walk its butterflies in natural order (coalesced loads), the last pass in natural spectrum order
+        for (int i = 0; i < q.np - 1; ++i)
+            if (q.ord[0][i] != q.np - 1 - i || q.ord[q.np - 1][i] != i) return false;
+    }
+    q.cost = pdj_cost(n, rad, q.tpr);
+    q.xreg = 0;
+    pl = q;
+    return true;
+}
+
 bool pdj_plan(int n, PdjPlan& out) {
     static std::mutex mu;
     static std::map<std::pair<int, std::string>, PdjPlan> memo;  // (length, forced plan or "") -> plan + layout
@@ -506,6 +571,16 @@ bool pdj_plan(int n, PdjPlan& out) {
         if (it != memo.end()) {
             out = it->second;
             return out.tpr > 0;
+        }
+    }
+    // plan + layout of earlier processes (the search is ~0.1-1 s for a length outside the tuned table: kept beside the code objects)
+    if (!forced_env) {
+        PdjPlan q;
+        if (plan_file_load(n, q)) {
+            out = q;
+            std::lock_guard<std::mutex> lk(mu);
+            memo[memo_key] = q;
+            return true;
         }
     }
     std::vector<int> best_rad;
@@ -572,7 +647,7 @@ bool pdj_plan(int n, PdjPlan& out) {
         rec(n);
         std::sort(cands.begin(), cands.end(), [](const Cand& a, const Cand& b) { return a.cost < b.cost; });
     }
-    // Among the plans the model prices within 4 % of the cheapest (eight at most), the one whose layout leaves the fewest
+    // Among the plans the model prices within 4 % of the cheapest (four at most), the one whose layout leaves the fewest
     // simulated bank-conflict cycles per conflict-free one: conflicts hardly show in the time of these VALU-bound kernels
     // (the fit gives a conflict cycle 1/7 of the weight of a conflict-free one), so the tie is broken in favour of the LDS.
     auto build = [&](const Cand& c, PdjPlan& pl) {
@@ -597,7 +672,7 @@ bool pdj_plan(int n, PdjPlan& out) {
     double best_ratio = 0.0;
     int tried = 0;
     for (const Cand& c : cands) {
-        if (tried >= 8 || (tried && c.cost > 1.04 * cands.front().cost)) break;
+        if (tried >= 4 || (tried && c.cost > 1.04 * cands.front().cost)) break;
         PdjPlan q;
         if (!build(c, q)) continue;
         const double ratio = q.lds_ops ? (double)q.conflict_cycles / (double)q.lds_ops : 0.0;
@@ -610,6 +685,7 @@ bool pdj_plan(int n, PdjPlan& out) {
         if (memo.size() > 4096) memo.clear();
         memo[memo_key] = pl;
     }
+    if (!forced_env && pl.tpr > 0) plan_file_store(pl);
     return pl.tpr > 0;
 }
 
@@ -662,7 +738,7 @@ void perdelay_jit_failed(int32_t n) {
     g_failed[n] = true;
 }
 bool perdelay_jit_ok(int32_t n) {
-    if (!jit_enabled() || n < 32 || n > 16384) return false;
+    if (!jit_enabled() || n < 32 || n > 20000) return false;  // (160 KB of LDS hold a row image of ~20000 points; the plan decides)
     int32_t r = n;
     for (int p : {2, 3, 5, 7, 11, 13, 17, 19, 23})
         while (r % p == 0) r /= p;

@@ -1723,14 +1723,14 @@ static void launch_fir_decim(const TIn* x, int64_t n, float scale, const float* 
         const size_t smp = (size_t)((dsr * qpad + 1) & ~1) * sizeof(float) +
                            (size_t)dsr * FIRP_R * (ncols / FIRP_R + 1) * sizeof(float2);
         if (smp <= 64 * 1024 && (size_t)ncols * dsr <= FIRP_MAXSPAN + 4 * FIRP_R * dsr) {
-            // A workgroup stages its window, meets at a barrier and only then computes: the more INDEPENDENT workgroups a CU
-            // holds, the better their phases cover for one another -- tiles of 512 outputs on 128 threads (half the LDS: twice
-            // the workgroups per CU, the same waves) where the launch has tiles to spare.  CAF_FIR_POLY_NT=256: the A/B switch.
+            // (Tiles of 512 outputs on 128 threads -- half the LDS, twice the independent workgroups per CU, the same waves -- measured
+            //  the same as 1024 on 256: 55.8 / 56.1 us for 2^24 int16 samples, 64 taps, dsr 4 (profiles/r05/ab_fir_poly_nt.log): the
+            //  stage -> barrier -> compute chain is not what bounds the kernel.  CAF_FIR_POLY_NT=128 selects them.)
             static const int nt_env = [] {
                 const char* e = getenv("CAF_FIR_POLY_NT");
                 return e ? atoi(e) : 0;
             }();
-            const bool small = nt_env ? nt_env == 128 : nout >= (int64_t)128 * FIRP_R * 2048;
+            const bool small = nt_env == 128;
             if (small) {
                 const int ncols2 = 128 * FIRP_R + qpad;
                 const size_t smp2 = (size_t)((dsr * qpad + 1) & ~1) * sizeof(float) +

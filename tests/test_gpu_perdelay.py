@@ -194,7 +194,9 @@ def test_mixed_radix_every_butterfly(n, plan, monkeypatch, capfd):
                                     (1250, "25,25,2/64"), (2500, "4,25,25/125"), (7000, "7,10,10,10/500"), (7776, "6,6,6,6,6/432"),
                                     # prime factors 11 .. 23 (direct-form butterflies): lengths rounds 1-4 sent through rocFFT rows
                                     (1430, None), (1001, None), (2431, None), (46, None), (33, None), (4199, None), (253, "11,23/23"),
-                                    (2873, "13,17,13/221"), (361, "19,19/19")])
+                                    (2873, "13,17,13/221"), (361, "19,19/19"),
+                                    # beyond 16384 samples: as long as a row image fits the 160 KB of LDS
+                                    (20000, None), (18000, None)])
 def test_jit_kernel_lengths_and_butterflies(n, plan, monkeypatch, capfd):
     monkeypatch.setenv("CAF_JIT_DEBUG", "1")
     monkeypatch.delenv("CAF_JIT", raising=False)
