@@ -263,6 +263,7 @@ constexpr int PDJ_MAXP = 5;
 constexpr int PDJ_PT = 20;  // points a thread holds in a pass (radix 25 alone: 25)
 struct PdjPlan {
     int n = 0, np = 0, tpr = 0, rpw = 0, wg = 0, img = 0, xreg = 0, p0_linear = 0;
+    int q = 1;  // cutout = q x n samples: q residues of an n-point transform (caf_perdelay_jit.h, PDJ_Q); set by pdj_plan_total
     int rad[PDJ_MAXP] = {1, 1, 1, 1, 1}, str[PDJ_MAXP] = {0, 0, 0, 0, 0};
     int ord[PDJ_MAXP][4];
     long conflict_cycles = 0, lds_ops = 0;  // simulated: extra LDS cycles per workgroup and row group / conflict-free cycles
@@ -498,7 +499,7 @@ void pdj_layout(PdjPlan& pl) {
 
 // "pdjplan <version> n np tpr rpw wg img p0_linear conflict base | rad.. | str.. | ord.." in <cache>/plan_v<V>_<n>.txt; the version
 // changes with the planner (model constants, layout search), so that a new library does not pick up an old library's choice
-constexpr int PDJ_PLAN_FILE_VERSION = 4;
+constexpr int PDJ_PLAN_FILE_VERSION = 5;
 std::string plan_file_path(int n) {
     const std::string dir = cache_dir();
     return dir.empty() ? std::string() : dir + "/plan_v" + std::to_string(PDJ_PLAN_FILE_VERSION) + "_" + std::to_string(n) + ".txt";
@@ -587,41 +588,42 @@ bool pdj_plan(int n, PdjPlan& out) {
     int best_tpr = 0;
     double best_cost = 0.0;
     bool forced = false;
-    if (const char* ov = forced_env) {
-        std::vector<int> rad;
-        const char* q = ov;
-        while (*q && *q != '/') {
-            rad.push_back((int)std::strtol(q, const_cast<char**>(&q), 10));
-            if (*q == ',') ++q;
-        }
-        const int tpr = *q == '/' ? (int)std::strtol(q + 1, nullptr, 10) : 0;
-        if (pdj_valid(n, rad, tpr)) best_rad = rad, best_tpr = tpr, best_cost = pdj_cost(n, rad, tpr), forced = true;
-    }
-    auto parse = [&](const char* txt, std::vector<int>& rad, int& tpr) {
+    // "r0,r1,../threads per row" with an optional "xR" = rows per workgroup (default: what fills 256 threads)
+    auto parse = [&](const char* txt, std::vector<int>& rad, int& tpr, int& rpw) {
         rad.clear();
         const char* q = txt;
         while (*q && *q != '/') {
             rad.push_back((int)std::strtol(q, const_cast<char**>(&q), 10));
             if (*q == ',') ++q;
         }
-        tpr = *q == '/' ? (int)std::strtol(q + 1, nullptr, 10) : 0;
+        tpr = *q == '/' ? (int)std::strtol(q + 1, const_cast<char**>(&q), 10) : 0;
+        rpw = *q == 'x' ? (int)std::strtol(q + 1, nullptr, 10) : 0;
+        if (rpw < 0 || (int64_t)rpw * tpr > 1024) rpw = 0;
     };
+    int best_rpw = 0;
+    if (forced_env) {
+        std::vector<int> rad;
+        int tpr = 0, rpw = 0;
+        parse(forced_env, rad, tpr, rpw);
+        if (pdj_valid(n, rad, tpr)) best_rad = rad, best_tpr = tpr, best_rpw = rpw, best_cost = pdj_cost(n, rad, tpr), forced = true;
+    }
     if (!forced && !std::getenv("CAF_PDJ_MODEL_ONLY"))
         for (const PdjTuned& t : PDJ_TUNED)
             if (t.n == n) {
                 std::vector<int> rad;
-                int tpr = 0;
-                parse(t.plan, rad, tpr);
-                if (pdj_valid(n, rad, tpr)) best_rad = rad, best_tpr = tpr, best_cost = pdj_cost(n, rad, tpr), forced = true;
+                int tpr = 0, rpw = 0;
+                parse(t.plan, rad, tpr, rpw);
+                if (pdj_valid(n, rad, tpr)) best_rad = rad, best_tpr = tpr, best_rpw = rpw, best_cost = pdj_cost(n, rad, tpr), forced = true;
             }
     struct Cand {
         std::vector<int> rad;
         int tpr;
         double cost;
+        int rpw;  // 0: the default
     };
     std::vector<Cand> cands;
     if (forced) {
-        cands.push_back({best_rad, best_tpr, best_cost});
+        cands.push_back({best_rad, best_tpr, best_cost, best_rpw});
     } else {
         std::vector<int> cur;
         std::function<void(int)> rec = [&](int rem) {
@@ -633,7 +635,7 @@ bool pdj_plan(int n, PdjPlan& out) {
                 // (rows of 32 threads and more in whole quarter / half / full waves: 250 or 500 threads per row measured 15-20 %
                 //  slower than 256 / 512 with the same radices)
                 for (int t : {t0 < 32 ? t0 : 0, (t0 + 15) / 16 * 16, (t0 + 31) / 32 * 32, (t0 + 63) / 64 * 64})
-                    if (t && pdj_valid(n, cur, t)) cands.push_back({cur, t, pdj_cost(n, cur, t)});
+                    if (t && pdj_valid(n, cur, t)) cands.push_back({cur, t, pdj_cost(n, cur, t), 0});
                 return;
             }
             if ((int)cur.size() >= PDJ_MAXP) return;
@@ -656,7 +658,7 @@ bool pdj_plan(int n, PdjPlan& out) {
         pl.np = (int)c.rad.size();
         for (int p = 0; p < pl.np; ++p) pl.rad[p] = c.rad[p];
         pl.tpr = c.tpr;
-        pl.rpw = std::max(1, 256 / pl.tpr);
+        pl.rpw = c.rpw ? c.rpw : std::max(1, 256 / pl.tpr);
         pl.wg = (pl.rpw * pl.tpr + 63) / 64 * 64;
         pl.cost = c.cost;
         pdj_layout(pl);
@@ -689,6 +691,24 @@ bool pdj_plan(int n, PdjPlan& out) {
     return pl.tpr > 0;
 }
 
+// Plan of a cutout of nt samples: the transform itself where one LDS image holds it, otherwise q residues of an (nt / q)-point
+// transform (2 <= q <= PDJ_QMAX: every residue re-reads the cutout and the window from the L2, and at q = 8 that costs what the
+// rows path's trip through HBM costs).  CAF_PDJ_Q=q forces a split (the tests run small lengths through it).
+constexpr int PDJ_QMAX = 8;
+constexpr int PDJ_NMAX = 20000;  // (160 KB of LDS hold a row image of ~20000 points; the plan decides)
+bool pdj_plan_total(int nt, PdjPlan& out) {
+    int qforced = 0;
+    if (const char* e = std::getenv("CAF_PDJ_Q")) qforced = std::atoi(e);
+    for (int q = qforced > 0 ? qforced : 1; q <= (qforced > 0 ? qforced : PDJ_QMAX); ++q) {
+        if (nt % q || nt / q > PDJ_NMAX || nt / q < 32) continue;
+        if (pdj_plan(nt / q, out)) {
+            out.q = q;
+            return true;
+        }
+    }
+    return false;
+}
+
 // e^{+j 2 pi q / n}, q < n: one table per loaded kernel (owned by its entry in launch_perdelay_jit's cache)
 int pdj_twiddles(int32_t n, float2** out) {
     std::vector<std::complex<float>> t(n);
@@ -718,7 +738,7 @@ std::vector<std::string> pdj_options(const PdjPlan& pl) {
     std::vector<std::string> opts = {
         "-DPDJ_N=" + std::to_string(pl.n),       "-DPDJ_NP=" + std::to_string(pl.np),   "-DPDJ_TPR=" + std::to_string(pl.tpr),
         "-DPDJ_RPW=" + std::to_string(pl.rpw),   "-DPDJ_WG=" + std::to_string(pl.wg),   "-DPDJ_IMG=" + std::to_string(pl.img),
-        "-DPDJ_XREG=" + std::to_string(pl.xreg), "-DPDJ_P0_LINEAR=" + std::to_string(pl.p0_linear)};
+        "-DPDJ_XREG=" + std::to_string(pl.xreg), "-DPDJ_P0_LINEAR=" + std::to_string(pl.p0_linear), "-DPDJ_Q=" + std::to_string(pl.q)};
     for (int p = 0; p < PDJ_MAXP; ++p) {
         opts.push_back("-DPDJ_R" + std::to_string(p) + "=" + std::to_string(pl.rad[p]));
         opts.push_back("-DPDJ_S" + std::to_string(p) + "=" + std::to_string(pl.str[p]));
@@ -738,7 +758,7 @@ void perdelay_jit_failed(int32_t n) {
     g_failed[n] = true;
 }
 bool perdelay_jit_ok(int32_t n) {
-    if (!jit_enabled() || n < 32 || n > 20000) return false;  // (160 KB of LDS hold a row image of ~20000 points; the plan decides)
+    if (!jit_enabled() || n < 32 || n > PDJ_NMAX * PDJ_QMAX) return false;
     int32_t r = n;
     for (int p : {2, 3, 5, 7, 11, 13, 17, 19, 23})
         while (r % p == 0) r /= p;
@@ -749,7 +769,7 @@ bool perdelay_jit_ok(int32_t n) {
         if (g_failed.count(n)) return false;
     }
     PdjPlan pl;
-    return pdj_plan(n, pl);
+    return pdj_plan_total(n, pl);
 }
 
 int launch_perdelay_jit(const float2* x, int32_t n, const float2* y, int64_t ylen, const double* prefix, const double* xnorm,
@@ -761,6 +781,7 @@ int launch_perdelay_jit(const float2* x, int32_t n, const float2* y, int64_t yle
         PdjPlan pl;
         hipFunction_t fn = nullptr;
         float2* tw = nullptr;  // owned: freed when the entry is evicted
+        float2* twq = nullptr;  // split form: e^{+j 2 pi i / (q n)}, owned
         uint64_t used = 0;     // last call (for the eviction of the least recently used entry)
     };
     static std::mutex mu;
@@ -770,7 +791,8 @@ int launch_perdelay_jit(const float2* x, int32_t n, const float2* y, int64_t yle
     int dev = 0;
     CAF_HIP_TRY(hipGetDevice(&dev));
     const char* forced_env = std::getenv("CAF_PDJ_PLAN");
-    const auto key = std::make_tuple(dev, (int)n, std::string(forced_env ? forced_env : ""));
+    const char* q_env = std::getenv("CAF_PDJ_Q");
+    const auto key = std::make_tuple(dev, (int)n, std::string(forced_env ? forced_env : "") + (q_env ? std::string("|") + q_env : std::string()));
     Ready r;
     bool have = false;
     {
@@ -782,7 +804,7 @@ int launch_perdelay_jit(const float2* x, int32_t n, const float2* y, int64_t yle
         }
     }
     if (!have) {
-        if (!pdj_plan(n, r.pl)) {
+        if (!pdj_plan_total(n, r.pl)) {
             set_error("launch_perdelay_jit: unsupported length");
             return CAF_ERR_INVALID;
         }
@@ -791,7 +813,7 @@ int launch_perdelay_jit(const float2* x, int32_t n, const float2* y, int64_t yle
         // re-read per row from the L1 / L2 otherwise: decided by compiling the first variant and reading its spill count
         int rc = CAF_OK;
         const char* xe = std::getenv("CAF_PDJ_XREG");
-        if (!xe || std::atoi(xe)) {
+        if (r.pl.q == 1 && (!xe || std::atoi(xe))) {
             r.pl.xreg = 1;
             rc = jit_function(dev, "#include \"caf_perdelay_jit.h\"\n", pdj_options(r.pl), "k_pdj", what.c_str(), &r.fn, xe ? 1L << 30 : 0);
             if (rc) return rc;
@@ -801,7 +823,11 @@ int launch_perdelay_jit(const float2* x, int32_t n, const float2* y, int64_t yle
             rc = jit_function(dev, "#include \"caf_perdelay_jit.h\"\n", pdj_options(r.pl), "k_pdj", what.c_str(), &r.fn);
             if (rc) return rc;
         }
-        if ((rc = pdj_twiddles(n, &r.tw))) return rc;
+        if ((rc = pdj_twiddles(r.pl.n, &r.tw))) return rc;
+        if (r.pl.q > 1 && (rc = pdj_twiddles(n, &r.twq))) {
+            (void)pool_free(r.tw);
+            return rc;
+        }
         std::lock_guard<std::mutex> lk(mu);
         if (ready.size() >= READY_MAX) {
             // the least recently used entry goes, with its twiddle table -- once nothing on the device can still be reading it
@@ -812,6 +838,7 @@ int launch_perdelay_jit(const float2* x, int32_t n, const float2* y, int64_t yle
                 if (it->second.used < old->second.used) old = it;
             CAF_HIP_TRY(hipDeviceSynchronize());
             (void)pool_free(old->second.tw);
+            if (old->second.twq) (void)pool_free(old->second.twq);
             ready.erase(old);
         }
         r.used = ++tick;
@@ -821,18 +848,19 @@ int launch_perdelay_jit(const float2* x, int32_t n, const float2* y, int64_t yle
     if (jit_debug()) {
         std::string t, sd;
         for (int p = 0; p < pl.np; ++p) t += (p ? "," : "") + std::to_string(pl.rad[p]), sd += (p ? "," : "") + std::to_string(pl.str[p]);
-        std::fprintf(stderr, "[caf jit] n=%d plan=%s/%d rows_per_workgroup=%d strides=%s image=%d cost=%.0f | simulated LDS: %ld conflict "
-                     "cycles on %ld conflict-free ones (%.1f %%)\n", n, t.c_str(), pl.tpr, pl.rpw, sd.c_str(), pl.img, pl.cost,
+        std::fprintf(stderr, "[caf jit] n=%d plan=%s/%d residues=%d rows_per_workgroup=%d strides=%s image=%d cost=%.0f | simulated LDS: %ld conflict "
+                     "cycles on %ld conflict-free ones (%.1f %%)\n", n, t.c_str(), pl.tpr, pl.q, pl.rpw, sd.c_str(), pl.img, pl.cost,
                      pl.conflict_cycles, pl.lds_ops, pl.lds_ops ? 100.0 * pl.conflict_cycles / pl.lds_ops : 0.0);
     }
     const float2* tw = r.tw;
+    const float2* twq = r.twq;
     const int64_t groups = (num + pl.rpw - 1) / pl.rpw;
     int32_t rows_per_wg = (int32_t)std::max<int64_t>(1, std::min<int64_t>(16, groups / 4096));
     const int64_t nwg = (groups + rows_per_wg - 1) / rows_per_wg;
     CAF_REQUIRE(nwg <= 0x7fffffff, "caf_xcorr_perdelay: too many delays for one launch");
     int32_t zo = zero_oor;
-    void* args[] = {(void*)&x,   (void*)&y,           (void*)&ylen, (void*)&tw,  (void*)&prefix, (void*)&xnorm,  (void*)&start, (void*)&step,
-                    (void*)&num, (void*)&rows_per_wg, (void*)&zo,   (void*)&qf2, (void*)&fidx,   (void*)&plane, (void*)&cplane};
+    void* args[] = {(void*)&x,     (void*)&y,    (void*)&ylen, (void*)&tw,          (void*)&twq, (void*)&prefix, (void*)&xnorm, (void*)&start,
+                    (void*)&step,  (void*)&num,  (void*)&rows_per_wg, (void*)&zo,   (void*)&qf2, (void*)&fidx,   (void*)&plane, (void*)&cplane};
     CAF_HIP_TRY(hipModuleLaunchKernel(r.fn, (unsigned)nwg, 1, 1, (unsigned)pl.wg, 1, 1, 0, st, args, nullptr));
     return CAF_OK;
 }
@@ -842,15 +870,15 @@ int launch_perdelay_jit(const float2* x, int32_t n, const float2* y, int64_t yle
 int perdelay_jit_describe(int32_t n, const char* arch, const char* dump_path, std::string* text) {
     PdjPlan pl;
     text->clear();
-    if (!pdj_plan(n, pl)) return CAF_OK;
+    if (!pdj_plan_total(n, pl)) return CAF_OK;
     char buf[640];
     std::string t, s, o;
     for (int p = 0; p < pl.np; ++p) {
         t += (p ? "," : "") + std::to_string(pl.rad[p]), s += (p ? "," : "") + std::to_string(pl.str[p]);
         o += (p ? " " : "") + brace_list(pl.ord[p], pl.np - 1);
     }
-    std::snprintf(buf, sizeof(buf), "n=%d radices=%s tpr=%d rpw=%d wg=%d strides=%s orders=%s img=%d lds_bytes=%d xreg=%d conflict_cycles=%ld base_cycles=%ld",
-                  n, t.c_str(), pl.tpr, pl.rpw, pl.wg, s.c_str(), o.c_str(), pl.img, pl.rpw * pl.img * 8, pl.xreg, pl.conflict_cycles, pl.lds_ops);
+    std::snprintf(buf, sizeof(buf), "n=%d q=%d radices=%s tpr=%d rpw=%d wg=%d strides=%s orders=%s img=%d lds_bytes=%d xreg=%d conflict_cycles=%ld base_cycles=%ld",
+                  n, pl.q, t.c_str(), pl.tpr, pl.rpw, pl.wg, s.c_str(), o.c_str(), pl.img, pl.rpw * pl.img * 8, pl.xreg, pl.conflict_cycles, pl.lds_ops);
     *text = buf;
     if (arch && *arch) {
         std::vector<char> code;

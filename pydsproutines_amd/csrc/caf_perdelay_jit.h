@@ -22,7 +22,17 @@
 // Macros (all integers): PDJ_N, PDJ_NP (passes, 2 .. 5), PDJ_R0 .. PDJ_R4 (1 beyond the last pass), PDJ_S0 .. PDJ_S4 (position
 // strides), PDJ_ORD0 .. PDJ_ORD4 (brace lists: for pass p the other dimensions, fastest lane digit first, -1 padded), PDJ_TPR
 // (threads per row), PDJ_RPW (rows per workgroup), PDJ_WG (workgroup size), PDJ_IMG (row image, elements), PDJ_XREG (cutout
-// held in registers across rows), PDJ_P0_LINEAR (pass 0: position == butterfly index).
+// held in registers across rows), PDJ_P0_LINEAR (pass 0: position == butterfly index), PDJ_Q (below; 1 when absent).
+//
+// Cutouts longer than one LDS image (PDJ_Q = Q > 1, cutout length NT = Q N): one decimation-in-frequency step in front of the
+// transform, taken one output residue at a time.  With n = j + m N and k = tq + Q k',
+//   Z[tq + Q k'] = sum_{j < N} g_tq[j] W_N^{j k'},     g_tq[j] = W_NT^{j tq} sum_{m < Q} u[j + m N] W_Q^{m tq},     u = conj(x y)
+// so a row is Q transforms of N points in the same image: pass 0 of residue tq forms g_tq on the fly -- Q loads of the cutout and
+// of the window per point instead of one, out of the L2 (a row's window and the cutout are re-read Q times, and consecutive rows
+// overlap in all but `step` samples) --, the constants W_Q^{m tq} and the step of the input twiddle are uniform (scalar loads
+// from the NT-entry table `twq`), the per-point twiddle W_NT^{j tq} is one table entry per butterfly times powers of that step.
+// Nothing goes through HBM between the product and the maximum, which is what the rows path (product rows -> rocFFT -> argmax)
+// does for these lengths.
 #ifdef __HIPCC_RTC__
 typedef int int32_t;
 typedef unsigned int uint32_t;
@@ -35,7 +45,12 @@ typedef unsigned long long uint64_t;
 namespace caf {
 namespace pdj {
 
+#ifndef PDJ_Q
+#define PDJ_Q 1
+#endif
 constexpr int P = PDJ_NP, N = PDJ_N, TPR = PDJ_TPR, RPW = PDJ_RPW, WG = PDJ_WG, IMG = PDJ_IMG;
+constexpr int Q = PDJ_Q, NT = N * Q;  // NT: the cutout's length; N: the transform the image holds
+static_assert(Q == 1 || !PDJ_XREG, "the cutout stays in registers only in the one-image form");
 // (as constexpr functions over local tables: namespace-scope arrays would be host variables to the device pass)
 constexpr int cRAD(int d) {
     constexpr int T[5] = {PDJ_R0, PDJ_R1, PDJ_R2, PDJ_R3, PDJ_R4};
@@ -183,7 +198,8 @@ __device__ __forceinline__ void middle_pass(float2* __restrict__ buf, const floa
 }  // namespace caf
 
 extern "C" __global__ __launch_bounds__(PDJ_WG, 4) void k_pdj(const float2* __restrict__ x, const float2* __restrict__ y, int64_t ylen,
-                                                              const float2* __restrict__ tw, const double* __restrict__ prefix,
+                                                              const float2* __restrict__ tw, const float2* __restrict__ twq,
+                                                              const double* __restrict__ prefix,
                                                               const double* __restrict__ xnorm, int64_t start, int64_t step,
                                                               int64_t num, int32_t rows_per_wg, int32_t zero_oor,
                                                               float* __restrict__ qf2, uint32_t* __restrict__ fidx,
@@ -220,7 +236,7 @@ extern "C" __global__ __launch_bounds__(PDJ_WG, 4) void k_pdj(const float2* __re
     double pa_n = 0.0, pb_n = 0.0;
     auto energy_bounds = [&](int64_t s_, int64_t& a_, int64_t& b_) {
         a_ = s_ < 0 ? 0 : (s_ > ylen ? ylen : s_);
-        b_ = s_ + N;
+        b_ = s_ + NT;
         b_ = b_ < 0 ? 0 : (b_ > ylen ? ylen : b_);
     };
     if (norm_lane) {
@@ -232,7 +248,7 @@ extern "C" __global__ __launch_bounds__(PDJ_WG, 4) void k_pdj(const float2* __re
         const int64_t row = row0 + (int64_t)it * RPW + rl;
         const bool live = active && row < num;
         const int64_t s = start + row * step;
-        const bool oor = (s < 0) || (s + N > ylen);
+        const bool oor = (s < 0) || (s + NT > ylen);
         const bool zero = !live || (oor && zero_oor);
         // (an opaque copy of the row-local thread index: everything derived from it -- sixteen 64-bit cutout addresses, plane
         //  indices, image positions -- is the same for every row, gets hoisted out of the row loop and is spilled there)
@@ -240,6 +256,12 @@ extern "C" __global__ __launch_bounds__(PDJ_WG, 4) void k_pdj(const float2* __re
         asm volatile("" : "+v"(l));
         const bool norm_thread = norm_lane && !zero;
         const double pa = pa_n, pb = pb_n;
+        float bv = -1.f;  // the row's maximum as this thread sees it (over its bins of every residue)
+        uint32_t bi = 0;
+#pragma unroll 1
+        for (int tq = 0; tq < Q; ++tq) {
+        const int pass_it = it * Q + tq;
+        if constexpr (Q > 1) asm volatile("" : "+v"(l));  // (as above, per residue: Q x R0 x CNT0 load offsets would be hoisted and spilled)
         // ---- pass 0: global loads, product with the cutout, butterfly, twiddles, into the image
         {
             const bool inside = !zero && !oor;
@@ -250,7 +272,7 @@ extern "C" __global__ __launch_bounds__(PDJ_WG, 4) void k_pdj(const float2* __re
                 const bool ok = active && (cFULL(0) || b < NB0);
                 const int bb = cFULL(0) ? b : min(b, NB0 - 1);
                 float2 v[R0];
-                {
+                if constexpr (Q == 1) {
                     // every load of the butterfly goes out before the first product is formed (left to itself the scheduler pairs
                     // each cutout / window load with its product and waits for memory sixteen times per butterfly)
                     float2 xa[R0], yq[R0];
@@ -276,17 +298,55 @@ extern "C" __global__ __launch_bounds__(PDJ_WG, 4) void k_pdj(const float2* __re
 #pragma unroll
                     for (int t = 0; t < R0; ++t)  // conj(x y): forward = conj(IDFT(conj .))
                         v[t] = make_float2(xa[t].x * yq[t].x - xa[t].y * yq[t].y, -(xa[t].x * yq[t].y + xa[t].y * yq[t].x));
+                } else {
+                    // g_tq of the butterfly's R0 points: Q batches of loads, each folded in with its uniform constant W_Q^{m tq}
+#pragma unroll
+                    for (int t = 0; t < R0; ++t) v[t] = make_float2(0.f, 0.f);
+#pragma unroll 1
+                    for (int m = 0; m < Q; ++m) {
+                        float2 xa[R0], yq[R0];
+#pragma unroll
+                        for (int t = 0; t < R0; ++t) xa[t] = gld(x, (uint32_t)(bb + t * NB0 + m * N));
+                        if (inside) {
+#pragma unroll
+                            for (int t = 0; t < R0; ++t) yq[t] = gld(yrow, (uint32_t)(bb + t * NB0 + m * N));
+                        } else {
+#pragma unroll
+                            for (int t = 0; t < R0; ++t) {
+                                const int64_t g = s + bb + t * NB0 + m * N;
+                                yq[t] = (!zero && g >= 0 && g < ylen) ? y[g] : make_float2(0.f, 0.f);
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        const float2 cm = twq[((m * tq) % Q) * N];  // (uniform: a scalar load)
+#pragma unroll
+                        for (int t = 0; t < R0; ++t) {
+                            const float2 u = make_float2(xa[t].x * yq[t].x - xa[t].y * yq[t].y, -(xa[t].x * yq[t].y + xa[t].y * yq[t].x));
+                            v[t].x = __builtin_fmaf(u.x, cm.x, __builtin_fmaf(-u.y, cm.y, v[t].x));
+                            v[t].y = __builtin_fmaf(u.x, cm.y, __builtin_fmaf(u.y, cm.x, v[t].y));
+                        }
+                    }
+                    if (tq) {  // W_NT^{(bb + t NB0) tq}: one entry per butterfly, times powers of the uniform step W_NT^{NB0 tq}
+                        float2 pw = gld(twq, (uint32_t)(bb * tq));
+                        const float2 ws = twq[NB0 * tq];
+                        v[0] = cmul(v[0], pw);
+#pragma unroll
+                        for (int t = 1; t < R0; ++t) {
+                            pw = cmul(pw, ws);
+                            v[t] = cmul(v[t], pw);
+                        }
+                    }
                 }
                 mr_idft<R0>(v);
                 int base, m;
                 decode<0>(bb, base, m);
-                twiddle<0>(v, gld(tw, (uint32_t)m), it);  // (K_0 = 1)
+                twiddle<0>(v, gld(tw, (uint32_t)m), pass_it);  // (K_0 = 1)
                 if (ok) {
 #pragma unroll
                     for (int t = 0; t < R0; ++t) lds_st(&buf[base + t * cSTR(0)], v[t]);
                 }
             }
-            if (active && l_fixed == 0) {
+            if (active && l_fixed == 0 && tq == 0) {
                 // rsq(E ||x||^2) + one Newton step (2^-45 or better before the rounding to float32).  E = 0: rsq = inf, 0 * inf = NaN row.
                 float inv0 = 0.f;
                 if (norm_thread) {
@@ -304,12 +364,11 @@ extern "C" __global__ __launch_bounds__(PDJ_WG, 4) void k_pdj(const float2* __re
             }
             row_sync();
         }
-        if constexpr (P > 2) middle_pass<1>(buf, tw, l, active, it);
-        if constexpr (P > 3) middle_pass<2>(buf, tw, l, active, it);
-        if constexpr (P > 4) middle_pass<3>(buf, tw, l, active, it);
-        // ---- last pass: butterflies in natural order of (k_0, k_1, ...): register (b, t) is spectrum index b + t NBL
-        float bv = -1.f;
-        uint32_t bi = 0;
+        if constexpr (P > 2) middle_pass<1>(buf, tw, l, active, pass_it);
+        if constexpr (P > 3) middle_pass<2>(buf, tw, l, active, pass_it);
+        if constexpr (P > 4) middle_pass<3>(buf, tw, l, active, pass_it);
+        // ---- last pass: butterflies in natural order of (k_0, k_1, ...): register (b, t) is spectrum index b + t NBL of the
+        // image's transform, i.e. bin tq + Q (b + t NBL) of the row
         {
             float2 v[CNTL][RL];
             bool okc[CNTL];
@@ -324,6 +383,8 @@ extern "C" __global__ __launch_bounds__(PDJ_WG, 4) void k_pdj(const float2* __re
                 mr_idft<RL>(v[c]);
             }
             const float inv = *(volatile float*)&s_inv[rl];  // (written before the barrier of pass 0)
+            float lv = -1.f;
+            uint32_t li = 0;
 #pragma unroll
             for (int t = 0; t < RL; ++t)
 #pragma unroll
@@ -331,28 +392,38 @@ extern "C" __global__ __launch_bounds__(PDJ_WG, 4) void k_pdj(const float2* __re
                     const float zr = v[c][t].x * inv, zi = v[c][t].y * inv;
                     v[c][t] = make_float2(zr, zi);
                     const float val = __builtin_fmaf(zr, zr, zi * zi);
-                    const bool up = okc[c] && val > bv;  // (ascending index: the strict comparison keeps the first maximum)
-                    bv = up ? val : bv;
-                    bi = up ? (uint32_t)(l + c * TPR + t * NBL) : bi;
+                    const bool up = okc[c] && val > lv;  // (ascending index: the strict comparison keeps the first maximum)
+                    lv = up ? val : lv;
+                    li = up ? (uint32_t)(l + c * TPR + t * NBL) : li;
                 }
-            // the optional planes leave from the registers as contiguous runs, behind ONE uniform branch each
+            if constexpr (Q == 1) {
+                bv = lv, bi = li;
+            } else {  // (residues are not visited in ascending bin order: equal values keep the lower bin)
+                li = (uint32_t)tq + (uint32_t)Q * li;
+                const bool take = lv > bv || (lv == bv && li < bi);
+                bv = take ? lv : bv;
+                bi = take ? li : bi;
+            }
+            // the optional planes leave from the registers as contiguous runs (Q > 1: every Q-th bin), behind ONE uniform branch each
             if (plane && live) {
-                float* prow = plane + row * N;
+                float* prow = plane + row * NT + tq;
 #pragma unroll
                 for (int t = 0; t < RL; ++t)
 #pragma unroll
                     for (int c = 0; c < CNTL; ++c)
-                        if (cFULL(P - 1) || okc[c]) prow[l + c * TPR + t * NBL] = __builtin_fmaf(v[c][t].x, v[c][t].x, v[c][t].y * v[c][t].y);
+                        if (cFULL(P - 1) || okc[c]) prow[Q * (l + c * TPR + t * NBL)] = __builtin_fmaf(v[c][t].x, v[c][t].x, v[c][t].y * v[c][t].y);
             }
             if (cplane && live) {
-                float2* crow = cplane + row * N;
+                float2* crow = cplane + row * NT + tq;
 #pragma unroll
                 for (int t = 0; t < RL; ++t)
 #pragma unroll
                     for (int c = 0; c < CNTL; ++c)
-                        if (cFULL(P - 1) || okc[c]) crow[l + c * TPR + t * NBL] = make_float2(v[c][t].x, -v[c][t].y);
+                        if (cFULL(P - 1) || okc[c]) crow[Q * (l + c * TPR + t * NBL)] = make_float2(v[c][t].x, -v[c][t].y);
             }
         }
+        if (Q > 1 && tq + 1 < Q) row_sync();  // the image is read to the end before the next residue's first pass overwrites it
+        }  // residues
         if (qf2 || fidx) {
             // one 64-bit maximum of (value bits, ~index) per row: values are >= +0, whose bit patterns order like the numbers; a
             // thread that saw only NaNs offers nothing, so an all-NaN row -- a zero-energy window -- keeps key 0 -> (NaN, 0)

@@ -4,7 +4,10 @@ measured-fastest plans (csrc/caf_pdj_tuned.inc):
                      + c[position] per pass )  +  a charge per row
 w = A + B log2(radix) + C [radix not a power of two]; position = first / middle / last pass.  Plans with a first radix above 16 are
 left out of the fit (they spill; the planner excludes them by rule).
-usage: python scripts/fit_pdj_model.py profiles/r05/pdj_plan_sweep.csv [--tuned pydsproutines_amd/csrc/caf_pdj_tuned.inc]"""
+Rows per workgroup: the default fills 256 threads; --rpw CSV (scripts/sweep_pdj_rpw.py) adds "xR" to a tuned plan where another count
+measured more than 4 % faster (and the two sweeps agree on the default's time within 3 %).
+usage: python scripts/fit_pdj_model.py profiles/r05/pdj_plan_sweep.csv [--rpw profiles/r05/pdj_rpw_sweep.csv]
+                                       [--tuned pydsproutines_amd/csrc/caf_pdj_tuned.inc]"""
 import collections
 import csv
 import math
@@ -56,6 +59,16 @@ print("    static const double PASS[3] = {%.1f, %.1f, %.1f}, BFLY[3] = {%.1f, %.
 by = collections.defaultdict(list)
 for (n, rad, tpr, ms) in rows:
     by[n].append((ms, float(features(n, rad, tpr) @ sol), rad, tpr))
+rpw_best = {}
+if "--rpw" in sys.argv:
+    per = collections.defaultdict(list)
+    for r in csv.reader(open(sys.argv[sys.argv.index("--rpw") + 1])):
+        if len(r) >= 6 and r[4] != "nan" and int(r[5]):
+            per[(int(r[0]), r[1], int(r[2]))].append((float(r[4]), int(r[3]), len(r) > 9 and r[9] == "default"))
+    for k, v in per.items():
+        dflt = [x for x in v if x[2]]
+        if dflt and min(v)[0] < 0.96 * dflt[0][0]:
+            rpw_best[k] = min(v) + (dflt[0][0],)
 worst, tuned = 0.0, []
 for n in sorted(by):
     best = min(by[n])
@@ -66,7 +79,13 @@ for n in sorted(by):
     frac = 1e5 * 5 * n * math.log2(n) / (best[0] * 1e-3) / 157.3e12
     print("n=%5d fastest %-14s/%-4d %.3f ms per 1e5 rows (%.3f of the f32 peak) | model picks %-14s/%-4d %.3f ms (+%.1f %%)" % (
         n, "-".join(map(str, best[2])), best[3], best[0], frac, "-".join(map(str, pick[2])), pick[3], pick[0], 100 * loss))
-    tuned.append('{%d, "%s/%d"},  // %.3f ms per 1e5 delays, %.3f of the f32 peak' % (n, ",".join(map(str, best[2])), best[3], best[0], frac))
+    rb = rpw_best.get((n, "-".join(map(str, best[2])), best[3]))
+    if rb and abs(rb[3] / best[0] - 1) < 0.03:  # (only where the two sweeps agree on the default's time: a noisy run proves nothing)
+        frac = 1e5 * 5 * n * math.log2(n) / (rb[0] * 1e-3) / 157.3e12
+        tuned.append('{%d, "%s/%dx%d"},  // %.3f ms per 1e5 delays, %.3f of the f32 peak (%d rows per workgroup: pdj_rpw_sweep.csv)' % (
+            n, ",".join(map(str, best[2])), best[3], rb[1], rb[0], frac, rb[1]))
+    else:
+        tuned.append('{%d, "%s/%d"},  // %.3f ms per 1e5 delays, %.3f of the f32 peak' % (n, ",".join(map(str, best[2])), best[3], best[0], frac))
 print("worst loss of the model's pick: %.1f %%" % (100 * worst))
 if "--tuned" in sys.argv:
     path = sys.argv[sys.argv.index("--tuned") + 1]

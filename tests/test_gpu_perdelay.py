@@ -209,6 +209,25 @@ def test_jit_kernel_lengths_and_butterflies(n, plan, monkeypatch, capfd):
         assert "[caf jit] n=%d plan=%s " % (n, plan) in err  # (the forced plan was valid and is the one that ran)
 
 
+# cutouts longer than one LDS image: Q residues of an (n / Q)-point transform per row (caf_perdelay_jit.h, PDJ_Q) -- forced on short
+# lengths for every Q, then the lengths that need it (rounds 1-4: product rows -> rocFFT rows -> argmax through HBM)
+@pytest.mark.parametrize("n,q", [(2400, 2), (3600, 3), (4800, 4), (6000, 5), (7200, 6), (8400, 7), (9600, 8), (2002, 2), (96, 3),
+                                 (19200, None), (24000, None), (32768, None), (40000, None), (50000, None), (65536, None)])
+def test_jit_kernel_split_form(n, q, monkeypatch, capfd):
+    monkeypatch.setenv("CAF_JIT_DEBUG", "1")
+    monkeypatch.delenv("CAF_JIT", raising=False)
+    if q:
+        monkeypatch.setenv("CAF_PDJ_Q", str(q))
+        monkeypatch.setenv("CAF_JIT_ALL", "1")
+    _composite_cutout_checks(n)
+    err = capfd.readouterr().err
+    assert "[caf jit] n=%d plan=" % n in err, err
+    if q:
+        assert " residues=%d " % q in err
+    else:
+        assert " residues=1 " not in err
+
+
 def test_jit_and_prebuilt_kernels_agree(monkeypatch):
     """The two mixed-radix kernels (run-time compiled / plan-driven) on the same rows: same maxima to float32 rounding, same bins."""
     rng = np.random.default_rng(12)
