@@ -692,9 +692,11 @@ bool pdj_plan(int n, PdjPlan& out) {
 }
 
 // Plan of a cutout of nt samples: the transform itself where one LDS image holds it, otherwise q residues of an (nt / q)-point
-// transform (2 <= q <= PDJ_QMAX: every residue re-reads the cutout and the window from the L2, and at q = 8 that costs what the
-// rows path's trip through HBM costs).  CAF_PDJ_Q=q forces a split (the tests run small lengths through it).
-constexpr int PDJ_QMAX = 8;
+// transform, 2 <= q <= PDJ_QMAX.  Every residue re-reads the cutout and the window from the L2 -- 16 q bytes per sample, delivered
+// at ~90 GB/s per CU, which is what bounds the split form -- so its lead over the rows path's trip through HBM shrinks with q:
+// 32768 samples (q = 2) 2.8 x, 40000 3.6 x, 65536 (4) 2.2 x, 100000 (5) 3.3 x, 131072 (8) 1.9 x, 262144 (16) 1.2 x, 320000 (16)
+// 1.06 x (profiles/r05/timing_perdelay_long.log).  CAF_PDJ_Q=q forces a split (the tests run small lengths through it).
+constexpr int PDJ_QMAX = 16;
 constexpr int PDJ_NMAX = 20000;  // (160 KB of LDS hold a row image of ~20000 points; the plan decides)
 bool pdj_plan_total(int nt, PdjPlan& out) {
     int qforced = 0;

@@ -193,6 +193,7 @@ def _smooth_lengths(limit, max_prime=23):
 
 
 _LENGTHS = _smooth_lengths(16384)
+_LONG_LENGTHS = [n for n in _smooth_lengths(120000) if n > 16384]  # up to 20000: one LDS image; beyond: residues (caf_perdelay_jit.h, PDJ_Q)
 
 
 @pytest.mark.parametrize("seed", CASES)
@@ -200,7 +201,7 @@ def test_perdelay_random_cutout_lengths(seed):
     """caf_xcorr_perdelay at random cutout lengths whose prime factors are at most 23 -- whatever kernel the library routes them to
     (powers of two / ten, or the kernel it compiles for the length at run time with the plan its model picks) -- against the
     oracle's fastXcorr(freqsearch=True): maxima to 2e-5, bins exact where the oracle's top-2 margin is clear, planes, strides in
-    both directions, the (0, 0) rule for windows that leave rx."""
+    both directions, the (0, 0) rule for windows that leave rx.  Every other seed adds a length of 16385 ... 120000 samples."""
     import ctypes as ct
 
     from pydsproutines_amd import _lib, asarray
@@ -209,8 +210,11 @@ def test_perdelay_random_cutout_lengths(seed):
     rng = np.random.default_rng(9100 + seed)
     lib = _lib.load()
     # two lengths per seed: one anywhere, one short (many rows per workgroup)
-    for n in (int(rng.choice(_LENGTHS)), int(rng.choice([v for v in _LENGTHS if v <= 600]))):
-        num = int(rng.integers(3, 40 if n > 4000 else 120))
+    lens = [int(rng.choice(_LENGTHS)), int(rng.choice([v for v in _LENGTHS if v <= 600]))]
+    if seed % 2 == 0:
+        lens.append(int(rng.choice(_LONG_LENGTHS)))
+    for n in lens:
+        num = int(rng.integers(3, 12 if n > 16384 else (40 if n > 4000 else 120)))
         step = int(rng.choice([1, 1, 2, -1, 5]))
         m = n + abs(step) * num + int(rng.integers(0, 50))
         rx = cn(rng, m)

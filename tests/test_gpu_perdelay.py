@@ -211,8 +211,8 @@ def test_jit_kernel_lengths_and_butterflies(n, plan, monkeypatch, capfd):
 
 # cutouts longer than one LDS image: Q residues of an (n / Q)-point transform per row (caf_perdelay_jit.h, PDJ_Q) -- forced on short
 # lengths for every Q, then the lengths that need it (rounds 1-4: product rows -> rocFFT rows -> argmax through HBM)
-@pytest.mark.parametrize("n,q", [(2400, 2), (3600, 3), (4800, 4), (6000, 5), (7200, 6), (8400, 7), (9600, 8), (2002, 2), (96, 3),
-                                 (19200, None), (24000, None), (32768, None), (40000, None), (50000, None), (65536, None)])
+@pytest.mark.parametrize("n,q", [(2400, 2), (3600, 3), (4800, 4), (6000, 5), (7200, 6), (8400, 7), (9600, 8), (2002, 2), (96, 3), (5120, 16), (3744, 13),
+                                 (19200, None), (24000, None), (32768, None), (40000, None), (50000, None), (65536, None), (100000, None)])
 def test_jit_kernel_split_form(n, q, monkeypatch, capfd):
     monkeypatch.setenv("CAF_JIT_DEBUG", "1")
     monkeypatch.delenv("CAF_JIT", raising=False)
