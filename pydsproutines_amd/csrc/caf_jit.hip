@@ -263,6 +263,7 @@ constexpr int PDJ_MAXP = 5;
 constexpr int PDJ_PT = 20;  // points a thread holds in a pass (radix 25 alone: 25)
 struct PdjPlan {
     int n = 0, np = 0, tpr = 0, rpw = 0, wg = 0, img = 0, xreg = 0, p0_linear = 0;
+    int blu = 0, nx = 0;  // blu: n is the length of Bluestein's circular convolution for a cutout of nx samples (pdj_plan_total)
     int q = 1;  // cutout = q x n samples: q residues of an n-point transform (caf_perdelay_jit.h, PDJ_Q); set by pdj_plan_total
     int rad[PDJ_MAXP] = {1, 1, 1, 1, 1}, str[PDJ_MAXP] = {0, 0, 0, 0, 0};
     int ord[PDJ_MAXP][4];
@@ -561,6 +562,33 @@ bool plan_file_load(int n, PdjPlan& pl) {
     return true;
 }
 
+// every valid (radix order, threads per row) of a length with its modelled cost
+template <class F>
+void pdj_enumerate(int n, F&& emit) {
+    std::vector<int> cur;
+    std::function<void(int)> rec = [&](int rem) {
+        if (rem == 1) {
+            if (cur.size() < 2) return;
+            int cap = PDJ_PT;
+            for (int r : cur) cap = std::min(cap, std::max(PDJ_PT, r) / r * r);
+            const int t0 = (n + cap - 1) / cap;
+            // (rows of 32 threads and more in whole quarter / half / full waves: 250 or 500 threads per row measured 15-20 %
+            //  slower than 256 / 512 with the same radices)
+            for (int t : {t0 < 32 ? t0 : 0, (t0 + 15) / 16 * 16, (t0 + 31) / 32 * 32, (t0 + 63) / 64 * 64})
+                if (t && pdj_valid(n, cur, t)) emit(cur, t, pdj_cost(n, cur, t));
+            return;
+        }
+        if ((int)cur.size() >= PDJ_MAXP) return;
+        for (int r : PDJ_RADICES) {  // (every ORDER of the radices is a plan of its own: the passes cost differently by position)
+            if (rem % r) continue;
+            cur.push_back(r);
+            rec(rem / r);
+            cur.pop_back();
+        }
+    };
+    rec(n);
+}
+
 bool pdj_plan(int n, PdjPlan& out) {
     static std::mutex mu;
     static std::map<std::pair<int, std::string>, PdjPlan> memo;  // (length, forced plan or "") -> plan + layout
@@ -625,28 +653,7 @@ bool pdj_plan(int n, PdjPlan& out) {
     if (forced) {
         cands.push_back({best_rad, best_tpr, best_cost, best_rpw});
     } else {
-        std::vector<int> cur;
-        std::function<void(int)> rec = [&](int rem) {
-            if (rem == 1) {
-                if (cur.size() < 2) return;
-                int cap = PDJ_PT;
-                for (int r : cur) cap = std::min(cap, std::max(PDJ_PT, r) / r * r);
-                const int t0 = (n + cap - 1) / cap;
-                // (rows of 32 threads and more in whole quarter / half / full waves: 250 or 500 threads per row measured 15-20 %
-                //  slower than 256 / 512 with the same radices)
-                for (int t : {t0 < 32 ? t0 : 0, (t0 + 15) / 16 * 16, (t0 + 31) / 32 * 32, (t0 + 63) / 64 * 64})
-                    if (t && pdj_valid(n, cur, t)) cands.push_back({cur, t, pdj_cost(n, cur, t), 0});
-                return;
-            }
-            if ((int)cur.size() >= PDJ_MAXP) return;
-            for (int r : PDJ_RADICES) {  // (every ORDER of the radices is a plan of its own: the passes cost differently by position)
-                if (rem % r) continue;
-                cur.push_back(r);
-                rec(rem / r);
-                cur.pop_back();
-            }
-        };
-        rec(n);
+        pdj_enumerate(n, [&](const std::vector<int>& rad, int t, double cost) { cands.push_back({rad, t, cost, 0}); });
         std::sort(cands.begin(), cands.end(), [](const Cand& a, const Cand& b) { return a.cost < b.cost; });
     }
     // Among the plans the model prices within 4 % of the cheapest (four at most), the one whose layout leaves the fewest
@@ -698,17 +705,116 @@ bool pdj_plan(int n, PdjPlan& out) {
 // 1.06 x (profiles/r05/timing_perdelay_long.log).  CAF_PDJ_Q=q forces a split (the tests run small lengths through it).
 constexpr int PDJ_QMAX = 16;
 constexpr int PDJ_NMAX = 20000;  // (160 KB of LDS hold a row image of ~20000 points; the plan decides)
+//
+// Any other length of at most (PDJ_NMAX + 1) / 2 samples -- a prime factor above 23, which is most lengths a burst happens to
+// have -- runs as Bluestein's chirp transform in the same image: n k = (n^2 + k^2 - (k - n)^2) / 2 turns the nx-point transform
+// into a circular convolution of any length m >= 2 nx - 1, i.e. a forward m-point transform, a product with the transformed chirp
+// and the transform back (caf_perdelay_jit.h, PDJ_BLU).  m is the smooth length in [2 nx - 1, 4 nx] whose cheapest plan the cost
+// model prices lowest.  CAF_PDJ_BLUESTEIN=1 sends smooth lengths that way too, CAF_PDJ_BLU_M=m fixes m (tests).
 bool pdj_plan_total(int nt, PdjPlan& out) {
     int qforced = 0;
     if (const char* e = std::getenv("CAF_PDJ_Q")) qforced = std::atoi(e);
-    for (int q = qforced > 0 ? qforced : 1; q <= (qforced > 0 ? qforced : PDJ_QMAX); ++q) {
-        if (nt % q || nt / q > PDJ_NMAX || nt / q < 32) continue;
-        if (pdj_plan(nt / q, out)) {
-            out.q = q;
+    const char* be = std::getenv("CAF_PDJ_BLUESTEIN");
+    const bool blu_forced = be && std::atoi(be) == 1, blu_off = be && std::atoi(be) == 0;
+    if (!blu_forced)
+        for (int q = qforced > 0 ? qforced : 1; q <= (qforced > 0 ? qforced : PDJ_QMAX); ++q) {
+            if (nt % q || nt / q > PDJ_NMAX || nt / q < 32) continue;
+            if (pdj_plan(nt / q, out)) {
+                out.q = q;
+                return true;
+            }
+        }
+    if (blu_off || qforced > 0 || nt < 16 || 2 * (int64_t)nt - 1 > PDJ_NMAX) return false;
+    static std::mutex mu;
+    static std::map<std::pair<int, int>, std::vector<int>> memo;  // (cutout length, forced m) -> convolution lengths, cheapest first
+    std::vector<int> ms;
+    const char* me = std::getenv("CAF_PDJ_BLU_M");
+    const std::pair<int, int> memo_key(nt, me ? std::atoi(me) : 0);
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = memo.find(memo_key);
+        if (it != memo.end()) ms = it->second;
+    }
+    if (ms.empty()) {
+        if (me) {
+            if (std::atoi(me) >= 2 * nt - 1) ms.push_back(std::atoi(me));
+        } else {
+            std::vector<std::pair<double, int>> priced;
+            for (int m = std::max(32, 2 * nt - 1); m <= std::min(PDJ_NMAX, 4 * nt); ++m) {
+                int r = m;
+                for (int p : {2, 3, 5, 7})
+                    while (r % p == 0) r /= p;
+                if (r != 1) continue;
+                double best = 0.0;
+                pdj_enumerate(m, [&](const std::vector<int>&, int, double cost) { best = best == 0.0 || cost < best ? cost : best; });
+                if (best > 0.0) priced.push_back({best, m});
+            }
+            std::sort(priced.begin(), priced.end());
+            for (size_t i = 0; i < priced.size() && i < 4; ++i) ms.push_back(priced[i].second);
+        }
+        std::lock_guard<std::mutex> lk(mu);
+        if (memo.size() > 4096) memo.clear();
+        memo[memo_key] = ms;
+    }
+    for (int m : ms)
+        if (pdj_plan(m, out)) {
+            out.blu = 1, out.nx = nt;
             return true;
         }
-    }
     return false;
+}
+
+// the chirp c[i] = e^{+j pi i^2 / nx}, i < nx, and the transformed, scaled chirp of the convolution, bhat[k] = (1 / m) sum_i b[i]
+// W_m^{i k} with b[i] = b[m - i] = conj(c[i]) for i < nx and zero between -- in float64 on the host (a mixed-radix transform over
+// the plan's own radices), rounded to float32 once
+int pdj_bluestein_tables(const PdjPlan& pl, float2** chirp_out, float2** bhat_out) {
+    using cd = std::complex<double>;
+    const int nx = pl.nx, m = pl.n;
+    std::vector<std::complex<float>> chirp(nx), bhat(m);
+    std::vector<cd> b(m, cd(0.0, 0.0)), wm(m);
+    for (int i = 0; i < m; ++i) wm[i] = std::polar(1.0, 2.0 * M_PI * (double)i / (double)m);
+    for (int i = 0; i < nx; ++i) {
+        const double ph = M_PI * (double)(((int64_t)i * i) % (2 * (int64_t)nx)) / (double)nx;
+        const cd c = std::polar(1.0, ph);
+        chirp[i] = std::complex<float>((float)c.real(), (float)c.imag());
+        b[i] = std::conj(c);
+        if (i) b[m - i] = std::conj(c);
+    }
+    std::vector<cd> out(m), tmp(32);
+    std::function<void(const cd*, cd*, int, int, int)> rec = [&](const cd* in, cd* o, int n, int stride, int level) {
+        if (n == 1) {
+            o[0] = in[0];
+            return;
+        }
+        const int r = pl.rad[level], sub = n / r;
+        for (int q = 0; q < r; ++q) rec(in + (int64_t)q * stride, o + (int64_t)q * sub, sub, stride * r, level + 1);
+        std::vector<cd> t(r), u(r);
+        for (int k = 0; k < sub; ++k) {
+            for (int q = 0; q < r; ++q) t[q] = o[(int64_t)q * sub + k] * wm[(int64_t)q * k * (m / n) % m];
+            for (int j = 0; j < r; ++j) {
+                cd acc(0.0, 0.0);
+                for (int q = 0; q < r; ++q) acc += t[q] * wm[(int64_t)q * j * (m / r) % m];
+                u[j] = acc;
+            }
+            for (int j = 0; j < r; ++j) o[k + (int64_t)sub * j] = u[j];
+        }
+    };
+    rec(b.data(), out.data(), m, 1, 0);
+    for (int k = 0; k < m; ++k) bhat[k] = std::complex<float>((float)(out[k].real() / m), (float)(out[k].imag() / m));
+    float2 *dc = nullptr, *db = nullptr;
+    int rc = pool_alloc((void**)&dc, (int64_t)nx * 8);
+    if (rc) return rc;
+    if ((rc = pool_alloc((void**)&db, (int64_t)m * 8))) {
+        (void)pool_free(dc);
+        return rc;
+    }
+    if ((rc = host_h2d(dc, chirp.data(), (int64_t)nx * 8, nullptr)) || (rc = host_h2d(db, bhat.data(), (int64_t)m * 8, nullptr))) {
+        (void)pool_free(dc);
+        (void)pool_free(db);
+        return rc;
+    }
+    *chirp_out = dc, *bhat_out = db;
+    return CAF_OK;
 }
 
 // e^{+j 2 pi q / n}, q < n: one table per loaded kernel (owned by its entry in launch_perdelay_jit's cache)
@@ -740,7 +846,8 @@ std::vector<std::string> pdj_options(const PdjPlan& pl) {
     std::vector<std::string> opts = {
         "-DPDJ_N=" + std::to_string(pl.n),       "-DPDJ_NP=" + std::to_string(pl.np),   "-DPDJ_TPR=" + std::to_string(pl.tpr),
         "-DPDJ_RPW=" + std::to_string(pl.rpw),   "-DPDJ_WG=" + std::to_string(pl.wg),   "-DPDJ_IMG=" + std::to_string(pl.img),
-        "-DPDJ_XREG=" + std::to_string(pl.xreg), "-DPDJ_P0_LINEAR=" + std::to_string(pl.p0_linear), "-DPDJ_Q=" + std::to_string(pl.q)};
+        "-DPDJ_XREG=" + std::to_string(pl.xreg), "-DPDJ_P0_LINEAR=" + std::to_string(pl.p0_linear), "-DPDJ_Q=" + std::to_string(pl.q),
+        "-DPDJ_BLU=" + std::to_string(pl.blu),   "-DPDJ_NX=" + std::to_string(pl.blu ? pl.nx : pl.n * pl.q)};
     for (int p = 0; p < PDJ_MAXP; ++p) {
         opts.push_back("-DPDJ_R" + std::to_string(p) + "=" + std::to_string(pl.rad[p]));
         opts.push_back("-DPDJ_S" + std::to_string(p) + "=" + std::to_string(pl.str[p]));
@@ -761,10 +868,6 @@ void perdelay_jit_failed(int32_t n) {
 }
 bool perdelay_jit_ok(int32_t n) {
     if (!jit_enabled() || n < 32 || n > PDJ_NMAX * PDJ_QMAX) return false;
-    int32_t r = n;
-    for (int p : {2, 3, 5, 7, 11, 13, 17, 19, 23})
-        while (r % p == 0) r /= p;
-    if (r != 1) return false;
     if (!rtc()->lib) return false;
     {
         std::lock_guard<std::mutex> lk(g_failed_mu);
@@ -783,7 +886,8 @@ int launch_perdelay_jit(const float2* x, int32_t n, const float2* y, int64_t yle
         PdjPlan pl;
         hipFunction_t fn = nullptr;
         float2* tw = nullptr;  // owned: freed when the entry is evicted
-        float2* twq = nullptr;  // split form: e^{+j 2 pi i / (q n)}, owned
+        float2* twq = nullptr;  // split form: e^{+j 2 pi i / (q n)}; Bluestein: the chirp; owned
+        float2* bhat = nullptr;  // Bluestein: the transformed chirp, owned
         uint64_t used = 0;     // last call (for the eviction of the least recently used entry)
     };
     static std::mutex mu;
@@ -793,8 +897,10 @@ int launch_perdelay_jit(const float2* x, int32_t n, const float2* y, int64_t yle
     int dev = 0;
     CAF_HIP_TRY(hipGetDevice(&dev));
     const char* forced_env = std::getenv("CAF_PDJ_PLAN");
-    const char* q_env = std::getenv("CAF_PDJ_Q");
-    const auto key = std::make_tuple(dev, (int)n, std::string(forced_env ? forced_env : "") + (q_env ? std::string("|") + q_env : std::string()));
+    std::string variant = forced_env ? forced_env : "";
+    for (const char* name : {"CAF_PDJ_Q", "CAF_PDJ_BLUESTEIN", "CAF_PDJ_BLU_M"})
+        if (const char* e = std::getenv(name)) variant += std::string("|") + name + "=" + e;
+    const auto key = std::make_tuple(dev, (int)n, variant);
     Ready r;
     bool have = false;
     {
@@ -815,7 +921,7 @@ int launch_perdelay_jit(const float2* x, int32_t n, const float2* y, int64_t yle
         // re-read per row from the L1 / L2 otherwise: decided by compiling the first variant and reading its spill count
         int rc = CAF_OK;
         const char* xe = std::getenv("CAF_PDJ_XREG");
-        if (r.pl.q == 1 && (!xe || std::atoi(xe))) {
+        if (r.pl.q == 1 && !r.pl.blu && (!xe || std::atoi(xe))) {
             r.pl.xreg = 1;
             rc = jit_function(dev, "#include \"caf_perdelay_jit.h\"\n", pdj_options(r.pl), "k_pdj", what.c_str(), &r.fn, xe ? 1L << 30 : 0);
             if (rc) return rc;
@@ -830,6 +936,10 @@ int launch_perdelay_jit(const float2* x, int32_t n, const float2* y, int64_t yle
             (void)pool_free(r.tw);
             return rc;
         }
+        if (r.pl.blu && (rc = pdj_bluestein_tables(r.pl, &r.twq, &r.bhat))) {
+            (void)pool_free(r.tw);
+            return rc;
+        }
         std::lock_guard<std::mutex> lk(mu);
         if (ready.size() >= READY_MAX) {
             // the least recently used entry goes, with its twiddle table -- once nothing on the device can still be reading it
@@ -841,6 +951,7 @@ int launch_perdelay_jit(const float2* x, int32_t n, const float2* y, int64_t yle
             CAF_HIP_TRY(hipDeviceSynchronize());
             (void)pool_free(old->second.tw);
             if (old->second.twq) (void)pool_free(old->second.twq);
+            if (old->second.bhat) (void)pool_free(old->second.bhat);
             ready.erase(old);
         }
         r.used = ++tick;
@@ -850,18 +961,19 @@ int launch_perdelay_jit(const float2* x, int32_t n, const float2* y, int64_t yle
     if (jit_debug()) {
         std::string t, sd;
         for (int p = 0; p < pl.np; ++p) t += (p ? "," : "") + std::to_string(pl.rad[p]), sd += (p ? "," : "") + std::to_string(pl.str[p]);
-        std::fprintf(stderr, "[caf jit] n=%d plan=%s/%d residues=%d rows_per_workgroup=%d strides=%s image=%d cost=%.0f | simulated LDS: %ld conflict "
-                     "cycles on %ld conflict-free ones (%.1f %%)\n", n, t.c_str(), pl.tpr, pl.q, pl.rpw, sd.c_str(), pl.img, pl.cost,
+        std::fprintf(stderr, "[caf jit] n=%d plan=%s/%d residues=%d bluestein=%d rows_per_workgroup=%d strides=%s image=%d cost=%.0f | simulated LDS: %ld conflict "
+                     "cycles on %ld conflict-free ones (%.1f %%)\n", n, t.c_str(), pl.tpr, pl.q, pl.blu ? pl.n : 0, pl.rpw, sd.c_str(), pl.img, pl.cost,
                      pl.conflict_cycles, pl.lds_ops, pl.lds_ops ? 100.0 * pl.conflict_cycles / pl.lds_ops : 0.0);
     }
     const float2* tw = r.tw;
     const float2* twq = r.twq;
+    const float2* bhat = r.bhat;
     const int64_t groups = (num + pl.rpw - 1) / pl.rpw;
     int32_t rows_per_wg = (int32_t)std::max<int64_t>(1, std::min<int64_t>(16, groups / 4096));
     const int64_t nwg = (groups + rows_per_wg - 1) / rows_per_wg;
     CAF_REQUIRE(nwg <= 0x7fffffff, "caf_xcorr_perdelay: too many delays for one launch");
     int32_t zo = zero_oor;
-    void* args[] = {(void*)&x,     (void*)&y,    (void*)&ylen, (void*)&tw,          (void*)&twq, (void*)&prefix, (void*)&xnorm, (void*)&start,
+    void* args[] = {(void*)&x,     (void*)&y,    (void*)&ylen, (void*)&tw,          (void*)&twq, (void*)&bhat, (void*)&prefix, (void*)&xnorm, (void*)&start,
                     (void*)&step,  (void*)&num,  (void*)&rows_per_wg, (void*)&zo,   (void*)&qf2, (void*)&fidx,   (void*)&plane, (void*)&cplane};
     CAF_HIP_TRY(hipModuleLaunchKernel(r.fn, (unsigned)nwg, 1, 1, (unsigned)pl.wg, 1, 1, 0, st, args, nullptr));
     return CAF_OK;
@@ -879,8 +991,8 @@ int perdelay_jit_describe(int32_t n, const char* arch, const char* dump_path, st
         t += (p ? "," : "") + std::to_string(pl.rad[p]), s += (p ? "," : "") + std::to_string(pl.str[p]);
         o += (p ? " " : "") + brace_list(pl.ord[p], pl.np - 1);
     }
-    std::snprintf(buf, sizeof(buf), "n=%d q=%d radices=%s tpr=%d rpw=%d wg=%d strides=%s orders=%s img=%d lds_bytes=%d xreg=%d conflict_cycles=%ld base_cycles=%ld",
-                  n, pl.q, t.c_str(), pl.tpr, pl.rpw, pl.wg, s.c_str(), o.c_str(), pl.img, pl.rpw * pl.img * 8, pl.xreg, pl.conflict_cycles, pl.lds_ops);
+    std::snprintf(buf, sizeof(buf), "n=%d q=%d bluestein=%d radices=%s tpr=%d rpw=%d wg=%d strides=%s orders=%s img=%d lds_bytes=%d xreg=%d conflict_cycles=%ld base_cycles=%ld",
+                  n, pl.q, pl.blu ? pl.n : 0, t.c_str(), pl.tpr, pl.rpw, pl.wg, s.c_str(), o.c_str(), pl.img, pl.rpw * pl.img * 8, pl.xreg, pl.conflict_cycles, pl.lds_ops);
     *text = buf;
     if (arch && *arch) {
         std::vector<char> code;

@@ -33,6 +33,17 @@
 // from the NT-entry table `twq`), the per-point twiddle W_NT^{j tq} is one table entry per butterfly times powers of that step.
 // Nothing goes through HBM between the product and the maximum, which is what the rows path (product rows -> rocFFT -> argmax)
 // does for these lengths.
+//
+// Lengths with a prime factor above 23 (PDJ_BLU = 1: the cutout has PDJ_NX samples, the image PDJ_N = M >= 2 NX - 1): Bluestein.
+//   Z[k] = c[k] sum_n (u[n] c[n]) conj(c[k - n]),   c[i] = e^{+j pi i^2 / NX}
+// is a circular convolution of length M: forward transform of a = u c (zero beyond NX) -- the passes above --, product with the
+// transformed chirp `bhat` (host, float64, 1 / M folded in), transform back.  The way back needs no reordering and no new
+// butterflies: the forward flow graph is F = Perm . Pass_{P-1} ... Pass_0 with Pass_p = (twiddles) . (butterflies); F is symmetric,
+// so F = Pass_0^T ... Pass_{P-1}^T Perm^T, and Pass_p^T = (butterflies) . (twiddles) on the same positions.  Applied to
+// d = conj(A bhat), which already sits where Perm^T puts it, the transposed passes P-1 ... 0 leave conj(convolution) in natural
+// order: the last forward pass and the first transposed one share their registers (the last pass has no twiddles), the middle
+// ones read, multiply by the SAME twiddles, transform and write back, and the transposed pass 0 ends in registers holding
+// samples b + t NB0 in ascending order.  |Z[k]|^2 = |conv[k]|^2 -- the outer chirp only matters to the complex plane.
 #ifdef __HIPCC_RTC__
 typedef int int32_t;
 typedef unsigned int uint32_t;
@@ -49,8 +60,16 @@ namespace pdj {
 #define PDJ_Q 1
 #endif
 constexpr int P = PDJ_NP, N = PDJ_N, TPR = PDJ_TPR, RPW = PDJ_RPW, WG = PDJ_WG, IMG = PDJ_IMG;
-constexpr int Q = PDJ_Q, NT = N * Q;  // NT: the cutout's length; N: the transform the image holds
-static_assert(Q == 1 || !PDJ_XREG, "the cutout stays in registers only in the one-image form");
+#ifndef PDJ_BLU
+#define PDJ_BLU 0
+#endif
+#ifndef PDJ_NX
+#define PDJ_NX (PDJ_N * PDJ_Q)
+#endif
+constexpr int Q = PDJ_Q, NT = PDJ_NX;  // NT: the cutout's length; N: the transform the image holds
+constexpr bool BLU = PDJ_BLU != 0;
+static_assert((Q == 1 && !BLU) || !PDJ_XREG, "the cutout stays in registers only in the one-image form");
+static_assert(BLU ? (Q == 1 && N >= 2 * NT - 1) : NT == N * Q, "lengths");
 // (as constexpr functions over local tables: namespace-scope arrays would be host variables to the device pass)
 constexpr int cRAD(int d) {
     constexpr int T[5] = {PDJ_R0, PDJ_R1, PDJ_R2, PDJ_R3, PDJ_R4};
@@ -194,12 +213,36 @@ __device__ __forceinline__ void middle_pass(float2* __restrict__ buf, const floa
     row_sync();
 }
 
+// the transposed middle pass (Bluestein's way back): image -> registers -> the same twiddles, butterfly -> the same positions
+template <int p>
+__device__ __forceinline__ void middle_pass_t(float2* __restrict__ buf, const float2* __restrict__ tw, int l, bool active, int row_it) {
+    constexpr int R = cRAD(p), CNT = cCNT(p), NB = cNB(p);
+#pragma unroll
+    for (int c = 0; c < CNT; ++c) {
+        const int b = l + c * TPR;
+        const bool ok = active && (cFULL(p) || b < NB);
+        if (ok) {
+            int base, m;
+            decode<p>(b, base, m);
+            const float2 w1 = gld(tw, (uint32_t)(m * cK(p)));
+            float2 v[R];
+#pragma unroll
+            for (int t = 0; t < R; ++t) v[t] = lds_ld(&buf[base + t * cSTR(p)]);
+            twiddle<p>(v, w1, row_it);
+            mr_idft<R>(v);
+#pragma unroll
+            for (int t = 0; t < R; ++t) lds_st(&buf[base + t * cSTR(p)], v[t]);
+        }
+    }
+    row_sync();
+}
+
 }  // namespace pdj
 }  // namespace caf
 
 extern "C" __global__ __launch_bounds__(PDJ_WG, 4) void k_pdj(const float2* __restrict__ x, const float2* __restrict__ y, int64_t ylen,
                                                               const float2* __restrict__ tw, const float2* __restrict__ twq,
-                                                              const double* __restrict__ prefix,
+                                                              const float2* __restrict__ bhat, const double* __restrict__ prefix,
                                                               const double* __restrict__ xnorm, int64_t start, int64_t step,
                                                               int64_t num, int32_t rows_per_wg, int32_t zero_oor,
                                                               float* __restrict__ qf2, uint32_t* __restrict__ fidx,
@@ -272,7 +315,31 @@ extern "C" __global__ __launch_bounds__(PDJ_WG, 4) void k_pdj(const float2* __re
                 const bool ok = active && (cFULL(0) || b < NB0);
                 const int bb = cFULL(0) ? b : min(b, NB0 - 1);
                 float2 v[R0];
-                if constexpr (Q == 1) {
+                if constexpr (BLU) {
+                    // a[n] = conj(x y) c[n] for n < NT, zero beyond (clamped loads, the zero selected afterwards)
+                    float2 xa[R0], yq[R0];
+#pragma unroll
+                    for (int t = 0; t < R0; ++t) xa[t] = gld(x, (uint32_t)min(bb + t * NB0, NT - 1));
+                    if (inside) {
+#pragma unroll
+                        for (int t = 0; t < R0; ++t) yq[t] = gld(yrow, (uint32_t)min(bb + t * NB0, NT - 1));
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < R0; ++t) {
+                            const int64_t g = s + min(bb + t * NB0, NT - 1);
+                            yq[t] = (!zero && g >= 0 && g < ylen) ? y[g] : make_float2(0.f, 0.f);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int t = 0; t < R0; ++t) v[t] = make_float2(xa[t].x * yq[t].x - xa[t].y * yq[t].y, -(xa[t].x * yq[t].y + xa[t].y * yq[t].x));
+                    // (the chirp in a batch of its own: three operands of R0 points in flight at once spill)
+#pragma unroll
+                    for (int t = 0; t < R0; ++t) xa[t] = gld(twq, (uint32_t)min(bb + t * NB0, NT - 1));
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int t = 0; t < R0; ++t) v[t] = (bb + t * NB0 < NT) ? cmul(v[t], xa[t]) : make_float2(0.f, 0.f);
+                } else if constexpr (Q == 1) {
                     // every load of the butterfly goes out before the first product is formed (left to itself the scheduler pairs
                     // each cutout / window load with its product and waits for memory sixteen times per butterfly)
                     float2 xa[R0], yq[R0];
@@ -367,6 +434,87 @@ extern "C" __global__ __launch_bounds__(PDJ_WG, 4) void k_pdj(const float2* __re
         if constexpr (P > 2) middle_pass<1>(buf, tw, l, active, pass_it);
         if constexpr (P > 3) middle_pass<2>(buf, tw, l, active, pass_it);
         if constexpr (P > 4) middle_pass<3>(buf, tw, l, active, pass_it);
+        if constexpr (BLU) {
+            // ---- last forward pass, product with the transformed chirp, conjugate, first transposed pass: in registers
+#pragma unroll
+            for (int c = 0; c < CNTL; ++c) {
+                const int b = l + c * TPR;
+                const bool ok = active && (cFULL(P - 1) || b < NBL);
+                if (ok) {
+                    int base, m;
+                    decode<P - 1>(b, base, m);
+                    float2 v[RL];
+#pragma unroll
+                    for (int t = 0; t < RL; ++t) v[t] = lds_ld(&buf[base + t * cSTR(P - 1)]);
+                    mr_idft<RL>(v);
+#pragma unroll
+                    for (int t = 0; t < RL; ++t) {
+                        const float2 z = cmul(v[t], gld(bhat, (uint32_t)(b + t * NBL)));
+                        v[t] = make_float2(z.x, -z.y);
+                    }
+                    mr_idft<RL>(v);
+#pragma unroll
+                    for (int t = 0; t < RL; ++t) lds_st(&buf[base + t * cSTR(P - 1)], v[t]);
+                }
+            }
+            row_sync();
+            if constexpr (P > 4) middle_pass_t<3>(buf, tw, l, active, pass_it);
+            if constexpr (P > 3) middle_pass_t<2>(buf, tw, l, active, pass_it);
+            if constexpr (P > 2) middle_pass_t<1>(buf, tw, l, active, pass_it);
+            // ---- transposed pass 0: register (b, t) is conj(convolution)[b + t NB0]; the first NT samples are the row's bins
+            float2 v[CNT0][R0];
+            bool okb[CNT0];
+#pragma unroll
+            for (int c = 0; c < CNT0; ++c) {
+                const int b = l + c * TPR;
+                okb[c] = active && (cFULL(0) || b < NB0);
+                const int bb = cFULL(0) ? b : min(b, NB0 - 1);
+                int base, m;
+                decode<0>(bb, base, m);
+#pragma unroll
+                for (int t = 0; t < R0; ++t) v[c][t] = lds_ld(&buf[base + t * cSTR(0)]);
+                twiddle<0>(v[c], gld(tw, (uint32_t)m), pass_it);
+                mr_idft<R0>(v[c]);
+            }
+            const float inv = *(volatile float*)&s_inv[rl];
+#pragma unroll
+            for (int t = 0; t < R0; ++t)
+#pragma unroll
+                for (int c = 0; c < CNT0; ++c) {
+                    const int k = l + c * TPR + t * NB0;
+                    okb[c] = okb[c] && k < NT;  // (k grows with t: once beyond the cutout's bins, always)
+                    const float zr = v[c][t].x * inv, zi = v[c][t].y * inv;
+                    v[c][t] = make_float2(zr, zi);
+                    const float val = __builtin_fmaf(zr, zr, zi * zi);
+                    const bool up = okb[c] && val > bv;  // (ascending index: the strict comparison keeps the first maximum)
+                    bv = up ? val : bv;
+                    bi = up ? (uint32_t)k : bi;
+                }
+            // (okb now says: butterfly c exists and its LAST bin is inside -- the stores test every bin)
+            if (plane && live) {
+                float* prow = plane + row * NT;
+#pragma unroll
+                for (int t = 0; t < R0; ++t)
+#pragma unroll
+                    for (int c = 0; c < CNT0; ++c) {
+                        const int k = l + c * TPR + t * NB0;
+                        if ((cFULL(0) || l + c * TPR < NB0) && k < NT) prow[k] = __builtin_fmaf(v[c][t].x, v[c][t].x, v[c][t].y * v[c][t].y);
+                    }
+            }
+            if (cplane && live) {
+                float2* crow = cplane + row * NT;
+#pragma unroll
+                for (int t = 0; t < R0; ++t)
+#pragma unroll
+                    for (int c = 0; c < CNT0; ++c) {
+                        const int k = l + c * TPR + t * NB0;
+                        if ((cFULL(0) || l + c * TPR < NB0) && k < NT) {
+                            const float2 ck = gld(twq, (uint32_t)k);  // conj(Z[k]) = conj(c[k]) conj(conv[k])
+                            crow[k] = make_float2(v[c][t].x * ck.x + v[c][t].y * ck.y, v[c][t].y * ck.x - v[c][t].x * ck.y);
+                        }
+                    }
+            }
+        } else
         // ---- last pass: butterflies in natural order of (k_0, k_1, ...): register (b, t) is spectrum index b + t NBL of the
         // image's transform, i.e. bin tq + Q (b + t NBL) of the row
         {

@@ -201,7 +201,8 @@ def test_perdelay_random_cutout_lengths(seed):
     """caf_xcorr_perdelay at random cutout lengths whose prime factors are at most 23 -- whatever kernel the library routes them to
     (powers of two / ten, or the kernel it compiles for the length at run time with the plan its model picks) -- against the
     oracle's fastXcorr(freqsearch=True): maxima to 2e-5, bins exact where the oracle's top-2 margin is clear, planes, strides in
-    both directions, the (0, 0) rule for windows that leave rx.  Every other seed adds a length of 16385 ... 120000 samples."""
+    both directions, the (0, 0) rule for windows that leave rx.  Every other seed adds a length of 16385 ... 120000 samples, every
+    seed an arbitrary length up to 10000 (whatever its factors)."""
     import ctypes as ct
 
     from pydsproutines_amd import _lib, asarray
@@ -213,6 +214,7 @@ def test_perdelay_random_cutout_lengths(seed):
     lens = [int(rng.choice(_LENGTHS)), int(rng.choice([v for v in _LENGTHS if v <= 600]))]
     if seed % 2 == 0:
         lens.append(int(rng.choice(_LONG_LENGTHS)))
+    lens.append(int(rng.integers(16, 10001)))  # any length at all: mostly a prime factor above 23 (Bluestein in LDS up to 10000 samples)
     for n in lens:
         num = int(rng.integers(3, 12 if n > 16384 else (40 if n > 4000 else 120)))
         step = int(rng.choice([1, 1, 2, -1, 5]))

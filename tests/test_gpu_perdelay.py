@@ -228,6 +228,28 @@ def test_jit_kernel_split_form(n, q, monkeypatch, capfd):
         assert " residues=1 " not in err
 
 
+# cutout lengths with a prime factor above 23 -- most lengths a burst happens to have -- as Bluestein's chirp transform in the same
+# LDS image (caf_perdelay_jit.h, PDJ_BLU): forward transform of the chirped products, product with the transformed chirp, the
+# transposed passes back.  Natural lengths (primes, 2 x prime, the longest that fits), smooth lengths forced that way, forced
+# convolution lengths with radices 3 / 5 / 7 in them.
+@pytest.mark.parametrize("n,m", [(1450, None), (1021, None), (2047, None), (4099, None), (9973, None), (58, None), (37, None), (6001, None),
+                                 (211, None), (1200, 0), (4096, 0), (100, 200), (1450, 2916), (1000, 2401), (997, 2000), (3001, 6075)])
+def test_jit_kernel_bluestein(n, m, monkeypatch, capfd):
+    monkeypatch.setenv("CAF_JIT_DEBUG", "1")
+    monkeypatch.delenv("CAF_JIT", raising=False)
+    if m is not None:
+        monkeypatch.setenv("CAF_PDJ_BLUESTEIN", "1")
+        monkeypatch.setenv("CAF_JIT_ALL", "1")
+    if m:
+        monkeypatch.setenv("CAF_PDJ_BLU_M", str(m))
+    _composite_cutout_checks(n)
+    err = capfd.readouterr().err
+    assert "[caf jit] n=%d plan=" % n in err, err
+    assert " bluestein=0 " not in err
+    if m:
+        assert " bluestein=%d " % m in err
+
+
 def test_jit_and_prebuilt_kernels_agree(monkeypatch):
     """The two mixed-radix kernels (run-time compiled / plan-driven) on the same rows: same maxima to float32 rounding, same bins."""
     rng = np.random.default_rng(12)
