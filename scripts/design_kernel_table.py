@@ -25,9 +25,11 @@ ROWS = [  # (workload, kernel prefix of the manifest entry, label)
     ("cp_fastxcorr_1e7", "k_sliding_multiply", "`k_sliding_multiply` (128 rows × 10⁷)"),
     ("perdelay_decimal_1000", "k_perdelay_r10", "`k_perdelay_r10<3>` (1000 × 10⁶, radix 10)"),
     ("perdelay_mixed_1200", "k_pdj", "`k_pdj` (1200 × 10⁵, compiled for the length: radices 5·16·15)"),
-    ("perdelay_mixed_5000", "k_pdj", "`k_pdj` (5000 × 10⁵: radices 5·10·5·20)"),
-    ("perdelay_mixed_1400", "k_pdj", "`k_pdj` (1400 × 10⁵: radices 5·14·20)"),
-    ("perdelay_rows_1450", "k_sliding_multiply", "`k_sliding_multiply` (10⁵ rows × 1450)"),
+    ("perdelay_mixed_5000", "k_pdj", "`k_pdj` (5000 × 10⁵: radices 10·25·20)"),
+    ("perdelay_mixed_1400", "k_pdj", "`k_pdj` (1400 × 10⁵: radices 4·25·14)"),
+    ("perdelay_bluestein_1450", "k_pdj", "`k_pdj` (1450 × 10⁵: Bluestein, 3072-point convolution)"),
+    ("perdelay_split_65536", "k_pdj", "`k_pdj` (65536 × 2·10⁴: 4 residues × 16384 points; bytes = L2 reads)"),
+    ("perdelay_rows_10007", "k_sliding_multiply", "`k_sliding_multiply` (2·10⁴ rows × 10007)"),
     ("cp_fastxcorr_1e7", "k_rows_argmax", "`k_rows_argmax` (chunked, 128 rows × 10⁷)"),
     ("kernels_misc", "k_magnsq", "`k_magnsq`"),
     ("kernels_misc", "k_iq16_to_c64", "`k_iq16_to_c64`"),

@@ -272,11 +272,27 @@ def w_perdelay_fused_256():
     return [("k_perdelay_fused", "N=256 x 1e6 delays (same accounting)", _perdelay_bytes(n, num), num * 5.0 * n * np.log2(n), 2)]
 
 
-def w_perdelay_rows_1450():
-    """A cutout length with a prime factor above 23 (1450 = 2 5^2 29: no in-LDS kernel): product rows -> rocFFT rows -> argmax."""
-    n, num = perdelay(1450, 100_000, "rows")
-    return [("k_sliding_multiply", "normalised product rows, N=1450 x 1e5 (8 B written per element)", num * n * 8.0, 0.0, 2),
+def w_perdelay_rows_10007():
+    """A prime cutout length beyond what Bluestein's convolution fits in LDS (10007 > 10000): product rows -> rocFFT rows -> argmax."""
+    n, num = perdelay(10007, 20_000, "rows")
+    return [("k_sliding_multiply", "normalised product rows, N=10007 x 2e4 (8 B written per element)", num * n * 8.0, 0.0, 2),
             ("k_rows_argmax", "|.|^2 + first argmax per row (8 B read per element)", num * n * 8.0, 0.0, 2)]
+
+
+def w_perdelay_bluestein_1450():
+    """1450 = 2 5^2 29: Bluestein's chirp transform in the LDS image (two 3072-point transforms per row; flops counted as the
+    cutout's own 5 N log2 N, as for every other length)."""
+    n, num = perdelay(1450, 100_000, "bluestein")
+    return [("k_pdj", "per-delay correlator for N=1450 (Bluestein, convolution length 3072), %d rows" % num, _perdelay_bytes(n, num),
+             num * 5.0 * n * np.log2(n), 2)]
+
+
+def w_perdelay_split_65536():
+    """65536-sample cutouts: four residues of a 16384-point transform per row; every residue re-reads cutout and window from the L2
+    (16 B per sample and residue = 4.2 MB per row, declared as bytes: the L2 -> CU delivery is what bounds this form)."""
+    n, num = perdelay(65536, 20_000, "split")
+    return [("k_pdj", "per-delay correlator for N=65536 (4 residues x 16384 points), %d rows; bytes = L2 reads of the products' operands" % num,
+             num * 4.0 * n * 16.0, num * 5.0 * n * np.log2(n), 2)]
 
 
 def w_perdelay_decimal_1000():
