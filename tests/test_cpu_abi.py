@@ -142,7 +142,11 @@ def test_perdelay_jit_planner_and_compile_without_a_gpu():
         assert int(np.prod(rad)) == n and 2 <= len(rad) <= 5
         assert int(d["lds_bytes"]) <= 160 * 1024 - 64
         assert int(d["conflict_cycles"]) <= 0.6 * int(d["base_cycles"]), d
-    rc, d = describe(97)  # (a prime: no plan)
+    rc, d = describe(97)  # (a prime: Bluestein's chirp transform on a 7-smooth image of at least 2 n - 1 points)
+    assert rc == 0 and int(d["bluestein"]) >= 2 * 97 - 1 and int(np.prod([int(r) for r in d["radices"].split(",")])) == int(d["bluestein"])
+    rc, d = describe(65536)  # (longer than one LDS image: four residues of a 16384-point transform per row)
+    assert rc == 0 and int(d["q"]) == 4 and int(np.prod([int(r) for r in d["radices"].split(",")])) == 16384
+    rc, d = describe(10007)  # (a prime whose chirp transform does not fit the LDS: no plan, the rows path keeps it)
     assert rc == 0 and not d
     rc, d = describe(1200, b"gfx950")
     if rc == 0:
