@@ -126,13 +126,17 @@ typedef struct caf_plan_desc {
 /* Inverse-transform engine of the hypothesis plan.
  *   ROCFFT: spectral multiply kernel -> batched rocFFT inverse -> |.|^2 kernel (any block size);
  *   FUSED : one hand-written kernel does multiply + 16384-point inverse FFT in LDS + |.|^2, a second
- *           one transposes/normalises/argmaxes; needs template_len <= 8192, (bins mode) grid | 16384,
+ *           one transposes/normalises/argmaxes; needs template_len <= 8192, (bins mode) every
+ *           bins[f] * 16384 / grid a whole number (any grid that divides 16384; bin 0 on any grid),
  *           and cannot produce d_cqf.
  *   PERSISTENT: the two FUSED stages as ONE work-queue launch (one resident workgroup per CU): the
- *           HBM-bound transpose runs on some CUs while the others compute FFTs.  Same conditions and
- *           results as FUSED.  d_cqf: supported with 16384-point blocks as the ONLY output of a call
- *           (the FFT work items write the complex rows themselves).
- *   AUTO  : PERSISTENT when the FUSED conditions hold and log2_block is 0 or 14, else ROCFFT. */
+ *           HBM-bound transpose runs on some CUs while the others compute FFTs.  Same results as
+ *           FUSED up to 8192 samples; templates up to 16384 samples on 32768-point blocks, up to
+ *           32768 on 65536-point blocks, up to 262144 on 65536-point blocks with the template cut into
+ *           partitions of 32768 samples (bins mode: bins[f] * block / grid whole and even).  d_cqf:
+ *           supported with 16384-point blocks as the ONLY output of a call (the FFT work items write
+ *           the complex rows themselves).
+ *   AUTO  : PERSISTENT when its conditions hold and log2_block is 0 or the engine's own, else ROCFFT. */
 #define CAF_ENGINE_AUTO 0
 #define CAF_ENGINE_ROCFFT 1
 #define CAF_ENGINE_FUSED 2

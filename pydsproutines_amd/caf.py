@@ -33,7 +33,7 @@ class CAFPlan:
     Parameters
     ----------
     templates : complex64 (T, N) or (N,)  -- NOT conjugated unless autoConj=False
-    bins, grid : on-grid hypotheses nu_f = bins[f]/grid (grid must divide the block size), or
+    bins, grid : on-grid hypotheses nu_f = bins[f]/grid (every bins[f] * block / grid must be whole), or
     freqs_norm : arbitrary hypotheses in cycles/sample (f / fs)
     group_starts, group_lens : support of a composite template (GroupXcorr semantics)
     max_rx_len : largest rx length that will be passed to run()

@@ -669,15 +669,16 @@ __device__ __forceinline__ void fused_item(float2* __restrict__ s_d, const float
 // hypothesis boundary.  (Round 3's schedule -- O's inputs in one batch before pass 3 of E, the next E's inside pass 4 of O --
 // left the second batch half a pass to arrive: N = 16384 at the C2 shape 22.2 -> 20.3 ms with the quotas.)
 template <int N_> struct caf_ic { static constexpr int value = N_; };
-template <int MODE, int NVH, bool FOLD, int R>
+template <int MODE, int NVH, bool FOLD, int R, bool PART = false>
 __device__ __forceinline__ void fused_item2q(float2* __restrict__ s_d, const float2* __restrict__ s_tw2,
                                              const float2* __restrict__ s_tw3, const float2* __restrict__ xb,  // FOLD: [blocks][2][16384] pairs; else [blocks][2][16384]
-                                             const float2* __restrict__ hc,       // rows of the same shape, per template or per hypothesis
+                                             const float2* __restrict__ hc,       // rows of the same shape, per template or per hypothesis (PART: npart consecutive rows each)
                                              const int32_t* __restrict__ shifts, const float2* __restrict__ tw1,
                                              int32_t table_mode, int32_t nfreq, int32_t nhyp, int blk, int h0, int h1,
-                                             int32_t tiles_per_blk, float* __restrict__ vt) {
+                                             int32_t tiles_per_blk, float* __restrict__ vt, int32_t npart = 1) {
     static_assert(FOLD || R == 0, "the output residue exists in the folded form only");
     static_assert(!FOLD || NVH == 0, "folded form: only the lower half of each residue's transform holds valid delays");
+    static_assert(!PART || FOLD, "partitioned templates ride on the folded form");
     constexpr int ROW = FOLD ? 4 * FB : 2 * FB;  // float2 per row (block spectrum, template row)
     using pt_t = typename std::conditional<FOLD, float4, float2>::type;
     const int tid = threadIdx.x;
@@ -704,13 +705,14 @@ __device__ __forceinline__ void fused_item2q(float2* __restrict__ s_d, const flo
     const float* hrow_n;  // the next hypothesis' row (its E half's inputs)
     uint32_t hb_n;
     auto row_of = [&](int h, const float*& hrow, uint32_t& hb) {
+        const int rows_per = PART ? npart : 1;
         if (table_mode) {
-            hrow = (const float*)(hc + (int64_t)h * ROW);
+            hrow = (const float*)(hc + (int64_t)h * rows_per * ROW);
             hb = (uint32_t)tid;
         } else {
             const int t = h / nfreq;
             const int32_t sh = *((const CAF_AS4 int32_t*)shifts + (h - t * nfreq)) >> 1;
-            hrow = (const float*)(hc + (int64_t)t * ROW);
+            hrow = (const float*)(hc + (int64_t)t * rows_per * ROW);
             hb = fp_hbase(m2, sh);
         }
     };
@@ -732,8 +734,11 @@ __device__ __forceinline__ void fused_item2q(float2* __restrict__ s_d, const flo
         }
     };
     // ... folded into pr[A0 ..]: FOLD: G = (X1 H1 + X2 H2) or (X1 H1 - X2 H2) W_32^a; else X H
-    auto fold = [&](float2* pr, const pt_t* bx, const pt_t* bh, uint32_t hb, auto a0_, auto np_) __attribute__((always_inline)) {
+    // (PART: the sum over the template's partitions is formed before the twiddle W_32^a, which then waits for pass 1; ACC: the
+    //  products are added to what the partitions fetched ahead of them have left in pr)
+    auto fold = [&](float2* pr, const pt_t* bx, const pt_t* bh, uint32_t hb, auto a0_, auto np_, auto acc_) __attribute__((always_inline)) {
         constexpr int A0 = decltype(a0_)::value, NP = decltype(np_)::value;
+        constexpr bool ACC = decltype(acc_)::value != 0;
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
             const int a = A0 + k;
@@ -744,7 +749,10 @@ __device__ __forceinline__ void fused_item2q(float2* __restrict__ s_d, const flo
                 const float2 h2 = make_float2(sw ? bh[k].x : bh[k].z, sw ? bh[k].y : bh[k].w);
                 const float2 z1 = cmul(make_float2(bx[k].x, bx[k].y), h1);
                 const float2 z2 = cmul(make_float2(bx[k].z, bx[k].w), h2);
-                if (R == 0)
+                if constexpr (PART) {
+                    const float2 dz = R == 0 ? cadd(z1, z2) : csub(z1, z2);
+                    pr[a] = ACC ? cadd(pr[a], dz) : dz;
+                } else if (R == 0)
                     pr[a] = cadd(z1, z2);
                 else if (a == 0)
                     pr[a] = csub(z1, z2);
@@ -760,18 +768,27 @@ __device__ __forceinline__ void fused_item2q(float2* __restrict__ s_d, const flo
     // points fetched per pass: in the E half first the O half's (QEO), then the next E half's (QEN); in the O half QON
     // (measured at the C2 shape, profiles/r04/ab_quota_schedules.log: fetching earlier -- 16 points in the first pass -- or
     //  later -- batches in the O half's last pass -- is slower in both forms)
-    constexpr int QEO[4] = {8, FOLD ? 6 : 8, FOLD ? 2 : 0, 0};
-    constexpr int QEN[4] = {0, 0, FOLD ? 4 : 6, FOLD ? 4 : 2};
-    constexpr int QON[4] = {4, 2, 2, 0};
+    // (PART: the next E half's points wait for the O half, so that the partitions fetched in front of the O half find registers)
+#ifndef PQ_EO
+#define PQ_EO 4, 4, 4, 4
+#define PQ_EN 0, 0, 0, 0
+#define PQ_ON 4, 4, 4, 4
+#define PQ_PBE 8
+#define PQ_PBO 4
+#endif
+    constexpr int QEO_P[4] = {PQ_EO}, QEN_P[4] = {PQ_EN}, QON_P[4] = {PQ_ON};
+    constexpr int QEO[4] = {PART ? QEO_P[0] : 8, PART ? QEO_P[1] : FOLD ? 6 : 8, PART ? QEO_P[2] : FOLD ? 2 : 0, PART ? QEO_P[3] : 0};
+    constexpr int QEN[4] = {PART ? QEN_P[0] : 0, PART ? QEN_P[1] : 0, PART ? QEN_P[2] : FOLD ? 4 : 6, PART ? QEN_P[3] : FOLD ? 4 : 2};
+    constexpr int QON[4] = {PART ? QON_P[0] : 4, PART ? QON_P[1] : 2, PART ? QON_P[2] : 2, PART ? QON_P[3] : 0};
     static_assert(QEO[0] + QEO[1] + QEO[2] + QEO[3] == 16 && QEN[0] + QEN[1] + QEN[2] + QEN[3] + QON[0] + QON[1] + QON[2] + QON[3] == 16, "quotas");
     float2 pro[16], prn[16];  // folded inputs: of the O half of the hypothesis in progress / of the next E half
     row_of(h0, hrow_o, hb_o);
     {
         pt_t bx[8], bh[8];
         issue(bx, bh, hrow_o, hb_o, caf_ic<0>{}, caf_ic<0>{}, caf_ic<8>{}, 0u);
-        fold(prn, bx, bh, hb_o, caf_ic<0>{}, caf_ic<8>{});
+        fold(prn, bx, bh, hb_o, caf_ic<0>{}, caf_ic<8>{}, caf_ic<0>{});
         issue(bx, bh, hrow_o, hb_o, caf_ic<0>{}, caf_ic<8>{}, caf_ic<8>{}, 0u);
-        fold(prn, bx, bh, hb_o, caf_ic<8>{}, caf_ic<8>{});
+        fold(prn, bx, bh, hb_o, caf_ic<8>{}, caf_ic<8>{}, caf_ic<0>{});
     }
     float2 e[16];  // E's outputs (register 4 i + n4 <-> n3 = q + 4 i, n4)
     uint32_t hoff = 0;
@@ -794,22 +811,71 @@ __device__ __forceinline__ void fused_item2q(float2* __restrict__ s_d, const flo
         if constexpr (c == 0) {
             constexpr int O0 = (PS > 0 ? QEO[0] : 0) + (PS > 1 ? QEO[1] : 0) + (PS > 2 ? QEO[2] : 0);
             constexpr int N0 = (PS > 0 ? QEN[0] : 0) + (PS > 1 ? QEN[1] : 0) + (PS > 2 ? QEN[2] : 0);
-            fold(pro, bx, bh, hb_o, caf_ic<O0>{}, caf_ic<QEO[PS]>{});
-            fold(prn, bx + QEO[PS], bh + QEO[PS], hb_n, caf_ic<N0>{}, caf_ic<QEN[PS]>{});
+            fold(pro, bx, bh, hb_o, caf_ic<O0>{}, caf_ic<QEO[PS]>{}, caf_ic<0>{});
+            fold(prn, bx + QEO[PS], bh + QEO[PS], hb_n, caf_ic<N0>{}, caf_ic<QEN[PS]>{}, caf_ic<0>{});
         } else {
             constexpr int N0 = QEN[0] + QEN[1] + QEN[2] + QEN[3] + (PS > 0 ? QON[0] : 0) + (PS > 1 ? QON[1] : 0) + (PS > 2 ? QON[2] : 0);
-            fold(prn, bx, bh, hb_n, caf_ic<N0>{}, caf_ic<QON[PS]>{});
+            fold(prn, bx, bh, hb_n, caf_ic<N0>{}, caf_ic<QON[PS]>{}, caf_ic<0>{});
+        }
+    };
+    // PART: partitions 1 .. npart - 1 of the template (Z = sum_p X[blk + p] . Hc_p: a template of up to npart * 32768 samples as
+    // npart spectra of 32768 samples each against the block spectra of the blocks that follow), added to the inputs of the
+    // sub-transform about to start, which hold partition 0.  Fetched here, latency exposed, in batches of what the registers
+    // leave: in front of the E half (e[] dead, pro empty) 8 points, in front of the O half 2.  (The role moves its inputs at
+    // the rate the L2 delivers them to a CU either way -- ~45 GB/s, 1 MB per hypothesis and partition: a partition costs what
+    // the whole one-partition hypothesis costs, however its loads are scheduled.)
+    auto parts_ahead = [&](auto c_) __attribute__((always_inline)) {
+        constexpr int cc = decltype(c_)::value;
+        constexpr int PB = cc == 0 ? PQ_PBE : PQ_PBO;
+        float2* pr = cc == 0 ? prn : pro;
+        for (int p = 1; p < npart; ++p) {
+            const float* xq = xp + (int64_t)p * ROW * 2;
+            const float* hq = hrow_o + (int64_t)p * ROW * 2;
+#pragma unroll
+            for (int a0 = 0; a0 < 16; a0 += PB) {
+                float4 bx[PB], bh[PB];
+                uint32_t lq = 0;  // (an opaque zero: the batch's loads stay behind the fold of the batch before)
+                asm volatile("" : "+v"(lq));
+#pragma unroll
+                for (int k = 0; k < PB; ++k) {
+                    const uint32_t a = (uint32_t)(a0 + k);
+                    bx[k] = gld4(xq, ((uint32_t)cc * 16384u + 1024u * a + (uint32_t)tid + lq) << 4);
+                    bh[k] = gld4(hq, ((uint32_t)cc * 16384u + ((1024u * a + hb_o) & 16383u) + lq) << 4);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < PB; ++k) {
+                    const int a = a0 + k;
+                    const bool sw = ((1024u * (uint32_t)a + hb_o) & 16384u) != 0;
+                    const float2 h1 = make_float2(sw ? bh[k].z : bh[k].x, sw ? bh[k].w : bh[k].y);
+                    const float2 h2 = make_float2(sw ? bh[k].x : bh[k].z, sw ? bh[k].y : bh[k].w);
+                    const float2 z1 = cmul(make_float2(bx[k].x, bx[k].y), h1);
+                    const float2 z2 = cmul(make_float2(bx[k].z, bx[k].w), h2);
+                    pr[a] = cadd(pr[a], R == 0 ? cadd(z1, z2) : csub(z1, z2));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     };
     auto sub = [&](auto c_) __attribute__((always_inline)) {
         constexpr int c = decltype(c_)::value;
         uint32_t lz = 0;
         asm volatile("" : "+v"(lz));
+        if constexpr (PART) parts_ahead(c_);
         // ---- pass 1: DFT16 over a of the (folded) products, twiddle (r = 1: the recurrence starts at the input base), write ----
         {
             float2 v1[16];
 #pragma unroll
-            for (int a = 0; a < 16; ++a) v1[a] = c == 0 ? prn[a] : pro[a];
+            for (int a = 0; a < 16; ++a) {
+                v1[a] = c == 0 ? prn[a] : pro[a];
+                if constexpr (PART && R != 0) {  // the fold's twiddle W_32^a, after the sum over the partitions
+                    constexpr double TWO_PI = 6.283185307179586476925;
+                    if (a == 8)
+                        v1[a] = mulj(v1[a]);
+                    else if (a != 0)
+                        v1[a] = cmul(v1[a], make_float2((float)__builtin_cos(TWO_PI * a / 32.0), (float)__builtin_sin(TWO_PI * a / 32.0)));
+                }
+            }
             pt_t bx[8], bh[8];
             batch_issue(bx, bh, c_, caf_ic<0>{}, lz);
             idft16(v1);
@@ -1786,8 +1852,9 @@ __device__ __attribute__((noinline)) void persistent_fft_item2(lds_float2* s_d, 
 }
 
 // FFT role for 65536-point blocks (templates of 16385 .. 32768 samples; fused_item2q<FOLD>): work item = (block, hypothesis group, output residue r), group
-// number = 2 * (hypothesis group) + r, same publish sequence
-template <int R>
+// number = 2 * (hypothesis group) + r, same publish sequence.  PART: templates of 32769 .. npart * 32768 samples as npart partitions
+// (template-spectrum rows [spectrum][npart], block spectra of the npart blocks from the item's own on)
+template <int R, bool PART>
 __device__ __attribute__((noinline)) void persistent_fft_item2f(lds_float2* s_d, const lds_float2* s_tw2, const lds_float2* s_tw3,
                                                                 const PersistParams* pp_in, int item_in) {
     const PersistParams* pp = uniform_ptr(pp_in);
@@ -1798,8 +1865,8 @@ __device__ __attribute__((noinline)) void persistent_fft_item2f(lds_float2* s_d,
     const int grp = (item - blk * ngroups) >> 1;
     const int h0 = grp * hyp_per_wg;
     const int h1 = min(h0 + hyp_per_wg, nhyp);
-    fused_item2q<1, 0, true, R>((float2*)s_d, (const float2*)s_tw2, (const float2*)s_tw3, P->xb, P->hc, P->shifts, P->tw1, P->table_mode,
-                                P->nfreq, nhyp, blk, h0, h1, P->tiles_per_blk, P->vt);
+    fused_item2q<1, 0, true, R, PART>((float2*)s_d, (const float2*)s_tw2, (const float2*)s_tw3, P->xb, P->hc, P->shifts, P->tw1, P->table_mode,
+                                      P->nfreq, nhyp, blk, h0, h1, P->tiles_per_blk, P->vt, PART ? P->npart : 1);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (threadIdx.x == 0)
@@ -1931,10 +1998,16 @@ __global__ __launch_bounds__(1024) void k_caf_persistent(const PersistParams* __
         }
         if (kind == 1) {
             if (__builtin_amdgcn_readfirstlane(params_of(pp)->block_log2) == 16) {
-                if ((item - (item / params_of(pp)->ngroups) * params_of(pp)->ngroups) & 1)
-                    persistent_fft_item2f<1>((lds_float2*)s_d, (const lds_float2*)s_tw2, (const lds_float2*)s_tw3, pp, item);
+                const bool odd_r = ((item - (item / params_of(pp)->ngroups) * params_of(pp)->ngroups) & 1) != 0;
+                if (__builtin_amdgcn_readfirstlane(params_of(pp)->npart) > 1) {
+                    if (odd_r)
+                        persistent_fft_item2f<1, true>((lds_float2*)s_d, (const lds_float2*)s_tw2, (const lds_float2*)s_tw3, pp, item);
+                    else
+                        persistent_fft_item2f<0, true>((lds_float2*)s_d, (const lds_float2*)s_tw2, (const lds_float2*)s_tw3, pp, item);
+                } else if (odd_r)
+                    persistent_fft_item2f<1, false>((lds_float2*)s_d, (const lds_float2*)s_tw2, (const lds_float2*)s_tw3, pp, item);
                 else
-                    persistent_fft_item2f<0>((lds_float2*)s_d, (const lds_float2*)s_tw2, (const lds_float2*)s_tw3, pp, item);
+                    persistent_fft_item2f<0, false>((lds_float2*)s_d, (const lds_float2*)s_tw2, (const lds_float2*)s_tw3, pp, item);
             } else if (__builtin_amdgcn_readfirstlane(params_of(pp)->block_log2) == 15) {
                 const int tpb2 = __builtin_amdgcn_readfirstlane(params_of(pp)->tiles_per_blk);  // tiles >= 256: upper half
                 if (tpb2 <= 256)

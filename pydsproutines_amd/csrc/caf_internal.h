@@ -97,7 +97,7 @@ void launch_gather_blocks(const float2* rx, int64_t rx_len, int64_t src0, int32_
                           float2* xb, hipStream_t st);
 void launch_conj_scale(float2* h, int64_t n, float scale, hipStream_t st);
 void launch_build_hyp_time(const float2* tm, const double* nu, int32_t n_tmpl, int32_t bsz, int32_t nfreq, int32_t ntmpl,
-                           int32_t conj_u, float2* hc, hipStream_t st);
+                           int32_t conj_u, float2* hc, hipStream_t st, int32_t npart = 1, int32_t plen = 0);
 void launch_spectral_mul(int mode, const float2* xb, const float2* hc, const int32_t* shifts, int32_t bsz,
                          int32_t pitch, int32_t nfreq, int32_t nhyp, int32_t hyp_per_wg, int32_t nblk, float2* pbuf,
                          hipStream_t st);
@@ -268,6 +268,8 @@ struct PersistParams {
                          // 16: 65536 points in the folded form: two chained halves per output residue r (fused_item2q<FOLD>:
                          // ngroups is then 2 x the hypothesis groups, group = 2 * hypothesis group + r)
     int32_t dstride;     // delay stride of a tile: 1; 2 with block_log2 == 16 (tile 256 r + u = the delays 2 (64 u + j) + r)
+    int32_t npart;       // block_log2 == 16: partitions of 32768 samples per template (templates of 32769 .. npart * 32768 samples:
+                         // hc holds npart consecutive rows per spectrum, xb the npart - 1 block spectra beyond the launch's last block)
     // tile items (same meaning as launch_transpose_norm_argmax)
     int32_t ntmpl, step, blk0;
     int32_t gpt;  // > 0: hypothesis groups are formed per template, gpt per template (group g of template t covers

@@ -605,14 +605,19 @@ void launch_gather_blocks(const float2* rx, int64_t rx_len, int64_t src0, int32_
 // spectrum table gets u_t[n] * exp(+j 2 pi nu_f n) for n < N and zeros up to B, u = tmpl or conj(tmpl).
 // The phase is reduced in cycles in float64 before the trig call (full accuracy for large nu * n), the product
 // is formed in float64 and rounded once -- what the host loop this replaces did, T*F*N sincos calls faster.
+// (npart > 1: row (t, f, q) holds the samples q * plen .. q * plen + plen - 1 of the modulated template at its start -- the
+//  partitions of a template longer than what one block correlates; the phase runs over the sample's place in the template)
 __global__ __launch_bounds__(256) void k_build_hyp_time(const float2* __restrict__ tm, const double* __restrict__ nu,
                                                         int32_t n_tmpl, int32_t bsz, int32_t nfreq, int32_t conj_u,
-                                                        float2* __restrict__ hc) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= bsz) return;
+                                                        float2* __restrict__ hc, int32_t npart, int32_t plen) {
+    const int nbx = (bsz + 255) / 256;
+    const int q = blockIdx.x / nbx;
+    const int m = (blockIdx.x - q * nbx) * 256 + threadIdx.x;  // place in the row
+    if (m >= bsz) return;
     const int f = blockIdx.y, t = blockIdx.z;
+    const int64_t n = (int64_t)q * plen + m;  // place in the template
     float2 o = make_float2(0.f, 0.f);
-    if (n < n_tmpl) {
+    if (m < plen && n < n_tmpl) {
         const float2 u = tm[(int64_t)t * n_tmpl + n];
         const double ur = u.x, ui = conj_u ? -(double)u.y : (double)u.y;
         double cyc = nu[f] * (double)n;
@@ -621,15 +626,19 @@ __global__ __launch_bounds__(256) void k_build_hyp_time(const float2* __restrict
         sincos(2.0 * M_PI * cyc, &s, &c);
         o = make_float2((float)(ur * c - ui * s), (float)(ur * s + ui * c));
     }
-    hc[((int64_t)t * nfreq + f) * bsz + n] = o;
+    hc[(((int64_t)t * nfreq + f) * npart + q) * bsz + m] = o;
 }
 
 void launch_build_hyp_time(const float2* tm, const double* nu, int32_t n_tmpl, int32_t bsz, int32_t nfreq, int32_t ntmpl,
-                           int32_t conj_u, float2* hc, hipStream_t st) {
+                           int32_t conj_u, float2* hc, hipStream_t st, int32_t npart, int32_t plen) {
+    if (npart <= 1) {
+        npart = 1;
+        plen = bsz;
+    }
     for (int f0 = 0; f0 < nfreq; f0 += 65535) {  // grid.y limit
         const int nf = std::min(65535, nfreq - f0);
-        hipLaunchKernelGGL(k_build_hyp_time, dim3((unsigned)((bsz + 255) / 256), (unsigned)nf, (unsigned)ntmpl), dim3(256),
-                           0, st, tm, nu + f0, n_tmpl, bsz, nfreq, conj_u, hc + (int64_t)f0 * bsz);
+        hipLaunchKernelGGL(k_build_hyp_time, dim3((unsigned)(npart * ((bsz + 255) / 256)), (unsigned)nf, (unsigned)ntmpl), dim3(256),
+                           0, st, tm, nu + f0, n_tmpl, bsz, nfreq, conj_u, hc + (int64_t)f0 * npart * bsz, npart, plen);
     }
 }
 

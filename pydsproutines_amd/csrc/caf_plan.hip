@@ -68,6 +68,7 @@ struct caf_plan_t {
     int T = 0, N = 0, F = 0, G = 0;
     int freq_mode = 0, mul_mode = 0;
     int B = 0, step = 0, pitch = 0, nb = 0, tiles_per_blk = 0, hyp_per_wg = 16, fwd_chunk = 1;
+    int npart = 1;  // 65536-point in-LDS engine: template partitions of 32768 samples (templates longer than 32768)
     int nb_nosurf = 0;  // persistent engine, no-surface mode: blocks per launch (the pair arrays are ~1/32 of the tiles)
     int64_t max_rx = 0, max_blocks = 0, partial_per_tmpl = 0;
     int device = 0;
@@ -461,13 +462,33 @@ static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
         const char* e = getenv("CAF_FUSED_LB16");
         return !e || atoi(e);
     }();
+    // (templates of 32769 .. 262144 samples: the same 65536-point blocks with the template cut into partitions of 32768
+    //  samples -- Z_b = sum_p X_{b + p} . Hc_p, the frequency-domain delay line of partitioned convolution: the products of the
+    //  item's block and of the blocks that follow it with the partitions' spectra are summed before the one inverse transform,
+    //  fused_item2q<PART>; CAF_FUSED_PARTS = the largest number of partitions taken, 1 sends them to the rocfft engine -- A/B switch)
+    static const int max_parts = [] {
+        const char* e = getenv("CAF_FUSED_PARTS");
+        return e ? std::min(std::max(atoi(e), 1), 8) : 8;
+    }();
     const int fused_lb = (N <= 8192 && !lb15_env) ? 14 : N <= 16384 ? 15 : 16;
-    const bool fused_ok = N <= (lb16_env ? 32768 : 16384) && (d->freq_mode != CAF_FREQ_BINS || (d->grid >= 1 && 16384 % d->grid == 0)) &&
-                          (d->log2_block == 0 || d->log2_block == fused_lb);
+    const int fused_parts = fused_lb == 16 ? (N + 32767) / 32768 : 1;
+    // on-grid hypotheses are circular shifts of one template spectrum: every bin must land on a whole element of the engine's
+    // block (any grid that divides 16384 does; so does bin 0 on any grid), an even one where the rows are read parity-major
+    const bool bins_fit = [&] {
+        if (d->freq_mode != CAF_FREQ_BINS) return true;
+        if (d->grid < 1 || !d->h_bins) return false;
+        const int64_t Bf = (int64_t)1 << fused_lb;
+        for (int f = 0; f < F; ++f) {
+            const int64_t num = (int64_t)d->h_bins[f] * Bf;
+            if (num % d->grid != 0 || (fused_lb >= 15 && ((num / d->grid) & 1))) return false;
+        }
+        return true;
+    }();
+    const bool fused_ok = N <= (lb16_env ? 32768 * max_parts : 16384) && bins_fit && (d->log2_block == 0 || d->log2_block == fused_lb);
     CAF_REQUIRE(d->engine != CAF_ENGINE_PERSISTENT || fused_ok,
-                "the persistent engine needs template_len <= 32768, grid | 16384 and log2_block 0, 14 (<= 8192 samples), 15 (<= 16384) or 16");
+                "the persistent engine needs template_len <= 262144, bins on whole (even, beyond 8192 samples) elements of its block and log2_block 0, 14 (<= 8192 samples), 15 (<= 16384) or 16");
     CAF_REQUIRE(d->engine != CAF_ENGINE_FUSED || (fused_ok && N <= 8192),
-                "the two-launch fused engine needs template_len <= 8192, grid | 16384 and log2_block 0 or 14");
+                "the two-launch fused engine needs template_len <= 8192, bins on whole elements of its 16384-point block and log2_block 0 or 14");
     p->fused = (d->engine == CAF_ENGINE_FUSED) || (d->engine == CAF_ENGINE_PERSISTENT) ||
                (d->engine == CAF_ENGINE_AUTO && fused_ok);
     // one launch for both stages whenever the fused FFT applies: its tile role handles any F (steps of 32
@@ -486,7 +507,8 @@ static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
         lb = std::min(lb, std::max(ilog2_ceil(d->max_rx_len), 12));
         lb = std::max(lb, lmin);
     }
-    CAF_REQUIRE(lb >= lmin && lb <= 24, "log2_block must satisfy 2N <= 2^log2_block <= 2^24");
+    p->npart = p->fused ? fused_parts : 1;
+    CAF_REQUIRE((lb >= lmin || p->npart > 1) && lb <= 24, "log2_block must satisfy 2N <= 2^log2_block <= 2^24");
     lb = std::max(lb, 9);  // the multiply kernel tiles 512 points per workgroup
     p->B = 1 << lb;
     p->step = p->B - N + 1;
@@ -507,11 +529,11 @@ static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
     bool all_even = true;
     if (d->freq_mode == CAF_FREQ_BINS) {
         CAF_REQUIRE(d->h_bins && d->grid >= 1, "CAF_FREQ_BINS needs bins and grid");
-        CAF_REQUIRE(B % d->grid == 0, "grid must divide the block size (use CAF_FREQ_NORM otherwise)");
-        const int64_t mult = B / d->grid;
         shifts.resize(F);
         for (int f = 0; f < F; ++f) {
-            int64_t s = ((int64_t)d->h_bins[f] * mult) % B;
+            const int64_t num = (int64_t)d->h_bins[f] * B;
+            CAF_REQUIRE(num % d->grid == 0, "every bin must be a whole number of elements of the block: bins * block_size / grid (use CAF_FREQ_NORM otherwise)");
+            int64_t s = (num / d->grid) % B;
             if (s < 0) s += B;
             shifts[f] = (int32_t)s;
             if (s & 1) all_even = false;
@@ -521,7 +543,8 @@ static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
         CAF_REQUIRE(d->h_freqs_norm, "CAF_FREQ_NORM needs freqs_norm");
         p->mul_mode = 2;
     }
-    const int64_t nspec = (p->mul_mode == 2) ? (int64_t)T * F : T;  // template spectra held
+    const int NP = p->npart, PLEN = NP > 1 ? 32768 : N;  // partitions per template and their length (one partition: the template)
+    const int64_t nspec = ((p->mul_mode == 2) ? (int64_t)T * F : T) * NP;  // template spectra held (one row per partition)
 
     // batch: aim at ~128 MiB of hypothesis products in flight
     const int64_t total_blocks = (d->max_rx_len - N + 1 + p->step - 1) / p->step;
@@ -604,8 +627,8 @@ static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
     // all rx block spectra are produced up front, fwd_chunk blocks per rocFFT launch
     // (~32 MiB of spectra per forward launch: 256 blocks of 16384, 64 blocks of 65536, ...)
     p->fwd_chunk = (int)std::min<int64_t>(std::max<int64_t>(1, ((int64_t)1 << 22) / B), p->max_blocks);
-    if ((rc = p->alloc(&p->d_xb, (p->max_blocks + p->fwd_chunk) * B))) return rc;
-    if (p->fused && p->B >= 32768 && (rc = p->alloc(&p->d_xb2, (p->max_blocks + p->fwd_chunk) * B))) return rc;
+    if ((rc = p->alloc(&p->d_xb, (p->max_blocks + NP - 1 + p->fwd_chunk) * B))) return rc;
+    if (p->fused && p->B >= 32768 && (rc = p->alloc(&p->d_xb2, (p->max_blocks + NP - 1 + p->fwd_chunk) * B))) return rc;
     if (p->fused) {
         if ((rc = p->alloc(&p->d_vt, (int64_t)nb * p->tiles_per_blk * T * F * 64))) return rc;
         if ((rc = fused_twiddles(p->device, &p->d_tw1, &p->d_tw23))) return rc;  // per device, shared by all plans
@@ -652,20 +675,23 @@ static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
             return rc;
         }
         launch_build_hyp_time((const float2*)tmp_tm, (const double*)tmp_nu, N, B, F, T, d->auto_conj ? 0 : 1, p->d_hc,
-                              nullptr);
+                              nullptr, NP, PLEN);
     } else {
         std::vector<std::complex<float>> host((size_t)nspec * B, std::complex<float>(0.f, 0.f));
         for (int t = 0; t < T; ++t) {
+            // (row of partition q of a spectrum: the samples q * PLEN .. of the template at the row's start; the on-grid shifts
+            //  need no phase per partition: an even shift at 65536 points makes nu * 32768 q a whole number of cycles)
             if (p->mul_mode != 2) {
                 for (int n = 0; n < N; ++n) {
                     std::complex<float> u = tm[(size_t)t * N + n];
-                    host[(size_t)t * B + n] = d->auto_conj ? u : std::conj(u);
+                    host[((size_t)t * NP + n / PLEN) * B + n % PLEN] = d->auto_conj ? u : std::conj(u);
                 }
             } else {
                 for (int f = 0; f < F; ++f) {
                     const double nu = d->h_freqs_norm[f];
-                    std::complex<float>* dst = &host[((size_t)t * F + f) * B];
+                    std::complex<float>* dst0 = &host[((size_t)t * F + f) * NP * B];
                     for (int n = 0; n < N; ++n) {
+                        std::complex<float>* dst = dst0 + (size_t)(n / PLEN) * B - (size_t)(n / PLEN) * PLEN;
                         std::complex<double> u(tm[(size_t)t * N + n]);
                         if (!d->auto_conj) u = std::conj(u);
                         // reduce the phase in cycles before the trig call to keep full f64 accuracy
@@ -888,7 +914,8 @@ int32_t caf_plan_execute2(caf_plan p, const float* d_rx, int64_t rx_len, int64_t
     const int64_t nblk = (num_shifts + p->step - 1) / p->step;
     const int64_t nblk_pad = (nblk + p->nb - 1) / p->nb * p->nb;
     // overlap-save blocks of rx -> spectra X[b] for every block of this call
-    const int64_t nfwd = ((p->fused ? nblk : nblk_pad) + p->fwd_chunk - 1) / p->fwd_chunk;
+    // (partitioned templates: block b's products also take the spectra of blocks b + 1 .. b + npart - 1)
+    const int64_t nfwd = ((p->fused ? nblk + p->npart - 1 : nblk_pad) + p->fwd_chunk - 1) / p->fwd_chunk;
     // LDS engines with 16384-point blocks: gather + forward transform in one launch of the in-LDS FFT, which also
     // writes the sliding energies of each block's delays from the samples it holds anyway.
     // (CAF_FWD_ROCFFT=1: the gather kernel + batched rocFFT transforms that every other block size uses;
@@ -1023,6 +1050,7 @@ int32_t caf_plan_execute2(caf_plan p, const float* d_rx, int64_t rx_len, int64_t
             h.tiles_per_blk = p->tiles_per_blk;
             h.block_log2 = p->B == 65536 ? 16 : p->B == 32768 ? 15 : 14;
             h.dstride = p->B == 65536 ? 2 : 1;
+            h.npart = p->npart;
             h.ntmpl = T;
             h.step = p->step;
             h.blk0 = (int32_t)b0;

@@ -1,6 +1,7 @@
 """The C2 shape (2^24-sample rx, 256 on-grid bins, full surface) for template lengths around the LDS engines' limits:
 N = 4096 / 8192 (16384-point blocks), 8193 / 16384 (32768-point blocks = two chained transforms), 16385 / 24576 / 32768
 (65536-point blocks in the folded form: two chained transforms per output residue), 32769 (rocfft engine)."""
+import os
 import sys
 import time
 
@@ -19,7 +20,8 @@ LENGTHS = tuple(int(a) for a in sys.argv[1:]) or (4096, 8192, 8193, 16384, 16385
 for n in LENGTHS:
     t = qpsk(rng, n)
     grid = min(16384, 1 << int(np.ceil(np.log2(n))))
-    for engine in (("auto",) if n <= 8192 or n > 32768 or len(sys.argv) > 1 else ("auto", "rocfft")):
+    both = n > 8192 and (len(sys.argv) == 1 or os.environ.get("TIME_BOTH_ENGINES"))  # (in-LDS engine and the rocfft engine)
+    for engine in (("auto", "rocfft") if both else ("auto",)):
         plan = CAFPlan(t, max_rx_len=M, bins=np.arange(-F // 2, F // 2), grid=grid, engine=engine)
         res = plan.run(d_rx, surface=True)
         _lib.check(_lib.load().caf_stream_sync(None))

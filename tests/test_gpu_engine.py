@@ -197,7 +197,7 @@ def test_argument_validation():
     with pytest.raises(ValueError):
         CAFPlan(t, max_rx_len=32, bins=[0], grid=64)  # rx shorter than template
     with pytest.raises(ValueError):
-        CAFPlan(t, max_rx_len=1000, bins=[0], grid=48)  # grid does not divide the block
+        CAFPlan(t, max_rx_len=1000, bins=[0, 1], grid=48)  # bin 1 of a 48-point grid is no whole element of the block
     with pytest.raises(ValueError):
         CAFPlan(t, max_rx_len=1000, bins=[0], grid=64, log2_block=5)  # block < 2N
     with pytest.raises(ValueError):
@@ -275,8 +275,10 @@ def test_engines_agree_with_oracle(engine, golden):
     if engine != "rocfft":
         with pytest.raises(ValueError):
             plan3.run(asarray(rxg), cqf=True)  # complex QF is a rocFFT-engine output
+        with pytest.raises(ValueError):  # (beyond the eight partitions of 32768 samples; the two-launch engine ends at 8192)
+            CAFPlan(np.ones(262145, np.complex64), max_rx_len=400000, bins=[0], grid=16384, engine=engine)
         with pytest.raises(ValueError):
-            CAFPlan(np.ones(33000, np.complex64), max_rx_len=80000, bins=[0], grid=16384, engine=engine)  # (> 32768 samples)
+            CAFPlan(np.ones(33000, np.complex64), max_rx_len=80000, bins=[0], grid=16384, engine="fused")
 
     # 2 templates x 128 bins (whole 128-hypothesis chunks: the full-tile path of the transposers), 3 blocks,
     # run twice on different data through the same plan: the second result must not see the first one's tiles
@@ -326,17 +328,19 @@ def test_engines_agree_with_oracle(engine, golden):
     assert np.all(r7.peak_delay.get()[1:20] == d6[1:20])
 
 
-@pytest.mark.parametrize("n", [4095, 8191, 8192, 8193, 12000, 16384, 16385, 24000, 32768, 32769])
+@pytest.mark.parametrize("n", [4095, 8191, 8192, 8193, 12000, 16384, 16385, 24000, 32768, 32769, 49152, 65536, 65537, 100000,
+                               131072, 131073, 200000, 262144, 262145])
 def test_template_lengths_around_the_fused_limits(n):
     """The LDS-resident engines: 16384-point blocks for templates up to 8192 samples (persistent and two-launch fused,
     bit-identical), 32768-point blocks as two chained 16384-point transforms up to 16384 samples, 65536-point blocks in the
-    folded form (two chained transforms per output residue) up to 32768 samples (persistent only); longer ones go to the
-    rocfft engine automatically and are refused by an explicit fused / persistent request."""
+    folded form (two chained transforms per output residue) up to 32768 samples (persistent only), the same blocks with the
+    template cut into 2 .. 8 partitions of 32768 samples up to 262144; longer ones go to the rocfft engine automatically and
+    are refused by an explicit fused / persistent request."""
     from pydsproutines_amd import CAFPlan, asarray
     from test_gpu_engine_fuzz import _oracle_rows
 
     rng = np.random.default_rng(n)
-    m = 40_000 if n <= 8192 else 90_000 if n <= 16384 else 150_000
+    m = 40_000 if n <= 8192 else 90_000 if n <= 16384 else 150_000 if n <= 32768 else n + 110_000
     t = qpsk(rng, n)
     rx = cn(rng, m)
     d0, bins = 12_345, np.arange(-4, 4)
@@ -347,7 +351,7 @@ def test_template_lengths_around_the_fused_limits(n):
                      98303, 98304, m - n])
     rows = rows[rows <= m - n]
     ref = _oracle_rows(t, rx, bins / grid, rows)
-    engines = ("persistent", "fused", "rocfft") if n <= 8192 else ("persistent", "rocfft") if n <= 32768 else ("rocfft",)
+    engines = ("persistent", "fused", "rocfft") if n <= 8192 else ("persistent", "rocfft") if n <= 262144 else ("rocfft",)
     surf = {}
     for engine in engines:
         plan = CAFPlan(t, max_rx_len=m, bins=bins, grid=grid, engine=engine)
@@ -374,7 +378,7 @@ def test_template_lengths_around_the_fused_limits(n):
         auto.close()
         with pytest.raises(ValueError):
             CAFPlan(t, max_rx_len=m, bins=bins, grid=grid, engine="fused")
-    elif n <= 32768:
+    elif n <= 262144:
         assert np.max(np.abs(surf["persistent"] - surf["rocfft"])) <= 2e-6 * max(1.0, surf["rocfft"].max())  # two engines
         auto = CAFPlan(t, max_rx_len=m, bins=bins, grid=grid)
         assert auto.engine_used == "persistent" and auto.block == 65536 and auto.step == 32768

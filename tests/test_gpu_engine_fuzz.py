@@ -167,10 +167,12 @@ CHAINED_CASES = list(range(max(10, int(os.environ.get("CAF_FUZZ_CASES", "28")) /
 
 
 def _chained_case(seed):
-    """Templates of 8193 .. 32768 samples: 32768-point blocks (two chained transforms; one, two or all four quarters of the
-    upper half valid) and 65536-point blocks (folded: tiles of every second delay)."""
+    """Templates of 8193 .. 262144 samples: 32768-point blocks (two chained transforms; one, two or all four quarters of the
+    upper half valid) and 65536-point blocks (folded: tiles of every second delay; beyond 32768 samples the template in
+    partitions of 32768 samples against the spectra of the blocks that follow)."""
     rng = np.random.default_rng(7000 + seed)
-    n = int(rng.choice([8193, 9000, 12288, 12289, 16383, 16384, 16385, 20000, 24576, 32767, 32768]))
+    n = int(rng.choice([8193, 9000, 12288, 12289, 16383, 16384, 16385, 20000, 24576, 32767, 32768,
+                        32769, 40000, 65535, 65536, 65537, 90000, 98304, 131072, 150000, 262144]))  # (from 32769: 2 .. 8 template partitions)
     t = int(rng.choice([1, 1, 2, 3]))
     f = int(rng.choice([1, 2, 5, 31, 33, 64, 70]))
     step = (32768 if n <= 16384 else 65536) - n + 1 if n <= 16384 else 32768
