@@ -209,17 +209,26 @@ __global__ __launch_bounds__(256) void k_inv_energy(const float2* __restrict__ r
 // ----------------------------------------------------------------------------------------
 // Overlap-save block gather: xb[b][m] = rx[src0 + b*step + m] (0 past the end of rx).
 // ----------------------------------------------------------------------------------------
+// (two consecutive points per thread: one 16-byte load -- 8-byte aligned, which global loads allow -- and one aligned 16-byte
+//  store; 8 bytes per lane left the copy at 2.0 TB/s, a quarter of the peak)
+typedef float v4f_a8_t __attribute__((ext_vector_type(4), aligned(8)));
 __global__ __launch_bounds__(256) void k_gather_blocks(const float2* __restrict__ rx, int64_t rx_len,
                                                        int64_t src0, int32_t step, int32_t log2_bsz,
                                                        int64_t total, float2* __restrict__ xb) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;  // (block sizes are even: a pair never straddles two blocks)
     if (i >= total) return;
     const int64_t b = i >> log2_bsz;
     const int64_t m = i & (((int64_t)1 << log2_bsz) - 1);
     const int64_t src = src0 + b * step + m;
-    float2 v = make_float2(0.f, 0.f);
-    if (src < rx_len) v = rx[src];
-    xb[i] = v;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (src + 1 < rx_len) {
+        const v4f_a8_t u = *reinterpret_cast<const v4f_a8_t*>(rx + src);
+        v = make_float4(u.x, u.y, u.z, u.w);
+    } else if (src < rx_len) {
+        const float2 u = rx[src];
+        v.x = u.x, v.y = u.y;
+    }
+    *reinterpret_cast<float4*>(xb + i) = v;
 }
 
 // hc[i] = conj(h[i]) * scale   (template spectra -> pre-conjugated, 1/B folded in)
@@ -597,7 +606,7 @@ void launch_gather_blocks(const float2* rx, int64_t rx_len, int64_t src0, int32_
     int lb = 0;
     while ((1 << lb) < bsz) ++lb;
     const int64_t total = (int64_t)nblk * bsz;
-    hipLaunchKernelGGL(k_gather_blocks, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, rx, rx_len, src0, step,
+    hipLaunchKernelGGL(k_gather_blocks, dim3((unsigned)((total / 2 + 255) / 256)), dim3(256), 0, st, rx, rx_len, src0, step,
                        lb, total, xb);
 }
 

@@ -80,9 +80,14 @@ __global__ __launch_bounds__(256) void k_sliding_multiply(const float2* __restri
                                                           const double* __restrict__ prefix, int64_t start,
                                                           int64_t step, double coef, int32_t zero_oor,
                                                           float2* __restrict__ z, const double* __restrict__ d_coef,
-                                                          int64_t rows, int32_t rpw) {
+                                                          int64_t rows, int32_t rpw, int32_t rows_fastest) {
     __shared__ float s_inv[SM_MAX_RPW];
-    const int64_t row0 = (int64_t)blockIdx.y * rpw;
+    // rows_fastest (long rows): the row groups are the fast grid dimension, so the workgroups in flight work on the SAME chunk of
+    // x and of the (overlapping) windows of y for different rows and find it in the L2 / Infinity Cache -- with the chunks fastest
+    // every row group streamed both arrays from HBM again (128 rows of 10^7 samples: 5.6 GB fetched for 0.16 GB of inputs)
+    const uint32_t bx = rows_fastest ? blockIdx.y : blockIdx.x, by = rows_fastest ? blockIdx.x : blockIdx.y;
+    const uint32_t gdx = rows_fastest ? gridDim.y : gridDim.x;
+    const int64_t row0 = (int64_t)by * rpw;
     if ((int)threadIdx.x < rpw && row0 + threadIdx.x < rows) {
         const int64_t s = start + (row0 + threadIdx.x) * step;
         const bool oor = (s < 0) || (s + xlen > ylen);
@@ -116,7 +121,7 @@ __global__ __launch_bounds__(256) void k_sliding_multiply(const float2* __restri
             iq[q] = live[q] ? s_inv[r + q] : 0.f;
             zrow[q] = z + (row0 + r + q) * (int64_t)xlen;
         }
-        for (int t = blockIdx.x * 256 + threadIdx.x; t < xlen; t += gridDim.x * 256) {
+        for (int t = bx * 256 + threadIdx.x; t < xlen; t += gdx * 256) {
             const float2 a = x[t];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -1059,11 +1064,25 @@ constexpr int FIRP_R = 4;
 constexpr int FIRP_TILE = 256 * FIRP_R;
 constexpr int FIRP_MAXSPAN = 7400;  // samples of the tile window (+ the tap table: < 64 KB of LDS)
 
-template <typename TIn, int NT>
+// A workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...: the next tile's window is fetched into REGISTERS (raw
+// TIn: one register per int16 IQ sample) right after the barrier that hands the current one to the sliding dot products, so its
+// round trips to memory run under a tile's worth of arithmetic instead of in front of it (one tile per workgroup: stage ->
+// barrier -> compute, 62 % of the wave cycles parked; the launch now keeps as many workgroups as are resident).
+__device__ __forceinline__ float2 fird_cvt(float2 v, float) { return v; }
+__device__ __forceinline__ float2 fird_cvt(short2 v, float scale) { return make_float2((float)v.x * scale, (float)v.y * scale); }
+template <typename TIn>
+__device__ __forceinline__ TIn fird_zero();
+template <>
+__device__ __forceinline__ float2 fird_zero<float2>() { return make_float2(0.f, 0.f); }
+template <>
+__device__ __forceinline__ short2 fird_zero<short2>() { return make_short2(0, 0); }
+
+// EPT: window elements a thread stages per tile (instantiated for 8 / 16 / 24 / 32: the prefetch registers of the shape at hand)
+template <typename TIn, int NT, int EPT>
 __global__ __launch_bounds__(NT) void k_fir_poly(const TIn* __restrict__ x, int64_t n, float scale,
                                                   const float* __restrict__ taps, int32_t ntaps,
                                                   const TIn* __restrict__ delay, int32_t dlen, int32_t dsr, int32_t phase,
-                                                  float2* __restrict__ out, int64_t nout) {
+                                                  float2* __restrict__ out, int64_t nout, int64_t ntiles) {
     extern __shared__ float s_firp[];
     const int qmax = (ntaps + dsr - 1) / dsr;                      // sub-filter length of branch 0 (the longest)
     const int qpad = (qmax + FIRP_R - 1) / FIRP_R * FIRP_R;        // padded with zero taps
@@ -1072,38 +1091,43 @@ __global__ __launch_bounds__(NT) void k_fir_poly(const TIn* __restrict__ x, int6
     const int rowpitch = FIRP_R * pitch2;
     float* s_g = s_firp;                                           // dsr * qpad sub-filter taps
     float2* s_x = reinterpret_cast<float2*>(s_firp + ((dsr * qpad + 1) & ~1));  // dsr rows of rowpitch
-    const int64_t o0 = (int64_t)blockIdx.x * (NT * FIRP_R);
-    const int64_t i0 = o0 * dsr + phase - (ntaps - 1);             // input index of window element 0
     for (int t = threadIdx.x; t < dsr * qpad; t += NT) {
         const int rho = t / qpad, q = t - rho * qpad;
         const int m = q * dsr + rho;
         s_g[t] = m < ntaps ? taps[ntaps - 1 - m] : 0.f;
     }
-    {   // window element e = c*dsr + rho -> row rho, column c; (rho, c) advance without divisions.
-        // Eight loads per thread are issued before the first of them is stored: element by element (load, wait, store) the
-        // ~16 round trips of a thread's share stood in front of the barrier one after the other (stage_batched above; here
-        // with the running (rho, c) instead of a division per element).
-        const int total = ncols * dsr;
-        int c = threadIdx.x / dsr, rho = threadIdx.x - c * dsr;
-        const int dc = NT / dsr, dr = NT - dc * dsr;
-        constexpr int STG = sizeof(TIn) == 8 ? 8 : 1;  // (raw int16 IQ: one at a time measured 5-15 % faster, ab_iq16_staging.log)
-        for (int e0 = threadIdx.x; e0 < total; e0 += NT * STG) {
-            float2 v[STG];
+    // window element e = c*dsr + rho -> row rho, column c; a thread stages the elements tid, tid + NT, ...
+    constexpr int MAXE = EPT;
+    const int total = ncols * dsr;
+    TIn pre[MAXE];
+    auto fetch = [&](int64_t tile) {
+        const int64_t i0 = tile * (NT * FIRP_R) * dsr + phase - (ntaps - 1);  // input index of window element 0
+        // elements lo <= e < hi come from x (uniform base + 32-bit offsets), dl <= e < lo from the delay line, the rest are zeros
+        const int lo = (int)std::min<int64_t>(std::max<int64_t>(-i0, 0), total), hi = (int)std::min<int64_t>(std::max<int64_t>(n - i0, 0), total);
+        const int dl = delay ? (int)std::min<int64_t>(std::max<int64_t>(-i0 - dlen, 0), total) : lo;
+        const TIn* xb = x + i0;
+        const TIn* db = delay + (dlen + i0);
 #pragma unroll
-            for (int u = 0; u < STG; ++u) {
-                const int64_t j = i0 + e0 + NT * u;
-                v[u] = make_float2(0.f, 0.f);
-                if (e0 + NT * u < total) {
-                    if (j >= 0) {
-                        if (j < n) v[u] = fird_load(x, j, scale);
-                    } else if (delay && -j <= dlen) {
-                        v[u] = fird_load(delay, dlen + j, scale);
-                    }
-                }
+        for (int u = 0; u < MAXE; ++u) {
+            const int e = (int)threadIdx.x + NT * u;
+            TIn v = fird_zero<TIn>();
+            if (e >= lo) {
+                if (e < hi) v = xb[e];
+            } else if (e >= dl) {
+                v = db[e];
             }
+            pre[u] = v;
+        }
+    };
+    int64_t tile = blockIdx.x;
+    if (tile < ntiles) fetch(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+        {   // (rho, c) advance without divisions
+            int c = threadIdx.x / dsr, rho = threadIdx.x - c * dsr;
+            const int dc = NT / dsr, dr = NT - dc * dsr;
 #pragma unroll
-            for (int u = 0; u < STG; ++u) {
-                if (e0 + NT * u < total) s_x[rho * rowpitch + (c % FIRP_R) * pitch2 + c / FIRP_R] = v[u];
+            for (int u = 0; u < MAXE; ++u) {
+                if ((int)threadIdx.x + NT * u < total) s_x[rho * rowpitch + (c % FIRP_R) * pitch2 + c / FIRP_R] = fird_cvt(pre[u], scale);
                 c += dc;
                 rho += dr;
                 if (rho >= dsr) {
@@ -1112,37 +1136,40 @@ __global__ __launch_bounds__(NT) void k_fir_poly(const TIn* __restrict__ x, int6
                 }
             }
         }
-    }
-    __syncthreads();
-    float2 acc[FIRP_R];
+        __syncthreads();
+        if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x);
+        const int64_t o0 = tile * (NT * FIRP_R);
+        float2 acc[FIRP_R];
 #pragma unroll
-    for (int r = 0; r < FIRP_R; ++r) acc[r] = make_float2(0.f, 0.f);
-    for (int rho = 0; rho < dsr; ++rho) {
-        const float2* xr = s_x + rho * rowpitch + threadIdx.x;  // column l0 + r + q with l0 = R * tid
-        const float* g = s_g + rho * qpad;
-        float2 win[FIRP_R];
+        for (int r = 0; r < FIRP_R; ++r) acc[r] = make_float2(0.f, 0.f);
+        for (int rho = 0; rho < dsr; ++rho) {
+            const float2* xr = s_x + rho * rowpitch + threadIdx.x;  // column l0 + r + q with l0 = R * tid
+            const float* g = s_g + rho * qpad;
+            float2 win[FIRP_R];
 #pragma unroll
-        for (int r = 0; r < FIRP_R; ++r) win[r] = xr[r * pitch2];  // columns l0 + r (q = 0)
-        for (int q0 = 0; q0 < qpad; q0 += FIRP_R) {
+            for (int r = 0; r < FIRP_R; ++r) win[r] = xr[r * pitch2];  // columns l0 + r (q = 0)
+            for (int q0 = 0; q0 < qpad; q0 += FIRP_R) {
 #pragma unroll
-            for (int qq = 0; qq < FIRP_R; ++qq) {
-                const float c = g[q0 + qq];
-                // output r at q reads column l0 + r + q, held in slot (r + qq) mod R
+                for (int qq = 0; qq < FIRP_R; ++qq) {
+                    const float c = g[q0 + qq];
+                    // output r at q reads column l0 + r + q, held in slot (r + qq) mod R
 #pragma unroll
-                for (int r = 0; r < FIRP_R; ++r) {
-                    const float2 w = win[(r + qq) % FIRP_R];
-                    acc[r].x += c * w.x;
-                    acc[r].y += c * w.y;
+                    for (int r = 0; r < FIRP_R; ++r) {
+                        const float2 w = win[(r + qq) % FIRP_R];
+                        acc[r].x += c * w.x;
+                        acc[r].y += c * w.y;
+                    }
+                    // column l0 + q is done; slot qq takes column l0 + q + R
+                    win[qq] = xr[qq * pitch2 + q0 / FIRP_R + 1];
                 }
-                // column l0 + q is done; slot qq takes column l0 + q + R
-                win[qq] = xr[qq * pitch2 + q0 / FIRP_R + 1];
             }
         }
-    }
 #pragma unroll
-    for (int r = 0; r < FIRP_R; ++r) {
-        const int64_t o = o0 + threadIdx.x * FIRP_R + r;
-        if (o < nout && o * dsr + phase < n) out[o] = acc[r];
+        for (int r = 0; r < FIRP_R; ++r) {
+            const int64_t o = o0 + threadIdx.x * FIRP_R + r;
+            if (o < nout && o * dsr + phase < n) out[o] = acc[r];
+        }
+        __syncthreads();  // the window is overwritten by the next tile
     }
 }
 
@@ -1387,8 +1414,10 @@ void launch_sliding_multiply(const float2* x, int32_t xlen, const float2* y, int
     // rows of up to 8192 samples: ~64K elements per workgroup (up to 64 rows), one chunk; longer rows: one row per
     // workgroup row, up to 64 chunks
     int rpw = 1;
+    int rows_fastest = 0;
     unsigned gx = std::min<unsigned>(cdiv(xlen, 256), 64);
     if (xlen > 8192 && rows >= 4) {
+        rows_fastest = 1;
         // long rows: four rows per workgroup (one x load for the four), enough chunks to fill the chip
         rpw = 4;
         const int64_t groups = (rows + 3) / 4;
@@ -1403,8 +1432,9 @@ void launch_sliding_multiply(const float2* x, int32_t xlen, const float2* y, int
     const int64_t rows_per_launch = (int64_t)65535 * rpw;
     for (int64_t r0 = 0; r0 < rows; r0 += rows_per_launch) {
         const int64_t nr = std::min<int64_t>(rows_per_launch, rows - r0);
-        hipLaunchKernelGGL(k_sliding_multiply, dim3(gx, (unsigned)((nr + rpw - 1) / rpw)), dim3(256), 0, st, x, xlen, y, ylen,
-                           prefix, start + r0 * step, step, coef, zero_oor, z + r0 * (int64_t)xlen, d_coef, nr, rpw);
+        const unsigned gy = (unsigned)((nr + rpw - 1) / rpw);
+        hipLaunchKernelGGL(k_sliding_multiply, rows_fastest ? dim3(gy, gx) : dim3(gx, gy), dim3(256), 0, st, x, xlen, y, ylen,
+                           prefix, start + r0 * step, step, coef, zero_oor, z + r0 * (int64_t)xlen, d_coef, nr, rpw, rows_fastest);
     }
 }
 
@@ -1724,23 +1754,42 @@ static void launch_fir_decim(const TIn* x, int64_t n, float scale, const float* 
                            (size_t)dsr * FIRP_R * (ncols / FIRP_R + 1) * sizeof(float2);
         if (smp <= 64 * 1024 && (size_t)ncols * dsr <= FIRP_MAXSPAN + 4 * FIRP_R * dsr) {
             // (Tiles of 512 outputs on 128 threads -- half the LDS, twice the independent workgroups per CU, the same waves -- measured
-            //  the same as 1024 on 256: 55.8 / 56.1 us for 2^24 int16 samples, 64 taps, dsr 4 (profiles/r05/ab_fir_poly_nt.log): the
-            //  stage -> barrier -> compute chain is not what bounds the kernel.  CAF_FIR_POLY_NT=128 selects them.)
-            static const int nt_env = [] {
-                const char* e = getenv("CAF_FIR_POLY_NT");
+            //  the same as 1024 on 256 with one tile per workgroup: 55.8 / 56.1 us for 2^24 int16 samples, 64 taps, dsr 4
+            //  (profiles/r05/ab_fir_poly_nt.log).)
+            const bool small = false;
+            // resident workgroups: what the LDS holds per CU, at most 16 waves' worth of registers (CAF_FIR_POLY_WGS: per CU, A/B)
+            static const int wgs_env = [] {
+                const char* e = getenv("CAF_FIR_POLY_WGS");
                 return e ? atoi(e) : 0;
             }();
-            const bool small = nt_env == 128;
-            if (small) {
-                const int ncols2 = 128 * FIRP_R + qpad;
-                const size_t smp2 = (size_t)((dsr * qpad + 1) & ~1) * sizeof(float) +
-                                    (size_t)dsr * FIRP_R * (ncols2 / FIRP_R + 1) * sizeof(float2);
-                hipLaunchKernelGGL((k_fir_poly<TIn, 128>), dim3(cdiv(nout, 128 * FIRP_R)), dim3(128), smp2, st, x, n, scale, taps, ntaps,
-                                   delay, dlen, dsr, phase, out, nout);
-                return;
-            }
-            hipLaunchKernelGGL((k_fir_poly<TIn, 256>), dim3(cdiv(nout, FIRP_TILE)), dim3(256), smp, st, x, n, scale, taps, ntaps,
-                               delay, dlen, dsr, phase, out, nout);
+            static const int ncu = [] {
+                int dev = 0, c = 256;
+                (void)hipGetDevice(&dev);
+                (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev);
+                return c;
+            }();
+            (void)small;
+            const int64_t ntiles = cdiv(nout, FIRP_TILE);
+            const int ept = (ncols * dsr + 255) / 256;
+            // the grid is what is RESIDENT (tiles are dealt by striding: a workgroup that waits for a slot would start its share late)
+            auto resident = [&](const void* kern) {
+                thread_local std::map<std::pair<const void*, size_t>, int> cache;
+                auto it = cache.find({kern, smp});
+                if (it != cache.end()) return it->second;
+                int nb = 1;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, smp) != hipSuccess || nb < 1) nb = 1;
+                cache[{kern, smp}] = nb;
+                return nb;
+            };
+#define CAF_FIR_POLY(E)                                                                                                            \
+    do {                                                                                                                           \
+        const int per_cu = wgs_env > 0 ? wgs_env : resident(reinterpret_cast<const void*>(&k_fir_poly<TIn, 256, E>));                \
+        const dim3 grid((unsigned)std::min<int64_t>(ntiles, (int64_t)ncu * per_cu));                                               \
+        hipLaunchKernelGGL((k_fir_poly<TIn, 256, E>), grid, dim3(256), smp, st, x, n, scale, taps, ntaps, delay, dlen, dsr, phase, \
+                           out, nout, ntiles);                                                                                     \
+    } while (0)
+            if (ept <= 8) CAF_FIR_POLY(8); else if (ept <= 16) CAF_FIR_POLY(16); else if (ept <= 24) CAF_FIR_POLY(24); else CAF_FIR_POLY(32);
+#undef CAF_FIR_POLY
             return;
         }
     }

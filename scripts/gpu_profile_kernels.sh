@@ -23,6 +23,9 @@ for w in $WL; do
   # where the waves' cycles go (SQ counters, a pass of their own; asked for with PROFILE_SQ=1: the small kernels)
   if [ -n "$PROFILE_SQ" ]; then
     PROFILE_REPS_SCALE=1 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU SQ_WAVES --kernel-trace --output-format csv -d $OUT/$w/pmc_sq -- python3 scripts/profile_workloads.py $w > $OUT/$w/sq.log 2>&1 || { tail -20 $OUT/$w/sq.log; exit 1; }
+    # the LDS array's own cycles (a pass of their own): SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE is the share of LDS-array cycles lost to
+    # bank conflicts (MI355X_MICROARCH.md, LDS); SQ_ACTIVE_INST_LDS above counts wave cycles and is no denominator for it
+    PROFILE_REPS_SCALE=1 rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS --kernel-trace --output-format csv -d $OUT/$w/pmc_lds -- python3 scripts/profile_workloads.py $w > $OUT/$w/lds.log 2>&1 || { tail -20 $OUT/$w/lds.log; exit 1; }
   fi
 done
 python3 scripts/summarize_kernels.py $OUT > $OUT/kernels_summary.txt

@@ -202,6 +202,26 @@ def w_c2_lb16():
              alg, flops, 2)]
 
 
+def w_c2_parts_65536():
+    """C2 shape with a 65536-sample template: the folded 65536-point role with the template in two partitions of 32768 samples
+    (products of the item's block and of the next one with the two partition spectra, summed before the transform)."""
+    n = 65536
+    d_rx = keep("lb16_rx", lambda: asarray(cn(rng, M)))
+    plan = keep("parts_plan", lambda: CAFPlan(qpsk(rng, n), max_rx_len=M, bins=np.arange(-128, 128), grid=16384))
+    assert plan.engine_used == "persistent" and plan.block == 65536
+    st = keep("parts_res", dict)
+    for _ in range(2):
+        st["res"] = plan.run(d_rx, surface=True, out=st.get("res"))
+    sync()
+    Sn = M - n + 1
+    B, step = plan.block, plan.step
+    nblk = -(-Sn // step)
+    alg = nblk * ((step // 64) * 64 * 256 * 4.0 + 8.0 * B) + Sn * 256 * 8.0 + Sn * 12.0
+    flops = nblk * 256 * 2 * (2 * 5.0 * 16384 * 14 + 2 * 17.0 * 32768 + 3.0 * 16384)  # per item: two transforms, two folds, |y|^2
+    return [("k_caf_persistent", "one-launch engine, N=65536 (B=65536 folded, template in 2 partitions of 32768), F=256, surface",
+             alg, flops, 2)]
+
+
 def w_c5_zoom():
     from pydsproutines_amd.zoom import caf_with_zoom
 

@@ -77,6 +77,8 @@ def main(out):
         write = load_pmc(find(os.path.join(wdir, "pmc_write"), "*counter_collection.csv"), "WRITE_SIZE")
         sq_path = find(os.path.join(wdir, "pmc_sq"), "*counter_collection.csv")
         sq = {c: load_pmc(sq_path, c) for c in SQ_COUNTERS} if sq_path else None
+        lds_path = find(os.path.join(wdir, "pmc_lds"), "*counter_collection.csv")
+        lds = {c: load_pmc(lds_path, c) for c in ("SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_INSTS_LDS")} if lds_path else None
         total_us = sum(v[1] for v in trace.values()) or 1.0
         print("=" * 150)
         print("workload %s   (all kernels of the run: %.1f ms)" % (name, total_us / 1e3))
@@ -113,11 +115,20 @@ def main(out):
                 tot = {c: sum(sq[c].get(k, 0.0) for k in ks) for c in SQ_COUNTERS}
                 wc = tot["SQ_WAVE_CYCLES"] or 1.0
                 sqrec = {c: tot[c] for c in SQ_COUNTERS}
-                print("      wave cycles: %.0f %% parked (s_waitcnt / barrier), %.0f %% issue-stalled, %.0f %% issuing (VALU %.0f %%, LDS %.0f %%); "
-                      "LDS bank-conflict cycles = %.0f %% of the LDS-active cycles" % (
+                # (SQ_ACTIVE_INST_LDS counts WAVE cycles with an LDS instruction in progress, SQ_LDS_BANK_CONFLICT cycles of the LDS
+                #  array: their quotient -- printed up to round 4 as "of the LDS-active cycles", up to 425 % -- is no share of anything;
+                #  the share of the array's cycles is conflict / SQ_LDS_IDX_ACTIVE, from the pmc_lds pass)
+                ldsrec = None
+                if lds:
+                    lt = {c: sum(lds[c].get(k, 0.0) for k in ks) for c in lds}
+                    ldsrec = dict(lt, conflict_share=lt["SQ_LDS_BANK_CONFLICT"] / max(lt["SQ_LDS_IDX_ACTIVE"], 1.0))
+                print("      wave cycles: %.0f %% parked (s_waitcnt / barrier), %.0f %% issue-stalled, %.0f %% issuing (VALU %.0f %%, LDS %.0f %%)%s" % (
                           100 * tot["SQ_WAIT_ANY"] / wc, 100 * tot["SQ_WAIT_INST_ANY"] / wc, 100 * tot["SQ_ACTIVE_INST_ANY"] / wc,
                           100 * tot["SQ_ACTIVE_INST_VALU"] / wc, 100 * tot["SQ_ACTIVE_INST_LDS"] / wc,
-                          100 * tot["SQ_LDS_BANK_CONFLICT"] / max(tot["SQ_ACTIVE_INST_LDS"], 1.0)))
+                          ("; LDS array: %.0f %% of its active cycles are bank-conflict cycles (%.2e of %.2e), %.1f array cycles per LDS instruction"
+                           % (100 * ldsrec["conflict_share"], ldsrec["SQ_LDS_BANK_CONFLICT"], ldsrec["SQ_LDS_IDX_ACTIVE"],
+                              ldsrec["SQ_LDS_IDX_ACTIVE"] / max(ldsrec["SQ_INSTS_LDS"], 1.0))) if ldsrec else ""))
+                sqrec["lds_array"] = ldsrec
             wres["kernels"].append({"kernel": e["kernel"], "what": e["what"], "matched": ks, "sq": sqrec, "dispatches": disp, "calls": calls,
                                     "total_ms": tus / 1e3, "avg_launch_us": tus / max(disp, 1), "median_launch_us": med_us,
                                     "min_launch_us": min_us, "per_call_us": per_call_us,
