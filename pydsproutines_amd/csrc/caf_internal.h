@@ -145,6 +145,7 @@ void launch_gather_f32_f64(const float* x, int64_t xlen, const int32_t* idx, int
 void launch_fir(const float2* x, int64_t n, const float* taps, int32_t ntaps, const float2* delay, int32_t dlen,
                 int32_t dsr, int32_t phase, float2* out, int64_t nout, hipStream_t st);
 bool fir_decim_ok(int32_t ntaps, int32_t dsr);
+bool fir_poly_fits(int32_t ntaps, int32_t dsr);  // ... and the register-tiled polyphase kernel takes it (small decimation factors)
 void launch_iq16_fir(const int16_t* iq, int64_t n, float scale, const float* taps, int32_t ntaps, const int16_t* delay,
                      int32_t dlen, int32_t dsr, int32_t phase, float2* out, int64_t nout, hipStream_t st);
 void launch_upfirdn(const float2* x, int64_t rows, int64_t n, const float* taps, int32_t ntaps, int32_t up, int32_t down,

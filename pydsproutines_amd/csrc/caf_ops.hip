@@ -108,6 +108,10 @@ bool fir_use_overlap_save(int32_t ntaps, int32_t dsr, int32_t direct_limit) {
         const char* e = getenv("CAF_FIR_OS_MIN_TAPS");
         return e ? atoi(e) : 96;
     }();
+    // decimation factors beyond the register-tiled polyphase kernel's window run on k_fir_decim (a tap and a sample read from LDS
+    // per multiply-add): level with overlap-save at 64 taps, half its speed at 128 (2^24 int16 samples, /8: 133 against 77 us) --
+    // there the 96 taps count as such, not per unit of decimation
+    if (dsr >= 2 && !fir_poly_fits(ntaps, dsr) && ntaps >= std::max(min_taps, 1) && fir_os_fused_block(ntaps)) return true;
     return ntaps > direct_limit || (int64_t)ntaps > (int64_t)min_taps * dsr;
 }
 

@@ -468,7 +468,7 @@ static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
     //  fused_item2q<PART>; CAF_FUSED_PARTS = the largest number of partitions taken, 1 sends them to the rocfft engine -- A/B switch)
     static const int max_parts = [] {
         const char* e = getenv("CAF_FUSED_PARTS");
-        return e ? std::min(std::max(atoi(e), 1), 8) : 8;
+        return e ? std::min(std::max(atoi(e), 1), 16) : 8;
     }();
     const int fused_lb = (N <= 8192 && !lb15_env) ? 14 : N <= 16384 ? 15 : 16;
     const int fused_parts = fused_lb == 16 ? (N + 32767) / 32768 : 1;

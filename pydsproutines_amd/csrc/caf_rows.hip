@@ -1741,18 +1741,28 @@ void launch_moving_tile(const float* x, int64_t rows, int64_t n, int32_t L, int3
 }
 
 bool fir_decim_ok(int32_t ntaps, int32_t dsr) { return dsr >= 1 && dsr <= FIRD_MAXDSR && ntaps <= 2048; }
+// the register-tiled polyphase form (k_fir_poly) applies: its tile window of 1024 kept outputs fits the LDS
+static size_t fir_poly_lds(int32_t ntaps, int32_t dsr, int* ncols_out) {
+    const int qmax = (ntaps + dsr - 1) / dsr;
+    const int qpad = (qmax + FIRP_R - 1) / FIRP_R * FIRP_R;
+    const int ncols = FIRP_TILE + qpad;
+    if (ncols_out) *ncols_out = ncols;
+    return (size_t)((dsr * qpad + 1) & ~1) * sizeof(float) + (size_t)dsr * FIRP_R * (ncols / FIRP_R + 1) * sizeof(float2);
+}
+bool fir_poly_fits(int32_t ntaps, int32_t dsr) {
+    int ncols = 0;
+    const size_t smp = fir_poly_lds(ntaps, dsr, &ncols);
+    return dsr >= 1 && smp <= 64 * 1024 && (size_t)ncols * dsr <= (size_t)FIRP_MAXSPAN + 4 * FIRP_R * dsr;
+}
 
 template <typename TIn>
 static void launch_fir_decim(const TIn* x, int64_t n, float scale, const float* taps, int32_t ntaps, const TIn* delay,
                              int32_t dlen, int32_t dsr, int32_t phase, float2* out, int64_t nout, hipStream_t st) {
     if (nout <= 0) return;
     {   // register-tiled polyphase form when its tile window fits the LDS (small decimation factors)
-        const int qmax = (ntaps + dsr - 1) / dsr;
-        const int qpad = (qmax + FIRP_R - 1) / FIRP_R * FIRP_R;
-        const int ncols = FIRP_TILE + qpad;
-        const size_t smp = (size_t)((dsr * qpad + 1) & ~1) * sizeof(float) +
-                           (size_t)dsr * FIRP_R * (ncols / FIRP_R + 1) * sizeof(float2);
-        if (smp <= 64 * 1024 && (size_t)ncols * dsr <= FIRP_MAXSPAN + 4 * FIRP_R * dsr) {
+        int ncols = 0;
+        const size_t smp = fir_poly_lds(ntaps, dsr, &ncols);
+        if (fir_poly_fits(ntaps, dsr)) {
             // (Tiles of 512 outputs on 128 threads -- half the LDS, twice the independent workgroups per CU, the same waves -- measured
             //  the same as 1024 on 256 with one tile per workgroup: 55.8 / 56.1 us for 2^24 int16 samples, 64 taps, dsr 4
             //  (profiles/r05/ab_fir_poly_nt.log).)
