@@ -72,6 +72,10 @@ CAF_EXPORT int32_t caf_d2d(void* d_dst, const void* d_src, int64_t bytes, void* 
  * 1028-1039).  rows <= 65536.  (ABI 1.8) */
 CAF_EXPORT int32_t caf_d2h_transposed(void* h_dst, int32_t dst_f64, const float* d_src, int64_t rows, int64_t pitch,
                                       int64_t col0, int64_t ncols, void* stream);
+/* caf_d2h_f64: count float32 values on the device arrive as float64 on the host (widened by the staging lanes' host threads:
+ * the CPU signatures of the reference return float64 surfaces, xcorrRoutines.py:553-566, and NumPy's astype of a 17 GB download
+ * is a second pass over it).  (ABI 1.9) */
+CAF_EXPORT int32_t caf_d2h_f64(double* h_dst, const float* d_src, int64_t count, void* stream);
 CAF_EXPORT int32_t caf_stream_sync(void* stream);
 /* a non-blocking HIP stream of the current device for the `stream` arguments below (cupy.cuda.Stream(non_blocking=True)
  * of a cupy caller); NULL = the default stream everywhere */

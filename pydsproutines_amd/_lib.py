@@ -125,6 +125,7 @@ _SIGNATURES = {
     "caf_d2h": [_P, _P, _I64, _P],
     "caf_d2d": [_P, _P, _I64, _P],
     "caf_d2h_transposed": [_P, _I32, _P, _I64, _I64, _I64, _I64, _P],
+    "caf_d2h_f64": [_P, _P, _I64, _P],
     "caf_stream_sync": [_P],
     "caf_stream_create": [ct.POINTER(_P)],
     "caf_stream_destroy": [_P],

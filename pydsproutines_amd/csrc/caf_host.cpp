@@ -164,8 +164,26 @@ void tr_block(const float* src, int64_t sp, int64_t nr, int64_t nc, void* dst, i
         tr_block_scalar(src, sp, nr, nc, dst, dp, f64);
 }
 
+// float32 -> float64, n values
+__attribute__((target("avx2"))) void widen_block_avx2(const float* src, double* dst, int64_t n) {
+    int64_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        const __m256 v = _mm256_loadu_ps(src + i);
+        _mm256_storeu_pd(dst + i, _mm256_cvtps_pd(_mm256_castps256_ps128(v)));
+        _mm256_storeu_pd(dst + i + 4, _mm256_cvtps_pd(_mm256_extractf128_ps(v, 1)));
+    }
+    for (; i < n; ++i) dst[i] = (double)src[i];
+}
+void widen_block(const float* src, double* dst, int64_t n) {
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2)
+        widen_block_avx2(src, dst, n);
+    else
+        for (int64_t i = 0; i < n; ++i) dst[i] = (double)src[i];
+}
+
 // ---- one lane's share of a transfer ----------------------------------------------------------------------------------
-enum Kind { H2D, D2H, D2H_T };
+enum Kind { H2D, D2H, D2H_T, D2H_W };  // D2H_W: float32 device values arrive as float64 (lo / hi: byte range of the source)
 struct Job {
     Kind kind;
     char* h;        // host base (D2H_T: the [cols][rows] array)
@@ -194,7 +212,7 @@ int run_lane(int dev, Lane& l, hipEvent_t start, const Job& j) {
         return CAF_OK;
     }
     // D2H (plain or transposed): chunk i is in flight while chunk i - 1 is moved out of its slot
-    const int64_t unit = j.kind == D2H ? (int64_t)SLOT_BYTES : std::max<int64_t>(16, (int64_t)(SLOT_BYTES / 4 / j.rows) & ~(int64_t)15);
+    const int64_t unit = j.kind != D2H_T ? (int64_t)SLOT_BYTES : std::max<int64_t>(16, (int64_t)(SLOT_BYTES / 4 / j.rows) & ~(int64_t)15);
     int64_t pend_off = 0, pend_n = 0;
     int pend_k = -1;
     auto drain = [&]() -> int {
@@ -202,6 +220,8 @@ int run_lane(int dev, Lane& l, hipEvent_t start, const Job& j) {
         XFER_TRY(hipEventSynchronize(l.ev[pend_k]));
         if (j.kind == D2H)
             std::memcpy(j.h + pend_off, l.slot[pend_k], (size_t)pend_n);
+        else if (j.kind == D2H_W)
+            widen_block((const float*)l.slot[pend_k], (double*)(j.h + 2 * pend_off), pend_n / 4);
         else  // slot holds [rows][pend_n] -> host rows pend_off - col0 ...
             tr_block((const float*)l.slot[pend_k], pend_n, j.rows, pend_n,
                      j.h + (pend_off - j.col0) * j.rows * (j.f64 ? 8 : 4), j.rows, j.f64);
@@ -212,7 +232,7 @@ int run_lane(int dev, Lane& l, hipEvent_t start, const Job& j) {
     for (int i = 0; off < j.hi; ++i) {
         const int k = i & 1;
         const int64_t n = std::min<int64_t>(unit, j.hi - off);
-        if (j.kind == D2H)
+        if (j.kind != D2H_T)
             XFER_TRY(hipMemcpyAsync(l.slot[k], j.d + off, (size_t)n, hipMemcpyDeviceToHost, l.s));
         else
             XFER_TRY(hipMemcpy2DAsync(l.slot[k], (size_t)n * 4, j.d + off * 4, (size_t)j.pitch * 4, (size_t)n * 4, (size_t)j.rows,
@@ -296,6 +316,12 @@ int host_d2h(void* h_dst, const void* d_src, int64_t bytes, hipStream_t st) {
     }
     Job j{D2H, (char*)h_dst, (const char*)d_src, 0, bytes, 0, 0, 0, false};
     return transfer(j, bytes, 4096, st);
+}
+
+int host_d2h_f64(double* h_dst, const float* d_src, int64_t count, hipStream_t st) {
+    if (count <= 0) return CAF_OK;
+    Job j{D2H_W, (char*)h_dst, (const char*)d_src, 0, count * 4, 0, 0, 0, true};
+    return transfer(j, count * 8, 4096, st);
 }
 
 int host_d2h_transposed(void* h_dst, bool dst_f64, const float* d_src, int64_t rows, int64_t pitch, int64_t col0, int64_t ncols,

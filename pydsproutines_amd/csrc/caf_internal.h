@@ -65,6 +65,7 @@ inline int allow_dynamic_lds(const void* kernel, size_t bytes) {
 // pageable host memory <-> device through the library's own pinned staging lanes (caf_host.cpp); complete on return
 int host_h2d(void* d_dst, const void* h_src, int64_t bytes, hipStream_t st);
 int host_d2h(void* h_dst, const void* d_src, int64_t bytes, hipStream_t st);
+int host_d2h_f64(double* h_dst, const float* d_src, int64_t count, hipStream_t st);  // float32 on the device -> float64 on the host
 int host_d2h_transposed(void* h_dst, bool dst_f64, const float* d_src, int64_t rows, int64_t pitch, int64_t col0, int64_t ncols,
                         hipStream_t st);
 // blocking upload of host memory of any size (a caller's array, a std::vector about to be freed) on the null stream

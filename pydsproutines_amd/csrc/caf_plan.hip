@@ -248,7 +248,7 @@ int32_t caf_last_error(char* buf, int32_t len) {
     return CAF_OK;
 }
 
-int32_t caf_abi_version(void) { return (1 << 16) | 8; }  // minor: +1 per batch of added entry points
+int32_t caf_abi_version(void) { return (1 << 16) | 9; }  // minor: +1 per batch of added entry points
 
 int32_t caf_device_count(int32_t* count) {
     CAF_REQUIRE(count, "count is NULL");
@@ -303,6 +303,10 @@ int32_t caf_h2d(void* d_dst, const void* h_src, int64_t bytes, void* stream) {
 int32_t caf_d2h(void* h_dst, const void* d_src, int64_t bytes, void* stream) {
     CAF_REQUIRE(bytes >= 0 && (bytes == 0 || (h_dst && d_src)), "caf_d2h: bad arguments");
     return host_d2h(h_dst, d_src, bytes, (hipStream_t)stream);
+}
+int32_t caf_d2h_f64(double* h_dst, const float* d_src, int64_t count, void* stream) {
+    CAF_REQUIRE(count >= 0 && (count == 0 || (h_dst && d_src)), "caf_d2h_f64: bad arguments");
+    return host_d2h_f64(h_dst, d_src, count, (hipStream_t)stream);
 }
 int32_t caf_d2h_transposed(void* h_dst, int32_t dst_f64, const float* d_src, int64_t rows, int64_t pitch, int64_t col0,
                            int64_t ncols, void* stream) {

@@ -149,7 +149,20 @@ def _host_surface(plan, d_rx, lo, cnt, rel, dtype):
             _lib.check(lib.caf_d2h_transposed(out.ctypes.data, 1 if out.dtype == np.float64 else 0, ct.c_void_p(res.surface_t.ptr),
                                               F, cnt, c0, nc, None), "caf_d2h_transposed")
         return out if contiguous else out[rel]
+    # (the other engines: the delay-major surface is the reference's layout already; a contiguous run of delays is downloaded
+    #  straight into the result -- widened to float64 by the transfer lanes, caf_d2h_f64 -- instead of download + selection +
+    #  astype: three passes over what can be 17 GB)
     res = plan.run(d_rx, shift_start=lo, num_shifts=cnt, surface=True, rows=False, peak=False)
+    contiguous = rel.size > 0 and rel[-1] - rel[0] + 1 == rel.size and (rel.size == 1 or np.all(np.diff(rel) == 1))
+    if plan.T == 1 and contiguous and np.dtype(dtype) in (np.dtype(np.float32), np.dtype(np.float64)) \
+            and os.environ.get("CAF_HOST_SURFACE_DELAY_MAJOR") != "1":
+        out = np.empty((int(rel.size), F), dtype)
+        src = ct.c_void_p(res.surface.ptr + int(rel[0]) * F * 4)
+        if out.dtype == np.float64:
+            _lib.check(lib.caf_d2h_f64(out.ctypes.data, src, out.size, None), "caf_d2h_f64")
+        else:
+            _lib.check(lib.caf_d2h(out.ctypes.data, src, out.size * 4, None), "caf_d2h")
+        return out
     return res.surface.get()[0][rel].astype(dtype, copy=False)
 
 

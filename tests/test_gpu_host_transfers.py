@@ -50,6 +50,20 @@ def test_d2h_transposed_matches_numpy(rows, pitch, col0, ncols, f64):
     assert np.array_equal(out, want)
 
 
+@pytest.mark.parametrize("count", [1, 7, 1000, (1 << 20) + 3, (24 << 20) + 5])
+def test_d2h_f64_widens_on_the_way(count):
+    """caf_d2h_f64: float32 on the device, float64 on the host, through one lane and through several."""
+    from pydsproutines_amd.devarray import asarray
+
+    L, lib = _lib()
+    src = np.random.default_rng(count).standard_normal(count).astype(np.float32)
+    d = asarray(src)
+    out = np.full(count, np.nan)
+    L.check(lib.caf_d2h_f64(out.ctypes.data, ct.c_void_p(d.ptr), count, None))
+    assert np.array_equal(out, src.astype(np.float64))
+    assert lib.caf_d2h_f64(None, ct.c_void_p(d.ptr), count, None) == L.CAF_ERR_INVALID
+
+
 def test_d2h_transposed_rejects_bad_shapes():
     from pydsproutines_amd.devarray import empty
 
@@ -125,6 +139,44 @@ def test_host_surface_calls_ride_the_hypothesis_major_launch_bit_for_bit(monkeyp
     q32 = cy.xcorr(rx, sh32)
     res, rel = cy._run(rx, sh32, surface=True, rows=False, peak=False)
     assert q32.dtype == np.float32 and np.array_equal(q32, res.surface.get()[0][rel])
+
+
+def test_host_surface_calls_beyond_8192_samples_fill_their_result_in_one_pass(monkeypatch):
+    """Templates beyond 8192 samples run the chained roles, which write the reference's delay-major surface: a contiguous run of
+    delays is downloaded straight into the float64 result (caf_d2h_f64), a scattered selection takes the plain path; both are
+    the device surface's numbers exactly."""
+    import pydsproutines_amd.xcorrRoutines as X
+    from pydsproutines_amd import CAFPlan
+    from pydsproutines_amd.devarray import asarray
+
+    rng = np.random.default_rng(6)
+    n, m = 10_000, 90_000
+    cut, rx = qpsk(rng, n), cn(rng, m)
+    rx[30_000 : 30_000 + n] += cut * np.exp(2j * np.pi * 0.0002 * np.arange(n)).astype(np.complex64)
+    fs, f1, f2, step = 1000.0, -1.0, 1.0, 0.125
+    monkeypatch.setattr(X, "_CZTXCORR_FORCE_ROWS", False)
+    used = []
+    real = X._host_surface
+
+    def spy(plan, *a):
+        used.append((plan.engine_used, plan.block))
+        return real(plan, *a)
+
+    monkeypatch.setattr(X, "_host_surface", spy)
+    k = int((f2 - f1) / step + 1)
+    f_eval = f1 + np.arange(k) * ((f2 - f1 + step) / k)
+    for shifts in (None, np.arange(25_000, 35_000), np.array([3, 29_999, 30_000, 30_001, 79_000])):
+        got, freqs = X.cztXcorr(cut, rx, f1, f2, fs, step, outputCAF=True, shifts=shifts)
+        sh = np.arange(m - n + 1) if shifts is None else shifts
+        assert got.dtype == np.float64 and got.shape == (sh.size, k)
+        plan = CAFPlan(cut, max_rx_len=m, freqs_norm=f_eval / fs)
+        lo, cnt = int(sh.min()), int(sh.max() - sh.min() + 1)
+        ref = plan.run(asarray(rx), shift_start=lo, num_shifts=cnt, surface=True, rows=False, peak=False).surface.get()[0]
+        assert np.array_equal(got, ref[sh - lo].astype(np.float64))
+        plan.close()
+    assert used and all(u == ("persistent", 32768) for u in used)
+    pk = np.unravel_index(np.argmax(got), got.shape)
+    assert sh[pk[0]] == 30_000 and abs(freqs[pk[1]] - 0.2) <= step
 
 
 def test_cztxcorr_long_rows_three_calls_stay_fast(monkeypatch):
