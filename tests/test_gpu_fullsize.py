@@ -334,10 +334,11 @@ def test_c5_full_size_zoom(c2):
     assert more[0]["coarse_qf2"] >= more[1]["coarse_qf2"] >= more[2]["coarse_qf2"] > 0.0045
 
 
-@pytest.mark.parametrize("n", [16385, 32768])
+@pytest.mark.parametrize("n", [16385, 32768, 32769, 65536, 100000])
 def test_long_templates_full_size_on_the_chained_role(n):
     """Templates of 16385 / 32768 samples at the C2 shape (2^24-sample rx, 256 bins, full surface): 65536-point blocks in the
-    folded form, two work items (output residues) per block and hypothesis group -- planted (delay, bin) exact, sampled
+    folded form, two work items (output residues) per block and hypothesis group; 32769 / 65536 / 100000 samples: the same
+    blocks with the template in 2 / 2 / 4 partitions of 32768 samples -- planted (delay, bin) exact, sampled
     rows (block boundaries at multiples of 32768, tile boundaries, both ends) against the oracle, row results ==
     the surface written, agreement with the rocfft engine on the per-delay maxima."""
     from pydsproutines_amd import CAFPlan, asarray

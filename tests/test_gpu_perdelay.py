@@ -304,6 +304,39 @@ def _composite_cutout_checks(n):
     assert np.all(np.isnan(q)) and np.all(fi == 0) and np.all(np.isnan(pl))
 
 
+@pytest.mark.parametrize("n", [10007, 20011])
+def test_rows_path_for_lengths_no_kernel_takes(n):
+    """Primes beyond the Bluestein image (10007) and beyond one LDS image (20011): product rows (k_sliding_multiply in its long-row
+    form: four rows per workgroup, the row groups as the fast grid dimension) -> rocFFT rows -> argmax, against the oracle's
+    branch B for consecutive, strided and descending delays and with the zero rows of the out-of-range rule."""
+    from pydsproutines_amd import _lib
+
+    assert not _lib.load().caf_xcorr_perdelay_one_kernel(n)
+    rng = np.random.default_rng(n)
+    m = n + 400
+    rx = cn(rng, m)
+    d0, k0 = 37, n // 3
+    cut = (rx[d0 : d0 + n] * np.exp(-2j * np.pi * k0 * np.arange(n) / n)).astype(np.complex64)
+    rx = (rx + 0.05 * cn(rng, m)).astype(np.complex64)
+    tol = 2e-5
+    for start, step, num in ((0, 1, 61), (5, 3, 23), (390, -7, 50), (30, 1, 3)):
+        q, fi, _, _ = _perdelay(cut.conj(), rx, start, step, num)
+        sh = start + step * np.arange(num)
+        rq, rf = O.fastXcorr(cut, rx, freqsearch=True, shifts=sh)
+        assert np.max(np.abs(q - rq)) <= tol
+        diff = np.nonzero(fi != rf)[0]
+        if diff.size:  # float32 ties only (DESIGN 5)
+            rows = O.fastXcorr(cut, rx, freqsearch=True, outputCAF=True, shifts=sh[diff])
+            assert np.all(rows[np.arange(diff.size), fi[diff]] >= rows.max(axis=1) - 2 * tol)
+        if start == 0:
+            assert (int(np.argmax(q)), int(fi[np.argmax(q)])) == (d0, k0)
+    sh = np.arange(-6, 12)
+    q, fi, _, _ = _perdelay(cut.conj(), rx, -6, 1, sh.size, zero_oor=True)
+    assert np.all(q[sh < 0] == 0) and np.all(fi[sh < 0] == 0)
+    rq, _ = O.fastXcorr(cut, rx, freqsearch=True, shifts=sh[sh >= 0])
+    assert np.max(np.abs(q[sh >= 0] - rq)) <= tol
+
+
 def test_fused_equals_three_kernel_form():
     """The same calls through the path it replaces (rocFFT rows), in a child process because the switch is read once."""
     code = r"""
