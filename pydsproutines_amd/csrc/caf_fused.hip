@@ -776,10 +776,24 @@ __device__ __forceinline__ void fused_item2q(float2* __restrict__ s_d, const flo
 #define PQ_PBE 8
 #define PQ_PBO 4
 #endif
+#ifndef FQ_EO  // (the folded role without partitions / the plain chained role: build-time switches for A/B libraries)
+#define FQ_EO 8, 6, 2, 0
+#define FQ_EN 0, 0, 4, 4
+#define FQ_ON 4, 2, 2, 0
+#endif
+#ifndef CQ_EO
+#define CQ_EO 8, 4, 4, 0  // (round 4: {8,8,0,0} / {0,0,6,2} / {4,2,2,0}; A/B in profiles/r05/ab_quota_schedules.log: -2 % at 12000 and 16384 samples)
+#define CQ_EN 0, 0, 0, 4
+#define CQ_ON 4, 4, 4, 0
+#endif
     constexpr int QEO_P[4] = {PQ_EO}, QEN_P[4] = {PQ_EN}, QON_P[4] = {PQ_ON};
-    constexpr int QEO[4] = {PART ? QEO_P[0] : 8, PART ? QEO_P[1] : FOLD ? 6 : 8, PART ? QEO_P[2] : FOLD ? 2 : 0, PART ? QEO_P[3] : 0};
-    constexpr int QEN[4] = {PART ? QEN_P[0] : 0, PART ? QEN_P[1] : 0, PART ? QEN_P[2] : FOLD ? 4 : 6, PART ? QEN_P[3] : FOLD ? 4 : 2};
-    constexpr int QON[4] = {PART ? QON_P[0] : 4, PART ? QON_P[1] : 2, PART ? QON_P[2] : 2, PART ? QON_P[3] : 0};
+    constexpr int QEO_F[4] = {FQ_EO}, QEN_F[4] = {FQ_EN}, QON_F[4] = {FQ_ON};
+    constexpr int QEO_C[4] = {CQ_EO}, QEN_C[4] = {CQ_EN}, QON_C[4] = {CQ_ON};
+#define CAF_Q(T, i) (PART ? T##_P[i] : FOLD ? T##_F[i] : T##_C[i])
+    constexpr int QEO[4] = {CAF_Q(QEO, 0), CAF_Q(QEO, 1), CAF_Q(QEO, 2), CAF_Q(QEO, 3)};
+    constexpr int QEN[4] = {CAF_Q(QEN, 0), CAF_Q(QEN, 1), CAF_Q(QEN, 2), CAF_Q(QEN, 3)};
+    constexpr int QON[4] = {CAF_Q(QON, 0), CAF_Q(QON, 1), CAF_Q(QON, 2), CAF_Q(QON, 3)};
+#undef CAF_Q
     static_assert(QEO[0] + QEO[1] + QEO[2] + QEO[3] == 16 && QEN[0] + QEN[1] + QEN[2] + QEN[3] + QON[0] + QON[1] + QON[2] + QON[3] == 16, "quotas");
     float2 pro[16], prn[16];  // folded inputs: of the O half of the hypothesis in progress / of the next E half
     row_of(h0, hrow_o, hb_o);
