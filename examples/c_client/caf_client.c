@@ -110,6 +110,11 @@ int main(void) {
     CHECK(caf_stream_sync(NULL));
     printf("caf_client: device call  -> peak QF^2 %.4f at delay %d, bin %d\n", pv, (int)pd, (int)bins[pf]);
     int bad = !(pd == D0 && bins[pf] == K0 && pv > 0.8f && pv < 1.0f);
+    /* the per-delay maxima around the peak as float64 on the host (what the reference's CPU signatures return): widened by the
+     * download itself */
+    double trace[5];
+    CHECK(caf_d2h_f64(trace, (const float*)d_row_max + (D0 - 2), 5, NULL));
+    bad |= !(trace[2] == (double)pv && trace[1] < trace[2] && trace[3] < trace[2]);
 
     /* fine frequency around the peak: one call, +-1 bin in steps of 1/16 bin */
     int32_t nfine = 0;
