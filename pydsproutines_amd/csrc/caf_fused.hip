@@ -776,8 +776,8 @@ __device__ __forceinline__ void fused_item2q(float2* __restrict__ s_d, const flo
 #define PQ_EO 4, 4, 4, 4
 #define PQ_EN 0, 0, 0, 0
 #define PQ_ON 4, 4, 4, 4
-#define PQ_PBE 8
-#define PQ_PBO 4
+#define PQ_PBE 4  // (8 points in flight in front of the E half spill seven loop invariants, whose reloads inside the passes wait for the
+#define PQ_PBO 4  //  prefetches issued before them: 37.3 against 35.5 ms at two partitions; batches of 2 are as fast as 4: ab_partition_front_batches.log)
 #endif
 #ifndef FQ_EO  // (the folded role without partitions / the plain chained role: build-time switches for A/B libraries)
 #define FQ_EO 8, 6, 2, 0
@@ -789,14 +789,7 @@ __device__ __forceinline__ void fused_item2q(float2* __restrict__ s_d, const flo
 #define CQ_EN 0, 0, 0, 4
 #define CQ_ON 4, 4, 4, 0
 #endif
-#ifndef PQ_RIDE
-#define PQ_RIDE 0  // (measured: 54.3 against 36.9 ms at two partitions -- the four extra points in flight spill inside the passes, and a reload's
-                   //  s_waitcnt vmcnt waits for every prefetch issued before it; profiles/r05/ab_partition_ride.log)
-#endif
     constexpr int QEO_P[4] = {PQ_EO}, QEN_P[4] = {PQ_EN}, QON_P[4] = {PQ_ON};
-    constexpr bool RIDE = PART && PQ_RIDE != 0;  // (needs the schedule {4,4,4,4} / {0,0,0,0}: asserted below)
-    static_assert(!RIDE || (QEO_P[0] == 4 && QEO_P[1] == 4 && QEO_P[2] == 4 && QEO_P[3] == 4 && QEN_P[0] + QEN_P[1] + QEN_P[2] + QEN_P[3] == 0),
-                  "the riding partition uses batch slots 4 .. 7 one pass behind the points of partition 0");
     constexpr int QEO_F[4] = {FQ_EO}, QEN_F[4] = {FQ_EN}, QON_F[4] = {FQ_ON};
     constexpr int QEO_C[4] = {CQ_EO}, QEN_C[4] = {CQ_EN}, QON_C[4] = {CQ_ON};
 #define CAF_Q(T, i) (PART ? T##_P[i] : FOLD ? T##_F[i] : T##_C[i])
@@ -825,10 +818,6 @@ __device__ __forceinline__ void fused_item2q(float2* __restrict__ s_d, const flo
             constexpr int N0 = (PS > 0 ? QEN[0] : 0) + (PS > 1 ? QEN[1] : 0) + (PS > 2 ? QEN[2] : 0);
             issue(bx, bh, hrow_o, hb_o, caf_ic<1>{}, caf_ic<O0>{}, caf_ic<QEO[PS]>{}, lz);
             issue(bx + QEO[PS], bh + QEO[PS], hrow_n, hb_n, caf_ic<0>{}, caf_ic<N0>{}, caf_ic<QEN[PS]>{}, lz);
-            // PART: the O half's points of partition 1 ride in the E half's passes, one pass behind partition 0's (their place in
-            // pro exists by then), in the four batch slots the next E half's points do not take in this schedule
-            if constexpr (RIDE && PS >= 1)
-                issue_from(xp + (int64_t)ROW * 2, bx + 4, bh + 4, hrow_o + (int64_t)ROW * 2, hb_o, caf_ic<1>{}, caf_ic<4 * (PS - 1)>{}, caf_ic<4>{}, lz);
         } else {
             constexpr int N0 = QEN[0] + QEN[1] + QEN[2] + QEN[3] + (PS > 0 ? QON[0] : 0) + (PS > 1 ? QON[1] : 0) + (PS > 2 ? QON[2] : 0);
             issue(bx, bh, hrow_n, hb_n, caf_ic<0>{}, caf_ic<N0>{}, caf_ic<QON[PS]>{}, lz);
@@ -841,7 +830,6 @@ __device__ __forceinline__ void fused_item2q(float2* __restrict__ s_d, const flo
             constexpr int N0 = (PS > 0 ? QEN[0] : 0) + (PS > 1 ? QEN[1] : 0) + (PS > 2 ? QEN[2] : 0);
             fold(pro, bx, bh, hb_o, caf_ic<O0>{}, caf_ic<QEO[PS]>{}, caf_ic<0>{});
             fold(prn, bx + QEO[PS], bh + QEO[PS], hb_n, caf_ic<N0>{}, caf_ic<QEN[PS]>{}, caf_ic<0>{});
-            if constexpr (RIDE && PS >= 1) fold(pro, bx + 4, bh + 4, hb_o, caf_ic<4 * (PS - 1)>{}, caf_ic<4>{}, caf_ic<1>{});
         } else {
             constexpr int N0 = QEN[0] + QEN[1] + QEN[2] + QEN[3] + (PS > 0 ? QON[0] : 0) + (PS > 1 ? QON[1] : 0) + (PS > 2 ? QON[2] : 0);
             fold(prn, bx, bh, hb_n, caf_ic<N0>{}, caf_ic<QON[PS]>{}, caf_ic<0>{});
@@ -850,54 +838,42 @@ __device__ __forceinline__ void fused_item2q(float2* __restrict__ s_d, const flo
     // PART: partitions 1 .. npart - 1 of the template (Z = sum_p X[blk + p] . Hc_p: a template of up to npart * 32768 samples as
     // npart spectra of 32768 samples each against the block spectra of the blocks that follow), added to the inputs of the
     // sub-transform about to start, which hold partition 0.  Fetched here with their latency exposed, in batches of what the
-    // registers leave: in front of the E half (e[] dead, pro empty) 8 points, in front of the O half 4 -- except the O half's
-    // first twelve points of partition 1, which rode in the E half's passes (RIDE, batch_issue).
+    // registers leave WITHOUT pushing loop invariants out of them: four points at a time (the batch size does not matter to the time --
+    // 2, 4: the same -- so the role is not waiting on these round trips but on what the L2 delivers).  (Letting partition 1's
+    // O-half points ride in the E half's passes, four more points in flight per pass, spills inside the passes, and a reload's
+    // s_waitcnt vmcnt waits for every prefetch issued before it: 54.3 against 36.9 ms at two partitions,
+    // profiles/r05/ab_partition_ride.log.)
     auto parts_ahead = [&](auto c_) __attribute__((always_inline)) {
         constexpr int cc = decltype(c_)::value;
         constexpr int PB = cc == 0 ? PQ_PBE : PQ_PBO;
+        static_assert(16 % PB == 0, "whole batches");
         float2* pr = cc == 0 ? prn : pro;
-        auto batch = [&](const float* xq, const float* hq, auto a0_) __attribute__((always_inline)) {
-            constexpr int a0 = decltype(a0_)::value;
-            float4 bx[PB], bh[PB];
-            uint32_t lq = 0;  // (an opaque zero: the batch's loads stay behind the fold of the batch before)
-            asm volatile("" : "+v"(lq));
-#pragma unroll
-            for (int k = 0; k < PB; ++k) {
-                const uint32_t a = (uint32_t)(a0 + k);
-                bx[k] = gld4(xq, ((uint32_t)cc * 16384u + 1024u * a + (uint32_t)tid + lq) << 4);
-                bh[k] = gld4(hq, ((uint32_t)cc * 16384u + ((1024u * a + hb_o) & 16383u) + lq) << 4);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int k = 0; k < PB; ++k) {
-                const int a = a0 + k;
-                const bool sw = ((1024u * (uint32_t)a + hb_o) & 16384u) != 0;
-                const float2 h1 = make_float2(sw ? bh[k].z : bh[k].x, sw ? bh[k].w : bh[k].y);
-                const float2 h2 = make_float2(sw ? bh[k].x : bh[k].z, sw ? bh[k].y : bh[k].w);
-                const float2 z1 = cmul(make_float2(bx[k].x, bx[k].y), h1);
-                const float2 z2 = cmul(make_float2(bx[k].z, bx[k].w), h2);
-                pr[a] = cadd(pr[a], R == 0 ? cadd(z1, z2) : csub(z1, z2));
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        int p = 1;
-        if constexpr (RIDE && cc == 1) {  // partition 1: points 12 .. 15 are what did not ride
-            static_assert(PB == 4, "the O half's batches are the riding partition's last four points");
-            batch(xp + (int64_t)ROW * 2, hrow_o + (int64_t)ROW * 2, caf_ic<12>{});
-            p = 2;
-        }
-        for (; p < npart; ++p) {
+        for (int p = 1; p < npart; ++p) {
             const float* xq = xp + (int64_t)p * ROW * 2;
             const float* hq = hrow_o + (int64_t)p * ROW * 2;
-            if constexpr (PB == 8) {
-                batch(xq, hq, caf_ic<0>{});
-                batch(xq, hq, caf_ic<8>{});
-            } else {
-                static_assert(PB == 4 || PB == 8, "batches of 4 or 8 points");
-                batch(xq, hq, caf_ic<0>{});
-                batch(xq, hq, caf_ic<4>{});
-                batch(xq, hq, caf_ic<8>{});
-                batch(xq, hq, caf_ic<12>{});
+#pragma unroll
+            for (int a0 = 0; a0 < 16; a0 += PB) {
+                float4 bx[PB], bh[PB];
+                uint32_t lq = 0;  // (an opaque zero: the batch's loads stay behind the fold of the batch before)
+                asm volatile("" : "+v"(lq));
+#pragma unroll
+                for (int k = 0; k < PB; ++k) {
+                    const uint32_t a = (uint32_t)(a0 + k);
+                    bx[k] = gld4(xq, ((uint32_t)cc * 16384u + 1024u * a + (uint32_t)tid + lq) << 4);
+                    bh[k] = gld4(hq, ((uint32_t)cc * 16384u + ((1024u * a + hb_o) & 16383u) + lq) << 4);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < PB; ++k) {
+                    const int a = a0 + k;
+                    const bool sw = ((1024u * (uint32_t)a + hb_o) & 16384u) != 0;
+                    const float2 h1 = make_float2(sw ? bh[k].z : bh[k].x, sw ? bh[k].w : bh[k].y);
+                    const float2 h2 = make_float2(sw ? bh[k].x : bh[k].z, sw ? bh[k].y : bh[k].w);
+                    const float2 z1 = cmul(make_float2(bx[k].x, bx[k].y), h1);
+                    const float2 z2 = cmul(make_float2(bx[k].z, bx[k].w), h2);
+                    pr[a] = cadd(pr[a], R == 0 ? cadd(z1, z2) : csub(z1, z2));
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     };
