@@ -718,7 +718,7 @@ __device__ __forceinline__ void fused_item2q(float2* __restrict__ s_d, const flo
     };
     // a batch: NP points a = A0 .. A0 + NP - 1 of parity CC, from row hrow / base hb, into bx / bh (lz: an opaque zero that
     // pins the loads behind their point of issue)
-    auto issue_from = [&](const float* xp, pt_t* bx, pt_t* bh, const float* hrow, uint32_t hb, auto cc_, auto a0_, auto np_, uint32_t lz) __attribute__((always_inline)) {
+    auto issue = [&](pt_t* bx, pt_t* bh, const float* hrow, uint32_t hb, auto cc_, auto a0_, auto np_, uint32_t lz) __attribute__((always_inline)) {
         constexpr int CC = decltype(cc_)::value, A0 = decltype(a0_)::value, NP = decltype(np_)::value;
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
@@ -732,9 +732,6 @@ __device__ __forceinline__ void fused_item2q(float2* __restrict__ s_d, const flo
                 bh[k] = ld2((const float2*)hrow, (uint32_t)CC * 16384u + hi + lz);
             }
         }
-    };
-    auto issue = [&](pt_t* bx, pt_t* bh, const float* hrow, uint32_t hb, auto cc_, auto a0_, auto np_, uint32_t lz) __attribute__((always_inline)) {
-        issue_from(xp, bx, bh, hrow, hb, cc_, a0_, np_, lz);
     };
     // ... folded into pr[A0 ..]: FOLD: G = (X1 H1 + X2 H2) or (X1 H1 - X2 H2) W_32^a; else X H
     // (PART: the sum over the template's partitions is formed before the twiddle W_32^a, which then waits for pass 1; ACC: the

@@ -1239,8 +1239,18 @@ int32_t caf_plan_execute_host(caf_plan p, const float* h_rx, int64_t rx_len, int
     CAF_REQUIRE(num_shifts >= 1, "num_shifts must be >= 1");
     const int T = p->T, F = p->F;
     float2* d_rx = nullptr;
-    caf_outputs o;
-    std::memset(&o, 0, sizeof(o));
+    caf_outputs2 o2;
+    std::memset(&o2, 0, sizeof(o2));
+    caf_outputs& o = o2.base;
+    // The surface goes to the host anyway: where the engine can write it hypothesis-major itself (persistent engine, 16384-point
+    // blocks: no |y|^2 tiles, no tile role -- 10.5 instead of 13.2 ms at config C2) that launch runs, and the transposition to the
+    // reference's (delays, frequencies) layout happens in the download (host_d2h_transposed): the same numbers bit for bit
+    // (tests/test_gpu_fullsize.py::test_c2_hypothesis_major_surface).  CAF_HOST_SURFACE_DELAY_MAJOR=1: the delay-major launch (A/B).
+    static const bool host_delay_major = [] {
+        const char* e = getenv("CAF_HOST_SURFACE_DELAY_MAJOR");
+        return e && atoi(e);
+    }();
+    const bool surf_t = h_surface && p->persistent && p->B == 16384 && F > 1 && F <= 65536 && !host_delay_major;
     std::vector<void*> owned;
     auto dalloc = [&](void** ptr, int64_t bytes) -> int {
         const int prc = pool_alloc(ptr, std::max<int64_t>(bytes, 16));  // cached across calls (caf_pool.hip)
@@ -1249,7 +1259,7 @@ int32_t caf_plan_execute_host(caf_plan p, const float* h_rx, int64_t rx_len, int
         return CAF_OK;
     };
     int rc = dalloc((void**)&d_rx, rx_len * 8);
-    if (!rc && h_surface) rc = dalloc((void**)&o.d_surface, (int64_t)T * num_shifts * F * 4);
+    if (!rc && h_surface) rc = dalloc((void**)(surf_t ? &o2.d_surface_t : &o.d_surface), (int64_t)T * num_shifts * F * 4);
     if (!rc && h_row_max) rc = dalloc((void**)&o.d_row_max, (int64_t)T * num_shifts * 4);
     if (!rc && h_row_arg) rc = dalloc((void**)&o.d_row_arg, (int64_t)T * num_shifts * 4);
     if (!rc && h_peak_val) rc = dalloc((void**)&o.d_peak_val, T * 4);
@@ -1264,7 +1274,7 @@ int32_t caf_plan_execute_host(caf_plan p, const float* h_rx, int64_t rx_len, int
     }
     // (host arrays travel through the library's pinned staging lanes, never as pinned user pages: caf_host.cpp)
     rc = host_h2d(d_rx, h_rx, rx_len * 8, nullptr);
-    if (!rc) rc = caf_plan_execute(p, reinterpret_cast<const float*>(d_rx), rx_len, shift_start, num_shifts, &o, nullptr);
+    if (!rc) rc = caf_plan_execute2(p, reinterpret_cast<const float*>(d_rx), rx_len, shift_start, num_shifts, &o2, nullptr);
     if (rc) {
         cleanup();
         return rc;
@@ -1273,7 +1283,13 @@ int32_t caf_plan_execute_host(caf_plan p, const float* h_rx, int64_t rx_len, int
     auto back = [&](void* h, const void* dptr, int64_t bytes) {
         if (!rc && h) rc = host_d2h(h, dptr, bytes, nullptr);
     };
-    back(h_surface, o.d_surface, (int64_t)T * num_shifts * F * 4);
+    if (surf_t) {
+        for (int t = 0; t < T && !rc; ++t)
+            rc = host_d2h_transposed(h_surface + (int64_t)t * num_shifts * F, false, o2.d_surface_t + (int64_t)t * F * num_shifts, F,
+                                     num_shifts, 0, num_shifts, nullptr);
+    } else {
+        back(h_surface, o.d_surface, (int64_t)T * num_shifts * F * 4);
+    }
     back(h_row_max, o.d_row_max, (int64_t)T * num_shifts * 4);
     back(h_row_arg, o.d_row_arg, (int64_t)T * num_shifts * 4);
     back(h_peak_val, o.d_peak_val, T * 4);

@@ -1766,7 +1766,6 @@ static void launch_fir_decim(const TIn* x, int64_t n, float scale, const float* 
             // (Tiles of 512 outputs on 128 threads -- half the LDS, twice the independent workgroups per CU, the same waves -- measured
             //  the same as 1024 on 256 with one tile per workgroup: 55.8 / 56.1 us for 2^24 int16 samples, 64 taps, dsr 4
             //  (profiles/r05/ab_fir_poly_nt.log).)
-            const bool small = false;
             // resident workgroups: what the LDS holds per CU, at most 16 waves' worth of registers (CAF_FIR_POLY_WGS: per CU, A/B)
             static const int wgs_env = [] {
                 const char* e = getenv("CAF_FIR_POLY_WGS");
@@ -1778,7 +1777,6 @@ static void launch_fir_decim(const TIn* x, int64_t n, float scale, const float* 
                 (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev);
                 return c;
             }();
-            (void)small;
             const int64_t ntiles = cdiv(nout, FIRP_TILE);
             const int ept = (ncols * dsr + 255) / 256;
             // the grid is what is RESIDENT (tiles are dealt by striding: a workgroup that waits for a slot would start its share late)

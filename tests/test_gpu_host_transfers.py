@@ -179,6 +179,32 @@ def test_host_surface_calls_beyond_8192_samples_fill_their_result_in_one_pass(mo
     assert sh[pk[0]] == 30_000 and abs(freqs[pk[1]] - 0.2) <= step
 
 
+def test_plan_execute_host_rides_the_hypothesis_major_launch_bit_for_bit():
+    """caf_plan_execute_host (the blocking host-pointer call of INTEGRATION.md's stub): on the persistent engine with 16384-point
+    blocks the surface is produced hypothesis-major and transposed by the download; the arrays the caller receives are the
+    device call's delay-major ones exactly, for several templates, a sub-range of delays and together with rows and peaks."""
+    from pydsproutines_amd import CAFPlan
+    from pydsproutines_amd.devarray import asarray
+
+    rng = np.random.default_rng(8)
+    n, m, T = 700, 50_000, 3
+    tm = np.stack([qpsk(rng, n) for _ in range(T)])
+    rx = cn(rng, m)
+    for i, d in enumerate((1000, 20_000, 44_000)):
+        rx[d : d + n] += (tm[i] * np.exp(2j * np.pi * (i - 1) * np.arange(n) / 1024)).astype(np.complex64)
+    bins = np.arange(-3, 4)
+    plan = CAFPlan(tm, max_rx_len=m, bins=bins, grid=1024)
+    assert plan.engine_used == "persistent" and plan.block == 16384
+    for lo, cnt in ((0, None), (777, 30_001)):
+        host = plan.run_host(rx, shift_start=lo, num_shifts=cnt, surface=True, rows=True, peak=True)
+        dev = plan.run(asarray(rx), shift_start=lo, num_shifts=cnt, surface=True, rows=True, peak=True)
+        assert host["surface"].shape == dev.surface.shape
+        assert np.array_equal(host["surface"], dev.surface.get())
+        assert np.array_equal(host["row_max"], dev.row_max.get()) and np.array_equal(host["row_arg"], dev.row_arg.get())
+        assert np.array_equal(host["peak_delay"], dev.peak_delay.get()) and np.array_equal(host["peak_freq"], dev.peak_freq.get())
+    plan.close()
+
+
 def test_cztxcorr_long_rows_three_calls_stay_fast(monkeypatch):
     """Round 4's record (profiles/r04/timing_cztxcorr.log): the per-delay form with a 100000-sample cutout, 201 delays and 2001
     bins -- 102060-point CZT rows, a 3.2 MB result -- took 1-4 ms for two calls and then exactly 100 ms per call: the runtime had
