@@ -394,6 +394,32 @@ def test_template_lengths_around_the_fused_limits(n):
                 CAFPlan(t, max_rx_len=m, bins=bins, grid=grid, engine=engine)
 
 
+@pytest.mark.parametrize("n", [20000, 40000, 70000])
+def test_chained_roles_one_plan_many_rx_lengths(n):
+    """A plan sized for the longest rx it will see, run on shorter ones and on delay sub-ranges in any order (the partitioned role
+    reads the spectra of the blocks BEYOND a call's last one: they must be this call's, zero-padded past the end of its rx, not
+    what a longer call left behind): every call equals a plan created for exactly that rx."""
+    from pydsproutines_amd import CAFPlan, asarray
+
+    rng = np.random.default_rng(n)
+    t = qpsk(rng, n)
+    bins = np.arange(-2, 3)
+    big = n + 200_000
+    rx = cn(rng, big)
+    plan = CAFPlan(t, max_rx_len=big, bins=bins, grid=16384)
+    assert plan.engine_used == "persistent"
+    for m, lo, cnt in ((big, 0, None), (n + 70_000, 0, None), (n + 131_072, 5, 100_000), (n + 1, 0, None), (big, 150_000, 50_001),
+                       (n + 32_768, 0, None)):
+        d = asarray(rx[:m].copy())
+        got = plan.run(d, shift_start=lo, num_shifts=cnt, surface=True)
+        ref_plan = CAFPlan(t, max_rx_len=m, bins=bins, grid=16384)
+        ref = ref_plan.run(d, shift_start=lo, num_shifts=cnt, surface=True)
+        assert np.array_equal(got.surface.get(), ref.surface.get()), (m, lo, cnt)
+        assert np.array_equal(got.row_arg.get(), ref.row_arg.get()) and np.array_equal(got.peak_delay.get(), ref.peak_delay.get())
+        ref_plan.close()
+    plan.close()
+
+
 def test_long_template_explicit_frequencies_and_many_hypotheses():
     """32768-point blocks with an explicit frequency table (off-grid hypotheses, table mode) and more hypotheses than
     one work item takes, several templates: against the rocfft engine and the oracle."""
