@@ -734,11 +734,9 @@ __device__ __forceinline__ void fused_item2q(float2* __restrict__ s_d, const flo
         }
     };
     // ... folded into pr[A0 ..]: FOLD: G = (X1 H1 + X2 H2) or (X1 H1 - X2 H2) W_32^a; else X H
-    // (PART: the sum over the template's partitions is formed before the twiddle W_32^a, which then waits for pass 1; ACC: the
-    //  products are added to what the partitions fetched ahead of them have left in pr)
-    auto fold = [&](float2* pr, const pt_t* bx, const pt_t* bh, uint32_t hb, auto a0_, auto np_, auto acc_) __attribute__((always_inline)) {
+    // (PART: the sum over the template's partitions is formed before the twiddle W_32^a, which then waits for pass 1)
+    auto fold = [&](float2* pr, const pt_t* bx, const pt_t* bh, uint32_t hb, auto a0_, auto np_) __attribute__((always_inline)) {
         constexpr int A0 = decltype(a0_)::value, NP = decltype(np_)::value;
-        constexpr bool ACC = decltype(acc_)::value != 0;
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
             const int a = A0 + k;
@@ -750,8 +748,7 @@ __device__ __forceinline__ void fused_item2q(float2* __restrict__ s_d, const flo
                 const float2 z1 = cmul(make_float2(bx[k].x, bx[k].y), h1);
                 const float2 z2 = cmul(make_float2(bx[k].z, bx[k].w), h2);
                 if constexpr (PART) {
-                    const float2 dz = R == 0 ? cadd(z1, z2) : csub(z1, z2);
-                    pr[a] = ACC ? cadd(pr[a], dz) : dz;
+                    pr[a] = R == 0 ? cadd(z1, z2) : csub(z1, z2);
                 } else if (R == 0)
                     pr[a] = cadd(z1, z2);
                 else if (a == 0)
@@ -800,9 +797,9 @@ __device__ __forceinline__ void fused_item2q(float2* __restrict__ s_d, const flo
     {
         pt_t bx[8], bh[8];
         issue(bx, bh, hrow_o, hb_o, caf_ic<0>{}, caf_ic<0>{}, caf_ic<8>{}, 0u);
-        fold(prn, bx, bh, hb_o, caf_ic<0>{}, caf_ic<8>{}, caf_ic<0>{});
+        fold(prn, bx, bh, hb_o, caf_ic<0>{}, caf_ic<8>{});
         issue(bx, bh, hrow_o, hb_o, caf_ic<0>{}, caf_ic<8>{}, caf_ic<8>{}, 0u);
-        fold(prn, bx, bh, hb_o, caf_ic<8>{}, caf_ic<8>{}, caf_ic<0>{});
+        fold(prn, bx, bh, hb_o, caf_ic<8>{}, caf_ic<8>{});
     }
     float2 e[16];  // E's outputs (register 4 i + n4 <-> n3 = q + 4 i, n4)
     uint32_t hoff = 0;
@@ -825,11 +822,11 @@ __device__ __forceinline__ void fused_item2q(float2* __restrict__ s_d, const flo
         if constexpr (c == 0) {
             constexpr int O0 = (PS > 0 ? QEO[0] : 0) + (PS > 1 ? QEO[1] : 0) + (PS > 2 ? QEO[2] : 0);
             constexpr int N0 = (PS > 0 ? QEN[0] : 0) + (PS > 1 ? QEN[1] : 0) + (PS > 2 ? QEN[2] : 0);
-            fold(pro, bx, bh, hb_o, caf_ic<O0>{}, caf_ic<QEO[PS]>{}, caf_ic<0>{});
-            fold(prn, bx + QEO[PS], bh + QEO[PS], hb_n, caf_ic<N0>{}, caf_ic<QEN[PS]>{}, caf_ic<0>{});
+            fold(pro, bx, bh, hb_o, caf_ic<O0>{}, caf_ic<QEO[PS]>{});
+            fold(prn, bx + QEO[PS], bh + QEO[PS], hb_n, caf_ic<N0>{}, caf_ic<QEN[PS]>{});
         } else {
             constexpr int N0 = QEN[0] + QEN[1] + QEN[2] + QEN[3] + (PS > 0 ? QON[0] : 0) + (PS > 1 ? QON[1] : 0) + (PS > 2 ? QON[2] : 0);
-            fold(prn, bx, bh, hb_n, caf_ic<N0>{}, caf_ic<QON[PS]>{}, caf_ic<0>{});
+            fold(prn, bx, bh, hb_n, caf_ic<N0>{}, caf_ic<QON[PS]>{});
         }
     };
     // PART: partitions 1 .. npart - 1 of the template (Z = sum_p X[blk + p] . Hc_p: a template of up to npart * 32768 samples as
