@@ -138,8 +138,8 @@ typedef struct caf_plan_desc {
  *           FUSED up to 8192 samples; templates up to 16384 samples on 32768-point blocks, up to
  *           32768 on 65536-point blocks, up to 262144 on 65536-point blocks with the template cut into
  *           partitions of 32768 samples (bins mode: bins[f] * block / grid whole and even).  d_cqf:
- *           supported with 16384-point blocks as the ONLY output of a call (the FFT work items write
- *           the complex rows themselves).
+ *           supported as the ONLY output of a call (the FFT work items write the complex rows
+ *           themselves, on every block size of this engine).
  *   AUTO  : PERSISTENT when its conditions hold and log2_block is 0 or the engine's own, else ROCFFT. */
 #define CAF_ENGINE_AUTO 0
 #define CAF_ENGINE_ROCFFT 1

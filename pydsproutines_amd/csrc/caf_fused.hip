@@ -675,8 +675,10 @@ __device__ __forceinline__ void fused_item2q(float2* __restrict__ s_d, const flo
                                              const float2* __restrict__ hc,       // rows of the same shape, per template or per hypothesis (PART: npart consecutive rows each)
                                              const int32_t* __restrict__ shifts, const float2* __restrict__ tw1,
                                              int32_t table_mode, int32_t nfreq, int32_t nhyp, int blk, int h0, int h1,
-                                             int32_t tiles_per_blk, float* __restrict__ vt, int32_t npart = 1) {
+                                             int32_t tiles_per_blk, float* __restrict__ vt, int32_t npart = 1,
+                                             const F1Direct* __restrict__ f1 = nullptr) {  // MODE 4: the complex-QF rows (no tiles)
     static_assert(FOLD || R == 0, "the output residue exists in the folded form only");
+    static_assert(MODE == 1 || MODE == 4, "|y|^2 tiles (write-through) or complex-QF rows");
     static_assert(!FOLD || NVH == 0, "folded form: only the lower half of each residue's transform holds valid delays");
     static_assert(!PART || FOLD, "partitioned templates ride on the folded form");
     constexpr int ROW = FOLD ? 4 * FB : 2 * FB;  // float2 per row (block spectrum, template row)
@@ -698,6 +700,21 @@ __device__ __forceinline__ void fused_item2q(float2* __restrict__ s_d, const flo
     float* vt_blk = vt + (int64_t)blk * tiles_per_blk * nhyp * 64;
     const __amdgpu_buffer_rsrc_t rvt = buf_of(uniform_ptr(vt_blk), (uint32_t)tiles_per_blk * (uint32_t)nhyp * 256u);
     const int n1o = tid & 15, n2o = (tid >> 4) & 15, qo = tid >> 8;  // this thread's pass-4 position
+    // MODE 4 (TemplateCrossCorrelator.correlate, fastXcorr(absResult=False) beyond 8192 samples): the O half writes
+    // y sqrt(1 / E) sqrt(1 / ||t||^2) as complex64 into row h of the plane itself.  The energies of the block's delays do not fit
+    // the registers of this role: they are fetched per output (range-checked descriptor: 0 past the block's valid delays, where
+    // the row descriptor drops the store), from the L2 after the item's first hypothesis.
+    uint32_t f1_bytes = 0;
+    int64_t f1_rel0 = 0;
+    __amdgpu_buffer_rsrc_t rie = rvt, f1_r0 = rvt;
+    float f1_ts = 0.f;
+    if constexpr (MODE == 4) {
+        f1_rel0 = (int64_t)f1->blk_abs * f1->step;
+        int64_t nv = f1->num_shifts - f1_rel0;
+        if (nv > f1->step) nv = f1->step;
+        f1_bytes = (uint32_t)nv * 4u;
+        rie = buf_of(uniform_ptr(f1->inv_e + f1_rel0), f1_bytes);
+    }
     // template row of a hypothesis and this thread's base index into it: the shift in parity-major elements (= half the
     // block's shift); FOLD: mod 32768 -- bits 0..13 of 1024 a + hb select the pair, bit 14 swaps its halves
     const float* hrow_o;  // the row of the hypothesis in progress (its O half's inputs)
@@ -972,6 +989,20 @@ __device__ __forceinline__ void fused_item2q(float2* __restrict__ s_d, const flo
                                      : n4 == 2 ? mulj(y[2])
                                                : make_float2((-y[3].x - y[3].y) * R2, (y[3].x - y[3].y) * R2);
                     const float2 ylo = cadd(e[4 * i + n4], t);
+                    if constexpr (MODE == 4) {
+                        // delay of the output inside the block: k = tid + 1024 i + 4096 n4 (plain: + 16384 for the upper half; folded: 2 k + r)
+                        const uint32_t ku = 1024u * (uint32_t)i + 4096u * (uint32_t)n4;
+                        const uint32_t dv = FOLD ? 2u * (uint32_t)tid : (uint32_t)tid, du = FOLD ? 2u * ku + (uint32_t)R : ku;
+                        const float gq = __builtin_sqrtf(__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rie, (int)(dv << 2), (int)(du << 2), 0))) * f1_ts;
+                        const v2f_t ov = {ylo.x * gq, ylo.y * gq};
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i_t, ov), f1_r0, (int)(dv << 3), (int)(du << 3), CAF_AUX_NT);
+                        if (n4 < NVH) {
+                            const float2 yhi = csub(e[4 * i + n4], t);
+                            const float gh = __builtin_sqrtf(__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rie, (int)(dv << 2), (int)((du + 16384u) << 2), 0))) * f1_ts;
+                            const v2f_t oh = {yhi.x * gh, yhi.y * gh};
+                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i_t, oh), f1_r0, (int)(dv << 3), (int)((du + 16384u) << 3), CAF_AUX_NT);
+                        }
+                    } else {
                     const int tile_u = 16 * i + 64 * n4 + 256 * R;
                     const int tile_t = (n2o >> 2) + 4 * qo;
                     const uint32_t soff = (uint32_t)tile_u * (uint32_t)nhyp * 256u + hoff;  // uniform (scalar) offset
@@ -981,6 +1012,7 @@ __device__ __forceinline__ void fused_item2q(float2* __restrict__ s_d, const flo
                         const uint32_t voff_hi = voff + (((uint32_t)256 * (uint32_t)nhyp * 64u) << 2);
                         const float2 yhi = csub(e[4 * i + n4], t);
                         tile_store<MODE>(rvt, voff_hi, soff, __builtin_fmaf(yhi.x, yhi.x, yhi.y * yhi.y));
+                    }
                     }
                 }
             }
@@ -992,6 +1024,10 @@ __device__ __forceinline__ void fused_item2q(float2* __restrict__ s_d, const flo
     for (int h = h0; h < h1; ++h) {
         hoff = (uint32_t)h * 256u;  // bytes
         asm volatile("" : "+s"(hoff));
+        if constexpr (MODE == 4) {  // this hypothesis' row of the plane (2 floats per value) and its template's scale
+            f1_ts = __builtin_sqrtf(*((const CAF_AS4 float*)f1->tscale + h / nfreq));
+            f1_r0 = buf_of(uniform_ptr(f1->out0 + 2 * ((int64_t)h * f1->num_shifts + f1_rel0)), 2u * f1_bytes);
+        }
         row_of(h + 1 < h1 ? h + 1 : h, hrow_n, hb_n);
         sub(caf_ic<0>{});
         sub(caf_ic<1>{});
@@ -1846,7 +1882,20 @@ __device__ __attribute__((noinline)) void persistent_fft_item(lds_float2* s_d, c
 }
 
 // FFT role for 32768-point blocks (templates of 8193 .. 16384 samples): fused_item2q, same publish sequence
-template <int NVH>
+// (CQ: the complex-QF rows instead of the |y|^2 tiles -- PersistParams::cqf, no tile items)
+__device__ __forceinline__ void cq_params(const CAF_AS4 PersistParams* P, int blk, F1Direct& f1) {
+    f1.out0 = P->cqf;
+    f1.out1 = nullptr;
+    f1.partial = nullptr;
+    f1.ppt = 0;
+    f1.shift_start = 0;
+    f1.inv_e = P->inv_e;
+    f1.tscale = P->tscale;
+    f1.num_shifts = P->num_shifts;
+    f1.step = P->step;
+    f1.blk_abs = P->blk0 + blk;
+}
+template <int NVH, bool CQ>
 __device__ __attribute__((noinline)) void persistent_fft_item2(lds_float2* s_d, const lds_float2* s_tw2, const lds_float2* s_tw3,
                                                                const PersistParams* pp_in, int item_in) {
     const PersistParams* pp = uniform_ptr(pp_in);
@@ -1857,6 +1906,12 @@ __device__ __attribute__((noinline)) void persistent_fft_item2(lds_float2* s_d, 
     const int grp = item - blk * ngroups;
     const int h0 = grp * hyp_per_wg;
     const int h1 = min(h0 + hyp_per_wg, nhyp);
+    if constexpr (CQ) {
+        F1Direct f1;
+        cq_params(P, blk, f1);
+        fused_item2q<4, NVH, false, 0>((float2*)s_d, (const float2*)s_tw2, (const float2*)s_tw3, P->xb, P->hc, P->shifts, P->tw1,
+                                       P->table_mode, P->nfreq, nhyp, blk, h0, h1, P->tiles_per_blk, P->vt, 1, &f1);
+    } else
     fused_item2q<1, NVH, false, 0>((float2*)s_d, (const float2*)s_tw2, (const float2*)s_tw3, P->xb, P->hc, P->shifts, P->tw1, P->table_mode,
                                    P->nfreq, nhyp, blk, h0, h1, P->tiles_per_blk, P->vt);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1868,7 +1923,7 @@ __device__ __attribute__((noinline)) void persistent_fft_item2(lds_float2* s_d, 
 // FFT role for 65536-point blocks (templates of 16385 .. 32768 samples; fused_item2q<FOLD>): work item = (block, hypothesis group, output residue r), group
 // number = 2 * (hypothesis group) + r, same publish sequence.  PART: templates of 32769 .. npart * 32768 samples as npart partitions
 // (template-spectrum rows [spectrum][npart], block spectra of the npart blocks from the item's own on)
-template <int R, bool PART>
+template <int R, bool PART, bool CQ>
 __device__ __attribute__((noinline)) void persistent_fft_item2f(lds_float2* s_d, const lds_float2* s_tw2, const lds_float2* s_tw3,
                                                                 const PersistParams* pp_in, int item_in) {
     const PersistParams* pp = uniform_ptr(pp_in);
@@ -1879,6 +1934,12 @@ __device__ __attribute__((noinline)) void persistent_fft_item2f(lds_float2* s_d,
     const int grp = (item - blk * ngroups) >> 1;
     const int h0 = grp * hyp_per_wg;
     const int h1 = min(h0 + hyp_per_wg, nhyp);
+    if constexpr (CQ) {
+        F1Direct f1;
+        cq_params(P, blk, f1);
+        fused_item2q<4, 0, true, R, PART>((float2*)s_d, (const float2*)s_tw2, (const float2*)s_tw3, P->xb, P->hc, P->shifts, P->tw1,
+                                          P->table_mode, P->nfreq, nhyp, blk, h0, h1, P->tiles_per_blk, P->vt, PART ? P->npart : 1, &f1);
+    } else
     fused_item2q<1, 0, true, R, PART>((float2*)s_d, (const float2*)s_tw2, (const float2*)s_tw3, P->xb, P->hc, P->shifts, P->tw1, P->table_mode,
                                       P->nfreq, nhyp, blk, h0, h1, P->tiles_per_blk, P->vt, PART ? P->npart : 1);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -2013,23 +2074,25 @@ __global__ __launch_bounds__(1024) void k_caf_persistent(const PersistParams* __
         if (kind == 1) {
             if (__builtin_amdgcn_readfirstlane(params_of(pp)->block_log2) == 16) {
                 const bool odd_r = ((item - (item / params_of(pp)->ngroups) * params_of(pp)->ngroups) & 1) != 0;
-                if (__builtin_amdgcn_readfirstlane(params_of(pp)->npart) > 1) {
-                    if (odd_r)
-                        persistent_fft_item2f<1, true>((lds_float2*)s_d, (const lds_float2*)s_tw2, (const lds_float2*)s_tw3, pp, item);
-                    else
-                        persistent_fft_item2f<0, true>((lds_float2*)s_d, (const lds_float2*)s_tw2, (const lds_float2*)s_tw3, pp, item);
-                } else if (odd_r)
-                    persistent_fft_item2f<1, false>((lds_float2*)s_d, (const lds_float2*)s_tw2, (const lds_float2*)s_tw3, pp, item);
-                else
-                    persistent_fft_item2f<0, false>((lds_float2*)s_d, (const lds_float2*)s_tw2, (const lds_float2*)s_tw3, pp, item);
+                const bool part = __builtin_amdgcn_readfirstlane(params_of(pp)->npart) > 1, cq = params_of(pp)->cqf != nullptr;
+#define CAF_FFT_ROLE2F(RR, PP, CC) persistent_fft_item2f<RR, PP, CC>((lds_float2*)s_d, (const lds_float2*)s_tw2, (const lds_float2*)s_tw3, pp, item)
+                if (cq) {
+                    if (part) { if (odd_r) CAF_FFT_ROLE2F(1, true, true); else CAF_FFT_ROLE2F(0, true, true); }
+                    else { if (odd_r) CAF_FFT_ROLE2F(1, false, true); else CAF_FFT_ROLE2F(0, false, true); }
+                } else if (part) {
+                    if (odd_r) CAF_FFT_ROLE2F(1, true, false); else CAF_FFT_ROLE2F(0, true, false);
+                } else {
+                    if (odd_r) CAF_FFT_ROLE2F(1, false, false); else CAF_FFT_ROLE2F(0, false, false);
+                }
+#undef CAF_FFT_ROLE2F
             } else if (__builtin_amdgcn_readfirstlane(params_of(pp)->block_log2) == 15) {
                 const int tpb2 = __builtin_amdgcn_readfirstlane(params_of(pp)->tiles_per_blk);  // tiles >= 256: upper half
-                if (tpb2 <= 256)
-                    persistent_fft_item2<0>((lds_float2*)s_d, (const lds_float2*)s_tw2, (const lds_float2*)s_tw3, pp, item);
-                else if (tpb2 <= 384)
-                    persistent_fft_item2<2>((lds_float2*)s_d, (const lds_float2*)s_tw2, (const lds_float2*)s_tw3, pp, item);
-                else
-                    persistent_fft_item2<4>((lds_float2*)s_d, (const lds_float2*)s_tw2, (const lds_float2*)s_tw3, pp, item);
+                const bool cq = params_of(pp)->cqf != nullptr;
+#define CAF_FFT_ROLE2(NN, CC) persistent_fft_item2<NN, CC>((lds_float2*)s_d, (const lds_float2*)s_tw2, (const lds_float2*)s_tw3, pp, item)
+                if (tpb2 <= 256) { if (cq) CAF_FFT_ROLE2(0, true); else CAF_FFT_ROLE2(0, false); }
+                else if (tpb2 <= 384) { if (cq) CAF_FFT_ROLE2(2, true); else CAF_FFT_ROLE2(2, false); }
+                else { if (cq) CAF_FFT_ROLE2(4, true); else CAF_FFT_ROLE2(4, false); }
+#undef CAF_FFT_ROLE2
             }
             else {
                 // (kind of output) x (valid quarters of the block: tiles <= 128 / 192 / 256) -> one out-of-line role each

@@ -985,8 +985,8 @@ int32_t caf_plan_execute2(caf_plan p, const float* d_rx, int64_t rx_len, int64_t
         // complex QF rows: written by the FFT items of the one-launch engine themselves (fused_item MODE 4), as the only
         // output of the call
         const bool cqf_rows = out->d_cqf != nullptr;
-        CAF_REQUIRE(!cqf_rows || (p->persistent && p->B == 16384 && !out->d_surface && !out->d_row_max && !out->d_row_arg && !want_peak),
-                    "the in-LDS engines write the complex-QF plane only from the persistent 16384-point engine and only as the "
+        CAF_REQUIRE(!cqf_rows || (p->persistent && !out->d_surface && !out->d_row_max && !out->d_row_arg && !want_peak),
+                    "the in-LDS engines write the complex-QF plane only from the persistent engine and only as the "
                     "sole output of a call (create the plan with CAF_ENGINE_ROCFFT for the other combinations)");
         // No surface wanted (per-delay traces / peaks only): the FFT items keep running per-delay maxima and
         // write one (value, hypothesis) pair per delay and group instead of the |y|^2 tiles (1/32 of the

@@ -171,13 +171,13 @@ def _host_surface(plan, d_rx, lo, cnt, rel, dtype):
 # ------------------------------------------------------------------------------------------
 def _complex_qf_plan(templates, max_rx_len, grid):
     """The plan behind the complex-QF plane (`caf_outputs.d_cqf`: fastXcorr(absResult=False), TemplateCrossCorrelator.correlate):
-    the one-launch in-LDS engine writes it from its own work items -- with 16384-point blocks only, i.e. templates of up to
-    8192 samples (and not under the CAF_FUSED_LB15 / CAF_PERSISTENT switches) --, the rocFFT engine otherwise.  Decided from
-    the template length first, so that the common cases build ONE plan; the engine actually chosen is checked."""
+    the one-launch in-LDS engine writes it from its own work items -- 16384-point blocks up to 8192 samples, the chained roles
+    (32768- / 65536-point blocks, partitions) up to 262144 --, the rocFFT engine otherwise (and under the A/B switches that
+    take AUTO plans off the persistent engine).  The engine actually chosen is checked."""
     n = templates.shape[-1]
-    if n <= 8192:
+    if n <= 262144:
         plan = CAFPlan(templates, max_rx_len=max_rx_len, bins=[0], grid=grid)
-        if plan.engine_used == "persistent" and plan.block == 16384:
+        if plan.engine_used == "persistent":
             return plan
         plan.close()
     return CAFPlan(templates, max_rx_len=max_rx_len, bins=[0], grid=grid, engine="rocfft")

@@ -616,6 +616,43 @@ def test_kat4_template_cross_correlator(golden):
         both.correlate(x)
 
 
+@pytest.mark.parametrize("L", [8193, 12000, 16384, 16385, 30000, 32768, 40000, 70000])
+def test_template_cross_correlator_long_templates(L):
+    """Templates beyond 8192 samples: the complex-QF rows come from the chained roles of the one-launch engine themselves
+    (32768-point blocks, folded 65536-point blocks, partitions) -- against the restated class (xcorrRoutines.py:277-371), with
+    planted delays, the (value, template) maxima, and fastXcorr(absResult=False) for a cutout of the same length."""
+    from pydsproutines_amd import asarray
+    from pydsproutines_amd.xcorrRoutines import TemplateCrossCorrelator, fastXcorr, _complex_qf_plan
+
+    rng = np.random.default_rng(L)
+    T = 3
+    m = L + 75_000
+    x = cn(rng, m)
+    tm = np.stack([qpsk(rng, L) * (0.5 + i) for i in range(T)])
+    delays = [123, 40_000, 74_999]
+    for i, d in enumerate(delays):
+        x[d : d + L] += (tm[i] * (2.0 / (0.5 + i))).astype(np.complex64)
+    plan = _complex_qf_plan(tm, m, 1 << int(np.ceil(np.log2(L))))
+    assert plan.engine_used == "persistent" and plan.block == (32768 if L <= 16384 else 65536)
+    plan.close()
+    tcc = TemplateCrossCorrelator(asarray(tm), m)
+    z = tcc.correlate(asarray(x)).get()
+    ref = O.TemplateCrossCorrelator(tm, m).correlate(x)
+    assert z.shape == ref.shape == (T, m - L + 1) and z.dtype == np.complex64
+    assert np.max(np.abs(z - ref)) <= 2e-5
+    for i, d in enumerate(delays):
+        assert int(np.argmax(np.abs(z[i]))) == d and abs(abs(z[i][d]) - abs(ref[i][d])) <= 2e-5
+    v, ti = tcc.correlate(asarray(x), returnMax=True)
+    mag = np.sqrt(z.real.astype(np.float64) ** 2 + z.imag.astype(np.float64) ** 2).astype(np.float32)
+    np.testing.assert_array_equal(v.get(), mag.max(axis=0))
+    np.testing.assert_array_equal(ti.get(), np.argmax(mag, axis=0))
+    # branch A' of fastXcorr (conj of the others: vdot(rx, cutout)) on a sub-range of delays
+    sh = np.arange(39_990, 40_011)
+    a = fastXcorr(tm[1], x, shifts=sh, absResult=False)
+    ra = O.fastXcorr(tm[1], x, shifts=sh, absResult=False)
+    assert a.dtype == np.complex128 and np.max(np.abs(a - ra)) <= 2e-5
+
+
 # ---- kernel-level wrappers --------------------------------------------------------------------
 def test_sliding_product_and_multitemplate_kernels():
     from pydsproutines_amd import asarray
