@@ -142,6 +142,26 @@ def w_c3_complex_rows():
              "per 32 templates)", T * S * 8.0 + nblk * 8.0 * 16384 * (T / 32.0), nblk * T * (5.0 * 16384 * 14 + 6.0 * 16384 + 4.0 * tcc._plan.step), 2)]
 
 
+def w_c3_complex_rows_12000():
+    """The same call with 64 templates of 12000 samples: the plain chained role (32768-point blocks) writes the complex rows from its
+    O halves (fused_item2q MODE 4; 8 B written + 4 B of window energy read per value, block spectrum + template row re-read per sub-transform)."""
+    from pydsproutines_amd.xcorrRoutines import TemplateCrossCorrelator
+
+    T, L = 64, 12000
+    tm = keep("tcc12000_tm", lambda: np.stack([qpsk(rng, L) for _ in range(T)]))
+    _, d_rx = c2_inputs()
+    tcc = keep("tcc12000", lambda: TemplateCrossCorrelator(asarray(tm), M))
+    assert tcc._plan.engine_used == "persistent" and tcc._plan.block == 32768
+    for _ in range(2):
+        out = tcc.correlate(d_rx)
+    sync()
+    del out
+    Sn = M - L + 1
+    nblk = -(-Sn // tcc._plan.step)
+    return [("k_caf_persistent", "one-launch engine, T=64 F=1 N=12000 (B=32768 as 2 x 16384), complex QF rows",
+             T * Sn * 12.0 + nblk * T * 2 * 8.0 * 32768, nblk * T * (2 * 5.0 * 16384 * 14 + 6.0 * 32768 + 4.0 * tcc._plan.step), 2)]
+
+
 def w_c4_share():
     return caf("persistent", False, T=64, F=512, reps=1, rows=False)
 
