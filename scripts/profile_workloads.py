@@ -151,11 +151,11 @@ def w_c3_complex_rows_12000():
     tm = keep("tcc12000_tm", lambda: np.stack([qpsk(rng, L) for _ in range(T)]))
     _, d_rx = c2_inputs()
     tcc = keep("tcc12000", lambda: TemplateCrossCorrelator(asarray(tm), M))
-    assert tcc._plan.engine_used == "persistent" and tcc._plan.block == 32768
     for _ in range(2):
         out = tcc.correlate(d_rx)
     sync()
     del out
+    assert tcc._plan.engine_used == "persistent" and tcc._plan.block == 32768
     Sn = M - L + 1
     nblk = -(-Sn // tcc._plan.step)
     return [("k_caf_persistent", "one-launch engine, T=64 F=1 N=12000 (B=32768 as 2 x 16384), complex QF rows",
