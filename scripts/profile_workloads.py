@@ -144,7 +144,7 @@ def w_c3_complex_rows():
 
 def w_c3_complex_rows_12000():
     """The same call with 64 templates of 12000 samples: the plain chained role (32768-point blocks) writes the complex rows from its
-    O halves (fused_item2q MODE 4; 8 B written + 4 B of window energy read per value, block spectrum + template row re-read per sub-transform)."""
+    O halves (fused_item2q MODE 4; 8 B written per value; the window energies, block spectra and template rows are re-read from the L2)."""
     from pydsproutines_amd.xcorrRoutines import TemplateCrossCorrelator
 
     T, L = 64, 12000
@@ -159,7 +159,7 @@ def w_c3_complex_rows_12000():
     Sn = M - L + 1
     nblk = -(-Sn // tcc._plan.step)
     return [("k_caf_persistent", "one-launch engine, T=64 F=1 N=12000 (B=32768 as 2 x 16384), complex QF rows",
-             T * Sn * 12.0 + nblk * T * 2 * 8.0 * 32768, nblk * T * (2 * 5.0 * 16384 * 14 + 6.0 * 32768 + 4.0 * tcc._plan.step), 2)]
+             T * Sn * 8.0 + Sn * 4.0 + nblk * 8.0 * 32768 * (T / 32.0), nblk * T * (2 * 5.0 * 16384 * 14 + 6.0 * 32768 + 4.0 * tcc._plan.step), 2)]
 
 
 def w_c4_share():
