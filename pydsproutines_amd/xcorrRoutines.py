@@ -190,29 +190,45 @@ def fastXcorr(cutout, rx, freqsearch=False, outputCAF=False, shifts=None, absRes
     cutout = np.asarray(cutout)
     rx = np.asarray(rx)
     n = len(cutout)
-    if shifts is None:
-        shifts = np.arange(len(rx) - n + 1)
-    shifts = np.asarray(shifts)
-    ns = len(shifts)
-    if ns and (shifts.min() < 0 or shifts.max() + n > len(rx)):
-        raise ValueError("shifts must keep the cutout inside rx")
+    all_delays = shifts is None
+    if all_delays and not freqsearch:
+        # every delay, no frequency search (the reference's default call): no index array is built for a million delays -- the
+        # engine's range is the whole run and the result is downloaded straight into the array that is returned
+        ns = max(len(rx) - n + 1, 0)
+        shifts = None
+    else:
+        if all_delays:
+            shifts = np.arange(len(rx) - n + 1)
+        shifts = np.asarray(shifts)
+        ns = len(shifts)
+        if ns and (shifts.min() < 0 or shifts.max() + n > len(rx)):
+            raise ValueError("shifts must keep the cutout inside rx")
     d_rx = asarray(_c64(rx))
 
     if not freqsearch:
-        out = np.zeros(ns, dtype=np.float64 if absResult else np.complex128)
+        out = np.empty(ns, dtype=np.float64 if absResult else np.complex128)
         if ns == 0:
             return out
-        lo, cnt, rel = _engine_range(shifts)
-        # (the complex QF plane comes from the one-launch in-LDS engine's own work items for cutouts of up to 8192 samples --
-        #  fused_item MODE 4 -- and from the rocFFT engine beyond)
+        if shifts is None:
+            lo, cnt, rel = 0, ns, None
+        else:
+            lo, cnt, rel = _engine_range(shifts)
+            if cnt == ns and (ns == 1 or np.all(np.diff(rel) == 1)):
+                rel = None  # (a contiguous run in order)
+        # (the complex QF plane comes from the one-launch in-LDS engine's own work items -- fused_item MODE 4, the chained roles
+        #  beyond 8192 samples -- and from the rocFFT engine beyond 262144)
         grid = 1 << int(np.ceil(np.log2(max(n, 2))))
         plan = CAFPlan(_c64(cutout), max_rx_len=len(rx), bins=[0], grid=grid) if absResult else _complex_qf_plan(_c64(cutout), len(rx), grid)
-        res = plan.run(d_rx, shift_start=lo, num_shifts=cnt, rows=absResult, peak=False, cqf=not absResult)
+        res = plan.run(d_rx, shift_start=lo, num_shifts=cnt, rows="max" if absResult else False, peak=False, cqf=not absResult)
         if absResult:
-            out[:] = res.row_max.get()[0][rel]
+            if rel is None:  # float32 on the device -> the float64 result, widened by the download (caf_d2h_f64)
+                _lib.check(_lib.load().caf_d2h_f64(out.ctypes.data, ct.c_void_p(res.row_max.ptr), ns, None), "caf_d2h_f64")
+            else:
+                out[:] = res.row_max.get()[0][rel]
         else:
             # branch A' is sum(conj(rx) * cutout) (np.vdot order, :503): the conjugate of the engine's value
-            out[:] = np.conj(res.cqf.get()[0, 0][rel])
+            z = res.cqf.get()[0, 0]
+            np.conjugate(z if rel is None else z[rel], out=out)
         plan.close()
         return out
 
