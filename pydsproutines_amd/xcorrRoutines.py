@@ -50,21 +50,44 @@ def _c64(a):
 def _runs(shifts):
     """Split an index array into maximal arithmetic-progression runs: [(offset, start, step, count)]."""
     s = np.asarray(shifts, dtype=np.int64).reshape(-1)
-    out, i, n = [], 0, s.size
+    n = s.size
+    if n == 0:
+        return []
+    if n == 1:
+        return [(0, int(s[0]), 1, 1)]
+    d = np.diff(s)
+    if d[0] != 0 and np.all(d == d[0]):  # one progression (the usual call: a million delays cost a Python loop 125 ms)
+        return [(0, int(s[0]), int(d[0]), n)]
+    out, i = [], 0
     while i < n:
         if i + 1 >= n:
             out.append((i, int(s[i]), 1, 1))
             break
-        step = int(s[i + 1] - s[i])
-        j = i + 1
-        while j + 1 < n and int(s[j + 1] - s[j]) == step:
-            j += 1
+        step = int(d[i])
         if step == 0:
-            step = 1
-            j = i
+            out.append((i, int(s[i]), 1, 1))
+            i += 1
+            continue
+        brk = np.flatnonzero(d[i:] != step)  # the run ends in front of the first other difference
+        j = i + (int(brk[0]) if brk.size else n - 1 - i)
         out.append((i, int(s[i]), step, j - i + 1))
         i = j + 1
     return out
+
+
+def _host_take(d_row, rel, dtype):
+    """``d_row[rel]`` (a 1-D device array) as a host array of ``dtype``: a contiguous run in order is downloaded straight into the
+    result -- float32 widened to float64 by the transfer itself -- instead of download + fancy-index copy + ``astype``."""
+    rel = np.asarray(rel)
+    n = rel.size
+    if n and int(rel[-1]) - int(rel[0]) + 1 == n and (n == 1 or np.all(np.diff(rel) == 1)):
+        lo = int(rel[0])
+        if d_row.dtype == np.float32 and np.dtype(dtype) == np.float64:
+            out = np.empty(n, np.float64)
+            _lib.check(_lib.load().caf_d2h_f64(out.ctypes.data, ct.c_void_p(d_row.ptr + 4 * lo), n, None), "caf_d2h_f64")
+            return out
+        return d_row[lo : lo + n].get().astype(dtype, copy=False)
+    return d_row.get()[rel].astype(dtype, copy=False)
 
 
 def _perdelay(d_cut, n, d_rx, rx_len, start, step, num, zero_oor, want_qf2, want_idx, want_caf, want_ccaf,
@@ -224,7 +247,7 @@ def fastXcorr(cutout, rx, freqsearch=False, outputCAF=False, shifts=None, absRes
             if rel is None:  # float32 on the device -> the float64 result, widened by the download (caf_d2h_f64)
                 _lib.check(_lib.load().caf_d2h_f64(out.ctypes.data, ct.c_void_p(res.row_max.ptr), ns, None), "caf_d2h_f64")
             else:
-                out[:] = res.row_max.get()[0][rel]
+                out[:] = _host_take(res.row_max[0], rel, np.float64)
         else:
             # branch A' is sum(conj(rx) * cutout) (np.vdot order, :503): the conjugate of the engine's value
             z = res.cqf.get()[0, 0]
@@ -513,8 +536,8 @@ class GroupXcorr(_GroupEngine):
             mi = np.argmax(plane, axis=1)
             return plane[np.arange(mi.size), mi].astype(np.float64), self.freqs[mi]
         res, rel = self._run(rx, shifts + self._first, rows=True, peak=False)
-        xc = res.row_max.get()[0][rel].astype(np.float64)
-        return xc, self.freqs[res.row_arg.get()[0][rel]]
+        xc = _host_take(res.row_max[0], rel, np.float64)
+        return xc, self.freqs[_host_take(res.row_arg[0], rel, np.int32)]
 
 
 class GroupXcorrCZT(_GroupEngine):
@@ -594,7 +617,7 @@ class GroupXcorrFFT(_GroupEngine):
         shifts = self._shifts_for(rx, shifts)
         if flattenToTime:
             res, rel = self._run(rx, shifts + self._first, rows=True, peak=False)
-            return res.row_max.get()[0][rel].astype(np.float64), res.row_arg.get()[0][rel].astype(np.uint32)
+            return _host_take(res.row_max[0], rel, np.float64), _host_take(res.row_arg[0], rel, np.uint32)
         return self._surface_host(rx, shifts + self._first, np.float64)
 
     def xcorrThreads(self, rx, shifts=None, NUM_THREADS=4):
@@ -1025,7 +1048,7 @@ class GroupXcorrGPU(GroupXcorr):
         shifts = np.asarray(shifts)
         assert shifts.size % numShiftsPerBlk == 0
         res, rel = self._run(rx, shifts + self._first, rows=True, peak=False)
-        return res.row_max.get()[0][rel].astype(np.float32), res.row_arg.get()[0][rel].astype(np.int32)
+        return _host_take(res.row_max[0], rel, np.float32), _host_take(res.row_arg[0], rel, np.int32)
 
 
 class GroupXcorrCZT_Permutations:
