@@ -195,6 +195,8 @@ int launch_block_spectra(const float2* rx, int64_t rx_len, int64_t src0, int32_t
                          const int32_t* glen = nullptr, int32_t ngroups = 0);
 // the same for the 32768-point blocks of the chained role, written parity-major and butterfly-ordered ([block][2][16384])
 int launch_block_spectra32(const float2* rx, int64_t rx_len, int64_t src0, int32_t step, int64_t nblk, float2* xb2, hipStream_t st);
+// ... 65536-point blocks in the pair layout of the folded role (caf_perdelay.hip: k_block_spectra64)
+int launch_block_spectra64(const float2* rx, int64_t rx_len, int64_t src0, int32_t step, int64_t nblk, float2* xb2, hipStream_t st);
 
 // what caf_zoom_czt needs from a plan (caf_plan.hip)
 struct PlanZoomView {

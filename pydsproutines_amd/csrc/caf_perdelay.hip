@@ -491,6 +491,132 @@ int launch_block_spectra32(const float2* rx, int64_t rx_len, int64_t src0, int32
     return CAF_OK;
 }
 
+// ----------------------------------------------------------------------------------------
+// ... and for the 65536-point blocks of the folded role (templates of 16385 ... 262144 samples), in the layout fused_item2q<FOLD>
+// reads: [block][parity c][16384] PAIRS (P_c[m], P_c[m + 16384]), P_c[m] = X[2 m + c], pair m at (m & ~1023) + fp_tid_of(m & 1023).
+// Two decimation-in-frequency steps in registers, four 16384-point transforms per block: with n < 16384, x_q = x[n + 16384 q],
+//     X[4 m + 2 d + c] = DFT_16384( [ (x_0 + (-1)^c x_2) + (-1)^d (-j)^c (x_1 + (-1)^c x_3) ] e^{-j 2 pi (c + 2 d) n / 65536} )[m]
+// and P_c[2 m + d] = X[4 m + 2 d + c]: the transform (c, d) holds both members of the pairs with m = 2 m'' + d, m'' < 8192 (its
+// outputs m'' and m'' + 8192).  The samples of a block are read once per c (the second time from the L2).  Thread tid takes
+// the logical butterfly l whose outputs' pair positions run with the lane: bits of l = a fixed permutation of the bits of tid
+// (below), so that a wave writes four runs of 256 bytes per store.  Replaces k_gather_blocks + batched rocFFT + k_parity_pairs.
+// ----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_block_spectra64(const float2* __restrict__ rx, int64_t rx_len, int64_t src0,
+                                                          int32_t step, int64_t nblk, const float2* __restrict__ tw,
+                                                          float4* __restrict__ xb2) {
+    constexpr int LOGN = 14, N = 1 << LOGN, NTR = N / 16;
+    extern __shared__ __attribute__((aligned(16))) float2 s_bs[];
+    // e^{+j 2 pi t / 64}, t = 0 .. 63 (the part of the input twiddle that runs with the register: n = l + 1024 t)
+    const uint32_t u = threadIdx.x & 511u, hb = threadIdx.x >> 9;
+    // position bits (without bit 4, which is d): pos[3:0] = u[3:0], pos[5] = u[4], pos[9:6] = u[8:5]; the pair at that position
+    // has source m2 = fp_m2(pos) = 2 lambda + d:  lambda[6:5] = u[1:0], lambda[2:1] = u[3:2], lambda[0] = u[4], lambda[8:7] = u[6:5],
+    // lambda[4:3] = u[8:7]
+    const uint32_t lam = ((u & 3u) << 5) | (((u >> 2) & 3u) << 1) | ((u >> 4) & 1u) | (((u >> 5) & 3u) << 7) | (((u >> 7) & 3u) << 3);
+    const int l0 = (int)(lam + 512u * hb);
+    const uint32_t pos0 = (u & 15u) | (((u >> 4) & 1u) << 5) | ((u >> 5) << 6);  // + 16 d
+    float sn, cs;
+    sincospif((float)l0 * (1.0f / 32768.0f), &sn, &cs);  // e^{+j 2 pi l / 65536}
+    const float2 w1_0 = make_float2(cs, sn), w2_0 = cmul(w1_0, w1_0), w3_0 = cmul(w2_0, w1_0);
+    for (int64_t b = blockIdx.x; b < nblk; b += gridDim.x) {
+        int lo = l0;
+        asm volatile("" : "+v"(lo));  // (keeps the passes' addresses out of the block loop's invariants)
+        float2 w1 = w1_0, w2 = w2_0, w3 = w3_0;  // (... and the 48 products with the per-register constants: 96 registers hoisted otherwise)
+        asm volatile("" : "+v"(w1.x), "+v"(w1.y), "+v"(w2.x), "+v"(w2.y), "+v"(w3.x), "+v"(w3.y));
+        const int64_t s0 = src0 + b * step;
+        const bool inside = s0 + 4 * N <= rx_len;
+        const float2* p = rx + s0;  // (whole block inside rx: one 64-bit pointer, 32-bit offsets)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            // the inputs of the transforms (c, 0) and (c, 1) from one read of the block's four quarters (conjugated: the inverse
+            // butterflies deliver conj(DFT)); the second one waits in registers while the first is transformed
+            float2 v0[16], v1[16];
+            constexpr double TWO_PI = 6.283185307179586476925;
+            auto combine = [&](int t, float2 x0, float2 x1, float2 x2, float2 x3) __attribute__((always_inline)) {
+                float2 sv, rv;
+                if (c == 0) {
+                    sv = make_float2(x0.x + x2.x, -(x0.y + x2.y));
+                    rv = make_float2(x1.x + x3.x, -(x1.y + x3.y));
+                } else {
+                    sv = make_float2(x0.x - x2.x, -(x0.y - x2.y));
+                    const float2 q = make_float2(x1.x - x3.x, -(x1.y - x3.y));  // conj(x1 - x3)
+                    rv = make_float2(-q.y, q.x);                                // * (+j) = conj((-j)(x1 - x3))
+                }
+                // * e^{+j 2 pi (c + 2 d) (l + 1024 t) / 65536}
+                const float2 a0 = cadd(sv, rv), a1 = csub(sv, rv);
+                const int e0 = (c * t) & 63, e1 = ((c + 2) * t) & 63;
+                v0[t] = c == 0 ? a0 : cmul(a0, cmul(w1, make_float2((float)__builtin_cos(TWO_PI * e0 / 64.0), (float)__builtin_sin(TWO_PI * e0 / 64.0))));
+                v1[t] = a1;  // (its twiddle waits until the first transform is done: fewer values alive beside it)
+                (void)e1;
+            };
+            if (inside) {
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const int n = lo + t * NTR;
+                    combine(t, p[n], p[n + N], p[n + 2 * N], p[n + 3 * N]);
+                    if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // sixteen loads in flight, not sixty-four (registers)
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const int64_t i = s0 + lo + t * NTR;
+                    const float2 z = make_float2(0.f, 0.f);
+                    combine(t, i < rx_len ? rx[i] : z, i + N < rx_len ? rx[i + N] : z, i + 2 * N < rx_len ? rx[i + 2 * N] : z,
+                            i + 3 * N < rx_len ? rx[i + 3 * N] : z);
+                    if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // register (q, t) of a transformed array holds m'' = l + 1024 (q + 4 t); the pairs of transform (c, d): t = 0, 1 with t + 2
+            auto xform = [&](float2(&v)[16], uint32_t d) __attribute__((always_inline)) {
+                pd_fft<LOGN>(s_bs, tw, lo, v);
+                float4* o = xb2 + b * (int64_t)(2 * N) + (int64_t)c * N + pos0 + 16u * d;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float2 a = v[q * 4 + t], h = v[q * 4 + t + 2];  // (pd_out_index: r = q * RL + t, RL = 4)
+                        // m = 2 m'' + d = 2 lambda + d + 1024 hb + 2048 (q + 4 t): chunk hb + 2 (q + 4 t)
+                        o[1024 * ((int)hb + 2 * (q + 4 * t))] = make_float4(a.x, -a.y, h.x, -h.y);
+                    }
+                // (pd_fft's last pass ends with a barrier and writes nothing after it: the next transform may overwrite the image)
+            };
+            xform(v0, 0u);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int e1 = ((c + 2) * t) & 63;
+                v1[t] = cmul(v1[t], cmul(c == 0 ? w2 : w3, make_float2((float)__builtin_cos(TWO_PI * e1 / 64.0), (float)__builtin_sin(TWO_PI * e1 / 64.0))));
+            }
+            xform(v1, 1u);
+        }
+    }
+}
+
+int launch_block_spectra64(const float2* rx, int64_t rx_len, int64_t src0, int32_t step, int64_t nblk, float2* xb2, hipStream_t st) {
+    int dev = 0;
+    CAF_HIP_TRY(hipGetDevice(&dev));
+    const float2* tw = nullptr;
+    const int rc = lds_fft_twiddles(dev, &tw);
+    if (rc) return rc;
+    const size_t lds = (size_t)(16384 + 1024) * sizeof(float2);
+    static std::mutex mu;
+    static std::vector<char> attr_set;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if ((int)attr_set.size() <= dev) attr_set.resize(dev + 1, 0);
+        if (!attr_set[dev]) {
+            CAF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_block_spectra64),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set[dev] = 1;
+        }
+    }
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const unsigned grid = (unsigned)std::min<int64_t>(nblk, std::max(cus, 1));
+    if (grid == 0) return CAF_OK;
+    hipLaunchKernelGGL(k_block_spectra64, dim3(grid), dim3(1024), lds, st, rx, rx_len, src0, step, nblk, tw, reinterpret_cast<float4*>(xb2));
+    CAF_HIP_TRY(hipGetLastError());
+    return CAF_OK;
+}
+
 namespace {
 
 template <int LOGN>

@@ -951,9 +951,11 @@ int32_t caf_plan_execute2(caf_plan p, const float* d_rx, int64_t rx_len, int64_t
         if (aux) CAF_HIP_TRY(hipEventRecord(p->ev_join, p->s_aux));
     }
     const bool lds_fwd32 = p->fused && p->B == 32768 && !fwd_rocfft;
-    if (lds_fwd32) {
+    const bool lds_fwd64 = p->fused && p->B == 65536 && !fwd_rocfft;
+    if (lds_fwd32 || lds_fwd64) {
         p->stage_begin(2, st);
-        const int rc = launch_block_spectra32(rx, rx_len, shift_start, p->step, nfwd * p->fwd_chunk, p->d_xb2, st);
+        const int rc = lds_fwd32 ? launch_block_spectra32(rx, rx_len, shift_start, p->step, nfwd * p->fwd_chunk, p->d_xb2, st)
+                                 : launch_block_spectra64(rx, rx_len, shift_start, p->step, nfwd * p->fwd_chunk, p->d_xb2, st);
         p->stage_end(st);
         if (rc) return rc;
     } else if (lds_fwd) {
@@ -977,7 +979,7 @@ int32_t caf_plan_execute2(caf_plan p, const float* d_rx, int64_t rx_len, int64_t
     }
     if (p->fused && p->B == 32768 && !lds_fwd32)  // block spectra parity-major for the two chained half-transforms
         launch_parity_major(p->d_xb, p->d_xb2, nfwd * p->fwd_chunk, p->B / 2, st, true);
-    if (p->fused && p->B == 65536)  // ... as pairs of the two halves of each parity for the folded form
+    if (p->fused && p->B == 65536 && !lds_fwd64)  // ... as pairs of the two halves of each parity for the folded form
         launch_parity_pairs(p->d_xb, p->d_xb2, nfwd * p->fwd_chunk, p->B / 4, st);
     if (aux) CAF_HIP_TRY(hipStreamWaitEvent(st, p->ev_join, 0));
     bool f1_direct = false, f1_item_peaks = false;
