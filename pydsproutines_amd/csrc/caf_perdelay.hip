@@ -558,10 +558,13 @@ __global__ __launch_bounds__(1024) void k_block_spectra64(const float2* __restri
             } else {
 #pragma unroll
                 for (int t = 0; t < 16; ++t) {
-                    const int64_t i = s0 + lo + t * NTR;
-                    const float2 z = make_float2(0.f, 0.f);
-                    combine(t, i < rx_len ? rx[i] : z, i + N < rx_len ? rx[i + N] : z, i + 2 * N < rx_len ? rx[i + 2 * N] : z,
-                            i + 3 * N < rx_len ? rx[i + 3 * N] : z);
+                    // (the block runs past the end of rx: loads clamped to the last sample and zeroed by a select -- no branch per load)
+                    const int64_t i = s0 + lo + t * NTR, last = rx_len - 1;
+                    auto at = [&](int64_t j) {
+                        const float2 v = rx[j < last ? j : last];
+                        return j <= last ? v : make_float2(0.f, 0.f);
+                    };
+                    combine(t, at(i), at(i + N), at(i + 2 * N), at(i + 3 * N));
                     if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
                 }
             }
