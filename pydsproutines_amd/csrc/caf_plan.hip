@@ -594,7 +594,9 @@ static int32_t plan_build(caf_plan p, const caf_plan_desc* d) {
         }
         // 65536-point blocks: the role re-reads its block spectrum per sub-transform whatever the item size, and smaller items
         // keep fewer blocks (512 KB of spectrum each) in flight per XCD: 44.8 -> 43.5 ms at the C2 shape with 32 (16: 43.3)
-        if (lb == 16 && !getenv("CAF_HYP_PER_WG")) p->hyp_per_wg = std::min(p->hyp_per_wg, 32);
+        // (partitioned templates read npart block spectra and npart template rows per sub-transform: smaller items again -- 16
+        //  hypotheses at 2 .. 5 partitions (35.7 -> 34.9 ms at two, 59.1 -> 58.1 at four), 8 beyond (127.9 -> 120.8 ms at eight))
+        if (lb == 16 && !getenv("CAF_HYP_PER_WG")) p->hyp_per_wg = std::min(p->hyp_per_wg, p->npart >= 6 ? 8 : p->npart > 1 ? 16 : 32);
         // groups that do not straddle templates allow the no-surface mode (running maxima instead of tiles):
         // prefer the largest divisor of F that is not much smaller than the group size chosen above
         if (F % p->hyp_per_wg != 0)
